@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/s of the GDN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full training step of BASELINE.json's configs[1]: DtoD mode
+(AutoEncoder_DtoD forward, BerHu + 3*Sobel loss, backward, fused Adam), batch 20
+per GPU, 128x416, fp32, synthetic KITTI-shaped inputs resident in HBM.  With N>1
+each rank trains its own batch-20 shard and the gradient arena is all-reduced
+with RCCL (weak scaling).  Rank 0 prints ONE JSON line.
+
+The same line carries
+  roofline     -- the fused 3x3 512->512 convolution kernel (north_star) timed
+                  with HIP events on the launch stream: algorithmic FLOP / time
+                  against the fp32 MFMA peak (157.3 TFLOP/s);
+  cpu_baseline -- the CPU oracle (same step, reference semantics, torch CPU) on a
+                  bounded sample, N=1 rank 0 only.
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "gdn-pytorch_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+DTOD_TRAIN_GFLOP_PER_IMG = 1017.5
+
+
+def conv3x3_roofline(dev, B, level, reps=20):
+    """Fused 3x3 s1 512->512 conv + BN-stats epilogue at level 3 (16x52) or 4 (8x26)."""
+    from gdn_amd import ops
+    H, W = (16, 52) if level == 3 else (8, 26)
+    op = ops.Conv(512, 512, 3, 1, 1)
+    x = torch.randn(B, H, W, 512, device=dev)
+    w = torch.randn(9, 512, 512, device=dev) * 0.02
+    for _ in range(3):
+        op.fwd(x, w, stats=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()                      # torch's current stream == the stream the C ABI launches on
+    for _ in range(reps):
+        op.fwd(x, w, stats=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flop = 2.0 * B * H * W * 4608 * 512
+    return ms, flop
+
+
+def cpu_baseline(batch=2):
+    """The oracle's DtoD training step on the host cores, bounded sample."""
+    from oracle import gdn_oracle as O
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    sd = O.init_state_dict("AutoEncoder_DtoD", seed=0)
+    data = O.synthetic_batch(batch, 128, 416, seed=0)
+    st = {}
+    t0 = time.time()
+    O.train_step("DtoD", sd, data, st)
+    t1 = time.time()
+    O.train_step("DtoD", sd, data, st)
+    t2 = time.time()
+    dt = min(t1 - t0, t2 - t1)
+    return {"value": round(batch / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "2 DtoD train steps (fwd+loss+bwd+Adam) of the CPU oracle at batch %d, 128x416 fp32, best of 2; "
+                      "per-image work identical to the batch-20 GPU step" % batch}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=20, help="images per GPU")
+    ap.add_argument("--mode", default="DtoD", choices=["DtoD", "RtoD"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from gdn_amd import distributed as D
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import utils as U
+    from gdn_amd.optim import Adam
+    from gdn_amd.synthetic import synthetic_batch
+
+    rank, local_rank, world = D.init()
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    B = args.batch
+    depth, rgb, sparse = synthetic_batch(B, 128, 416, seed=rank, device=dev)
+
+    G = None
+    if args.mode == "DtoD":
+        model = M.AutoEncoder_DtoD(input_dim=1).to(dev)
+    else:
+        model = M.AutoEncoder_2(input_dim=3).to(dev)
+        torch.manual_seed(1)
+        G = M.AutoEncoder_DtoD(input_dim=1).to(dev).eval()
+    model.train()
+    opt = Adam(model.parameters(), 2e-5, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
+
+    def step():
+        if args.mode == "DtoD":
+            out = model(depth, istrain=False)
+            loss, _, _ = U.dtod_loss(out, depth, sparse)
+        else:
+            out = model(rgb, istrain=False)
+            with torch.no_grad():
+                ft_tar = G(depth, istrain=True)[:4]
+                ft = G(out, istrain=True)[:4]
+            pix, _, _ = U.rtod_pixel_loss(out, depth, rgb, sparse)
+            loss = pix + U.latent_loss(ft, ft_tar)
+        opt.zero_grad()
+        loss.backward()
+        D.sync_gradients(model, opt)
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = B * world * args.steps / dt
+        gflop_img = DTOD_TRAIN_GFLOP_PER_IMG if args.mode == "DtoD" else 1922.6
+        rec = {
+            "metric": "training images/sec at 128x416 batch=20",
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s training step (fwd + losses + bwd + fused Adam), batch %d per GPU, 128x416, "
+                                   "fp32, BASELINE configs[%d]" % (args.mode, B, 1 if args.mode == "DtoD" else 2),
+                       "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "model_tflops_per_gpu": round(gflop_img * B * args.steps / dt / 1e3, 2),
+                       "final_loss": round(final_loss, 6)},
+        }
+        if not args.no_roofline:
+            ms3, fl3 = conv3x3_roofline(dev, B, 3)
+            ms4, fl4 = conv3x3_roofline(dev, B, 4)
+            a3 = fl3 / (ms3 * 1e-3) / 1e12
+            rec["roofline"] = {
+                "kernel": "conv_igemm_f32 3x3 s1 512->512 + BN-stats epilogue, B=%d 16x52 (level 3)" % B,
+                "bound": "mfma", "achieved": round(a3, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(a3 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "gflop_per_launch": round(fl3 / 1e9, 2), "ms_per_launch": round(ms3, 4),
+                "level4_8x26": {"achieved": round(fl4 / (ms4 * 1e-3) / 1e12, 2),
+                                "frac": round(fl4 / (ms4 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                "gflop_per_launch": round(fl4 / 1e9, 2), "ms_per_launch": round(ms4, 4)},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

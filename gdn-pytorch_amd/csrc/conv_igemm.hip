@@ -1,0 +1,507 @@
+// Implicit-GEMM convolution for gfx950 (MI355X), exact fp32 on the matrix cores.
+//
+//   out[m][n] = sum_{tap, c} in[pix(m) (+) tap][c] * w[tap][n][c]
+//
+// One kernel serves every convolution-shaped op on the GDN hot path:
+//   * Conv2d forward, stride 1/2, zero or reflection padding (im2col-free: the
+//     A tile of a k-step is gathered straight from the NHWC activation, one
+//     filter tap and one 32-channel slab at a time, 128-B coalesced per pixel);
+//   * ConvTranspose2d forward and strided-conv data gradients as `stride^2`
+//     output phases in ONE launch (grid.y = phase), each phase a dense
+//     stride-1 gather over its own tap subset -- no zero-insertion;
+//   * concat-free 1x1 conv: reduction channels [0,C1) come from x, the rest from x2;
+//   * epilogue fusions: per-channel sum / sum-of-squares partials for train-mode
+//     BatchNorm, residual/gradient accumulation (addsrc), tanh.
+//
+// Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 256 FLOP/clk/CU).  A wave
+// owns TM x TN tiles of 32x32; a k-step is 32 reduction channels.  The MFMA
+// reduces over k in any order, so lane-half h takes channels [16h,16h+16) of
+// the slab: every fragment load is a 16-byte ds_read_b128 (4 k-substeps per
+// read) from an LDS image with a 36-float row pitch (conflict-free for the
+// 16-lane ds_read_b128 groups).  Global -> register -> LDS staging is split
+// (issue loads for k-step i+1, run the MFMAs of k-step i, then write LDS) so
+// HBM/L2 latency hides under the 2-4k MFMA cycles of a k-step.
+#include "common.h"
+
+#define MAX_TAPS 81
+#define MAX_PHASE 4
+#define KC 32
+#define LDS_LD 36
+
+struct IgemmPhase { int Ho, Wo, oy0, ox0, tap_begin, tap_end; };
+
+struct IgemmParams {
+    const float* x; const float* x2; const float* w; float* y; const float* addsrc; float* stats;
+    int B, Hi, Wi, C1, C2, ldx1, ldx2;
+    int N, ldy, ld_add, Hy, Wy, osy, osx;
+    int stride, pad_mode, act, nphase;
+    int Cred, w_tap_stride;
+    int grid_m, grid_n;
+    IgemmPhase ph[MAX_PHASE];
+    short tdy[MAX_TAPS], tdx[MAX_TAPS], twi[MAX_TAPS];
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALAR>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(TM >= 1 && TN >= 1, "tile");
+    constexpr int A_FLOATS = BM * LDS_LD, B_FLOATS = BN * LDS_LD;
+    __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS + 3 * BM];
+    float* As = smem;
+    float* Bs = smem + A_FLOATS;
+    int* row_pix = reinterpret_cast<int*>(smem + A_FLOATS + B_FLOATS);
+    int* row_out = row_pix + BM;
+    int* row_yx = row_out + BM;   // iy0 | ix0 << 16
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ph_i = blockIdx.y;
+    const IgemmPhase ph = p.ph[ph_i];
+
+    // XCD-aware tile order: blocks b, b+8, ... share an XCD (its L2); keep the
+    // N-tiles of one M-tile (same activation rows) on the same XCD, adjacent in time.
+    const int bid = blockIdx.x, xcd = bid & 7, q = bid >> 3;
+    const int nt = q % p.grid_n, mt = (q / p.grid_n) * 8 + xcd;
+    if (mt >= p.grid_m) return;
+    const int M = p.B * ph.Ho * ph.Wo;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int slot = ph_i * p.grid_m + mt;
+    if (m0 >= M) {
+        if (p.stats && tid < BN && n0 + tid < p.N) {
+            p.stats[((size_t)slot * 2 + 0) * p.N + n0 + tid] = 0.f;
+            p.stats[((size_t)slot * 2 + 1) * p.N + n0 + tid] = 0.f;
+        }
+        return;
+    }
+
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        if (m < M) {
+            const int ox = m % ph.Wo, t = m / ph.Wo, oy = t % ph.Ho, b = t / ph.Ho;
+            row_pix[r] = b * p.Hi * p.Wi;
+            row_yx[r] = (oy * p.stride) | ((ox * p.stride) << 16);
+            row_out[r] = (b * p.Hy + oy * p.osy + ph.oy0) * p.Wy + ox * p.osx + ph.ox0;
+        } else {
+            row_pix[r] = -1; row_yx[r] = 0; row_out[r] = -1;
+        }
+    }
+    __syncthreads();
+
+    const int ntap = ph.tap_end - ph.tap_begin;
+    const int nchunks = p.Cred / KC;
+    const int Ktot = ntap * p.Cred;
+    const int nk = SCALAR ? (Ktot + KC - 1) / KC : ntap * nchunks;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---------------- staging registers ----------------
+    constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;       // VEC: 8 threads x 16 B per row
+    constexpr int A_KP = 256 / BM > 0 ? 256 / BM : 1, A_E = KC / A_KP;   // SCALAR
+    constexpr int B_KP = 256 / BN > 0 ? 256 / BN : 1, B_E = KC / B_KP;
+    f32x4 ra[SCALAR ? 1 : A_PASSES], rb[SCALAR ? 1 : B_PASSES];
+    float sa[SCALAR ? A_E : 1], sb[SCALAR ? B_E : 1];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto gload = [&](int ks) {
+        if constexpr (!SCALAR) {
+            const int tl = ks / nchunks, cc = ks - tl * nchunks, t = ph.tap_begin + tl;
+            const int dy = p.tdy[t], dx = p.tdx[t], wi = p.twi[t];
+            const int ci0 = cc * KC;
+            const float* src; int ld, cb;
+            if (ci0 < p.C1) { src = p.x; ld = p.ldx1; cb = ci0; }
+            else { src = p.x2; ld = p.ldx2; cb = ci0 - p.C1; }
+            cb += (tid & 7) * 4;
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps) {
+                const int r = ps * 32 + (tid >> 3);
+                const int base = row_pix[r], yx = row_yx[r];
+                int iy = (yx & 0xffff) + dy, ix = (yx >> 16) + dx;
+                bool ok = base >= 0;
+                if (p.pad_mode == 1) { iy = reflect_idx(iy, p.Hi); ix = reflect_idx(ix, p.Wi); }
+                else ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+                ra[ps] = ok ? *reinterpret_cast<const f32x4*>(src + (size_t)(base + iy * p.Wi + ix) * ld + cb) : zero4;
+            }
+            const float* wsrc = p.w + (size_t)wi * p.w_tap_stride + ci0 + (tid & 7) * 4;
+#pragma unroll
+            for (int ps = 0; ps < B_PASSES; ++ps) {
+                const int n = n0 + ps * 32 + (tid >> 3);
+                rb[ps] = n < p.N ? *reinterpret_cast<const f32x4*>(wsrc + (size_t)n * p.Cred) : zero4;
+            }
+        } else {
+            {
+                const int r = tid % BM, kp = tid / BM;
+                const int base = row_pix[r], yx = row_yx[r];
+#pragma unroll
+                for (int e = 0; e < A_E; ++e) {
+                    const int kk = ks * KC + kp * A_E + e;
+                    float v = 0.f;
+                    if (kk < Ktot && base >= 0 && kp < A_KP) {
+                        const int tl = kk / p.Cred, ci = kk - tl * p.Cred, t = ph.tap_begin + tl;
+                        int iy = (yx & 0xffff) + p.tdy[t], ix = (yx >> 16) + p.tdx[t];
+                        bool ok = true;
+                        if (p.pad_mode == 1) { iy = reflect_idx(iy, p.Hi); ix = reflect_idx(ix, p.Wi); }
+                        else ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+                        if (ok) v = p.x[(size_t)(base + iy * p.Wi + ix) * p.ldx1 + ci];
+                    }
+                    sa[e] = v;
+                }
+            }
+            {
+                const int n = n0 + tid % BN, kp = tid / BN;
+#pragma unroll
+                for (int e = 0; e < B_E; ++e) {
+                    const int kk = ks * KC + kp * B_E + e;
+                    float v = 0.f;
+                    if (kk < Ktot && n < p.N && kp < B_KP) {
+                        const int tl = kk / p.Cred, ci = kk - tl * p.Cred, t = ph.tap_begin + tl;
+                        v = p.w[(size_t)p.twi[t] * p.w_tap_stride + (size_t)n * p.Cred + ci];
+                    }
+                    sb[e] = v;
+                }
+            }
+        }
+    };
+
+    auto lds_store = [&]() {
+        if constexpr (!SCALAR) {
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps)
+                *reinterpret_cast<f32x4*>(&As[(ps * 32 + (tid >> 3)) * LDS_LD + (tid & 7) * 4]) = ra[ps];
+#pragma unroll
+            for (int ps = 0; ps < B_PASSES; ++ps)
+                *reinterpret_cast<f32x4*>(&Bs[(ps * 32 + (tid >> 3)) * LDS_LD + (tid & 7) * 4]) = rb[ps];
+        } else {
+            if (tid / BM < A_KP) {
+#pragma unroll
+                for (int e = 0; e < A_E; ++e) As[(tid % BM) * LDS_LD + (tid / BM) * A_E + e] = sa[e];
+            }
+            if (tid / BN < B_KP) {
+#pragma unroll
+                for (int e = 0; e < B_E; ++e) Bs[(tid % BN) * LDS_LD + (tid / BN) * B_E + e] = sb[e];
+            }
+        }
+    };
+
+    const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 16;
+    const int b_off = (wn * TN * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 16;
+
+    gload(0);
+    lds_store();
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + 1 < nk) gload(ks + 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[a_off + i * 32 * LDS_LD + g * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(&Bs[b_off + j * 32 * LDS_LD + g * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (ks + 1 < nk) {
+            lds_store();
+            __syncthreads();
+        }
+    }
+
+    // ---------------- epilogue ----------------
+    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    const int col_l = lane & 31, rsh = 4 * (lane >> 5);
+    if (p.stats) {
+        float* red = As;  // [WAVES_M][BN][2], safe: all waves are past their last LDS read
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s1 += v; s2 += v * v; }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) {
+                const int c = wn * TN * 32 + j * 32 + lane;
+                red[(wm * BN + c) * 2 + 0] = s1;
+                red[(wm * BN + c) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int wmi = 0; wmi < WAVES_M; ++wmi) { s1 += red[(wmi * BN + tid) * 2]; s2 += red[(wmi * BN + tid) * 2 + 1]; }
+            p.stats[((size_t)slot * 2 + 0) * p.N + n0 + tid] = s1;
+            p.stats[((size_t)slot * 2 + 1) * p.N + n0 + tid] = s2;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + rsh;
+            const int op = row_out[row];
+            if (op < 0) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+                if (n < p.N) {
+                    float v = acc[i][j][r];
+                    if (p.addsrc) v += p.addsrc[(size_t)op * p.ld_add + n];
+                    if (p.act == GDN_ACT_TANH) v = tanhf(v);
+                    p.y[(size_t)op * p.ldy + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Host side: geometry -> phases / tap lists, tile selection, launch.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct TileCfg { int bm, bn; };
+// cfg ids: 1: 128x128  2: 128x64  3: 64x64  4: 128x32  (5: scalar-gather 128x64)
+const TileCfg kCfg[6] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 64}};
+
+int pick_cfg(int64_t M, int N, bool scalar, int forced) {
+    if (scalar) return 5;
+    if (forced >= 1 && forced <= 4) return forced;
+    if (N <= 32) return 4;
+    if (N <= 64) return 2;
+    const int64_t blocks128 = cdiv64(M, 128) * cdiv(N, 128);
+    return blocks128 < 512 ? 3 : 1;
+}
+
+// Builds the phase decomposition of a "transposed-type" gather:
+//   out[o] += in[(o + pp - k)/s] * w[k]  for taps with (o + pp - k) % s == 0.
+// Used by ConvTranspose2d forward and by Conv2d data gradients.
+void build_transposed_phases(IgemmParams& P, int k, int s, int pp, int Hout, int Wout, int B) {
+    P.nphase = s * s;
+    P.stride = 1;
+    P.osy = s; P.osx = s;
+    int nt = 0;
+    for (int a = 0; a < s; ++a)
+        for (int b = 0; b < s; ++b) {
+            IgemmPhase& ph = P.ph[a * s + b];
+            ph.oy0 = a; ph.ox0 = b;
+            ph.Ho = (Hout - a + s - 1) / s; ph.Wo = (Wout - b + s - 1) / s;
+            ph.tap_begin = nt;
+            for (int ky = 0; ky < k; ++ky) {
+                if (((a + pp - ky) % s + s) % s != 0) continue;
+                for (int kx = 0; kx < k; ++kx) {
+                    if (((b + pp - kx) % s + s) % s != 0) continue;
+                    // exact division (numerator is a multiple of s, may be negative)
+                    const int ny = a + pp - ky, nx = b + pp - kx;
+                    P.tdy[nt] = (short)(ny >= 0 ? ny / s : -((-ny) / s));
+                    P.tdx[nt] = (short)(nx >= 0 ? nx / s : -((-nx) / s));
+                    P.twi[nt] = (short)(ky * k + kx);
+                    ++nt;
+                }
+            }
+            ph.tap_end = nt;
+        }
+}
+
+void build_direct_phase(IgemmParams& P, int k, int s, int pad, int Ho, int Wo) {
+    P.nphase = 1;
+    P.stride = s;
+    P.osy = 1; P.osx = 1;
+    IgemmPhase& ph = P.ph[0];
+    ph.oy0 = 0; ph.ox0 = 0; ph.Ho = Ho; ph.Wo = Wo; ph.tap_begin = 0;
+    int nt = 0;
+    for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx) {
+            P.tdy[nt] = (short)(ky - pad); P.tdx[nt] = (short)(kx - pad); P.twi[nt] = (short)(ky * k + kx);
+            ++nt;
+        }
+    ph.tap_end = nt;
+}
+
+int64_t max_phase_m(const IgemmParams& P) {
+    int64_t m = 0;
+    for (int i = 0; i < P.nphase; ++i) {
+        const int64_t v = (int64_t)P.B * P.ph[i].Ho * P.ph[i].Wo;
+        if (v > m) m = v;
+    }
+    return m;
+}
+
+template <int BM, int BN, int WM, int WN, bool SC>
+void launch_one(const IgemmParams& P, hipStream_t st) {
+    const int gm_pad = cdiv(P.grid_m, 8) * 8;
+    dim3 grid((unsigned)(gm_pad * P.grid_n), (unsigned)P.nphase, 1);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, SC>), grid, dim3(256), 0, st, P);
+}
+
+int launch_igemm(IgemmParams& P, int cfg, hipStream_t st) {
+    const TileCfg tc = kCfg[cfg];
+    P.grid_m = (int)cdiv64(max_phase_m(P), tc.bm);
+    P.grid_n = cdiv(P.N, tc.bn);
+    switch (cfg) {
+        case 1: launch_one<128, 128, 2, 2, false>(P, st); break;
+        case 2: launch_one<128, 64, 2, 2, false>(P, st); break;
+        case 3: launch_one<64, 64, 2, 2, false>(P, st); break;
+        case 4: launch_one<128, 32, 4, 1, false>(P, st); break;
+        case 5: launch_one<128, 64, 2, 2, true>(P, st); break;
+        default: return GDN_ERR_BAD_ARG;
+    }
+    return gdn_launch_status();
+}
+
+bool geom_ok(const gdn_conv_geom* g) {
+    if (!g || g->B <= 0 || g->H <= 0 || g->W <= 0 || g->Cin <= 0 || g->Cout <= 0) return false;
+    if (g->k < 1 || g->k * g->k > MAX_TAPS || g->stride < 1 || g->stride > 2 || g->pad < 0) return false;
+    if (g->transposed && g->pad_mode != 0) return false;
+    if (g->pad_mode == 1 && (g->pad >= g->H || g->pad >= g->W)) return false;
+    return true;
+}
+
+__global__ void reflect_fold_kernel(const float* __restrict__ dxp, float* __restrict__ dx,
+                                    const float* __restrict__ addsrc, int ld_add, int ldx,
+                                    int B, int H, int W, int C, int p) {
+    // dx[y][x] = sum of dxp over the padded coordinates that reflect onto (y, x).
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    const int c4n = C / 4;
+    const int64_t total = (int64_t)B * H * W * c4n;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        int qy[3], qx[3], ny = 0, nx = 0;
+        qy[ny++] = y + p;
+        if (y >= 1 && y <= p) qy[ny++] = p - y;
+        if (y <= H - 2 && y >= H - 1 - p) qy[ny++] = 2 * (H - 1) - y + p;
+        qx[nx++] = x + p;
+        if (x >= 1 && x <= p) qx[nx++] = p - x;
+        if (x <= W - 2 && x >= W - 1 - p) qx[nx++] = 2 * (W - 1) - x + p;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a)
+            for (int e = 0; e < nx; ++e)
+                s += *reinterpret_cast<const f32x4*>(dxp + ((size_t)(b * Hp + qy[a]) * Wp + qx[e]) * C + c4 * 4);
+        const size_t op = (size_t)(b * H + y) * W + x;
+        if (addsrc) s += *reinterpret_cast<const f32x4*>(addsrc + op * ld_add + c4 * 4);
+        *reinterpret_cast<f32x4*>(dx + op * ldx + c4 * 4) = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int gdn_conv_out_dims(const gdn_conv_geom* g, int32_t* Ho, int32_t* Wo) {
+    if (!geom_ok(g)) return GDN_ERR_BAD_ARG;
+    if (g->transposed) {
+        *Ho = (g->H - 1) * g->stride - 2 * g->pad + g->k;
+        *Wo = (g->W - 1) * g->stride - 2 * g->pad + g->k;
+    } else {
+        *Ho = (g->H + 2 * g->pad - g->k) / g->stride + 1;
+        *Wo = (g->W + 2 * g->pad - g->k) / g->stride + 1;
+    }
+    return (*Ho > 0 && *Wo > 0) ? GDN_OK : GDN_ERR_BAD_ARG;
+}
+
+static int fill_fwd(const gdn_conv_geom* g, IgemmParams& P) {
+    int Ho, Wo;
+    if (gdn_conv_out_dims(g, &Ho, &Wo) != GDN_OK) return GDN_ERR_BAD_ARG;
+    P.B = g->B; P.Hi = g->H; P.Wi = g->W; P.N = g->Cout; P.Cred = g->Cin;
+    P.w_tap_stride = g->Cout * g->Cin;
+    P.Hy = Ho; P.Wy = Wo;
+    P.pad_mode = g->pad_mode;
+    if (g->transposed) build_transposed_phases(P, g->k, g->stride, g->pad, Ho, Wo, g->B);
+    else build_direct_phase(P, g->k, g->stride, g->pad, Ho, Wo);
+    return GDN_OK;
+}
+
+// Slot count written for the configuration the launcher picks.
+extern "C" int64_t gdn_conv_stats_slots(const gdn_conv_geom* g, int32_t tile_cfg) {
+    IgemmParams P{};
+    if (fill_fwd(g, P) != GDN_OK) return GDN_ERR_BAD_ARG;
+    const bool scalar = (g->Cin % KC) != 0;
+    const int cfg = pick_cfg(max_phase_m(P), g->Cout, scalar, tile_cfg);
+    return (int64_t)P.nphase * cdiv64(max_phase_m(P), kCfg[cfg].bm);
+}
+
+extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* x2, int32_t ldx2,
+                            int32_t C1, const float* w, float* y, int32_t ldy, const float* addsrc, int32_t ld_add,
+                            float* stats, int32_t act, int32_t tile_cfg, void* stream) {
+    if (!geom_ok(g) || !x || !w || !y) return GDN_ERR_BAD_ARG;
+    IgemmParams P{};
+    if (fill_fwd(g, P) != GDN_OK) return GDN_ERR_BAD_ARG;
+    const bool scalar = (g->Cin % KC) != 0;
+    if (x2 == nullptr) C1 = g->Cin;
+    if (C1 <= 0 || C1 > g->Cin) return GDN_ERR_BAD_ARG;
+    if (scalar && C1 != g->Cin) return GDN_ERR_UNSUPPORTED;
+    if (!scalar && ((C1 % KC) || (ldx % 4) || (x2 && (ldx2 % 4)))) return GDN_ERR_UNSUPPORTED;
+    P.x = x; P.x2 = x2; P.w = w; P.y = y; P.addsrc = addsrc; P.stats = stats;
+    P.C1 = C1; P.C2 = g->Cin - C1; P.ldx1 = ldx; P.ldx2 = ldx2; P.ldy = ldy; P.ld_add = ld_add; P.act = act;
+    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg);
+    return launch_igemm(P, cfg, (hipStream_t)stream);
+}
+
+extern "C" size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g) {
+    if (!geom_ok(g)) return 0;
+    if (!g->transposed && g->pad_mode == 1 && g->pad > 0)
+        return (size_t)g->B * (g->H + 2 * g->pad) * (g->W + 2 * g->pad) * g->Cin * sizeof(float);
+    return 0;
+}
+
+extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* wt, float* dx,
+                              int32_t ldx, const float* addsrc, int32_t ld_add, void* workspace,
+                              size_t workspace_bytes, int32_t tile_cfg, void* stream) {
+    if (!geom_ok(g) || !dy || !wt || !dx) return GDN_ERR_BAD_ARG;
+    int Ho, Wo;
+    if (gdn_conv_out_dims(g, &Ho, &Wo) != GDN_OK) return GDN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    IgemmParams P{};
+    P.B = g->B; P.Hi = Ho; P.Wi = Wo;             // the gathered tensor is dy
+    P.N = g->Cin; P.Cred = g->Cout; P.C1 = g->Cout; P.C2 = 0;
+    P.w_tap_stride = g->Cin * g->Cout;
+    P.x = dy; P.ldx1 = ldy; P.w = wt; P.pad_mode = 0; P.act = GDN_ACT_NONE;
+    const bool scalar = (g->Cout % KC) != 0;
+    if (!scalar && (ldy % 4)) return GDN_ERR_UNSUPPORTED;
+    const bool fold = !g->transposed && g->pad_mode == 1 && g->pad > 0;
+    if (g->transposed) {
+        // dx_T[i] = sum_k dy_T[i*s - p + k] w[k]: a plain strided gather over dy.
+        P.Hy = g->H; P.Wy = g->W;
+        build_direct_phase(P, g->k, g->stride, g->pad, g->H, g->W);
+        P.y = dx; P.ldy = ldx; P.addsrc = addsrc; P.ld_add = ld_add;
+    } else if (!fold) {
+        P.Hy = g->H; P.Wy = g->W;
+        build_transposed_phases(P, g->k, g->stride, g->pad, g->H, g->W, g->B);
+        P.y = dx; P.ldy = ldx; P.addsrc = addsrc; P.ld_add = ld_add;
+    } else {
+        const size_t need = gdn_conv_dgrad_workspace_bytes(g);
+        if (!workspace || workspace_bytes < need) return GDN_ERR_WORKSPACE;
+        if (g->Cin % 4) return GDN_ERR_UNSUPPORTED;
+        const int Hp = g->H + 2 * g->pad, Wp = g->W + 2 * g->pad;
+        P.Hy = Hp; P.Wy = Wp;
+        build_transposed_phases(P, g->k, g->stride, 0, Hp, Wp, g->B);
+        P.y = (float*)workspace; P.ldy = g->Cin; P.addsrc = nullptr; P.ld_add = 0;
+    }
+    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg);
+    int rc = launch_igemm(P, cfg, st);
+    if (rc != GDN_OK) return rc;
+    if (fold) {
+        const int64_t total = (int64_t)g->B * g->H * g->W * (g->Cin / 4);
+        const int blocks = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+        hipLaunchKernelGGL(reflect_fold_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dx, addsrc,
+                           ld_add, ldx, g->B, g->H, g->W, g->Cin, g->pad);
+        rc = gdn_launch_status();
+    }
+    return rc;
+}

@@ -1,0 +1,511 @@
+// HBM-bound glue kernels of the GDN hot path for gfx950: BatchNorm finalize /
+// apply / backward, x2 bilinear up-sampling, layout transforms, fused Adam.
+// All are 16-byte-per-lane streaming kernels (NHWC, channel count % 4 == 0).
+#include "common.h"
+
+namespace {
+
+inline int stream_blocks(int64_t n_items, int threads = 256, int cap = 2048) {
+    int64_t b = cdiv64(n_items, threads);
+    if (b < 1) b = 1;
+    return (int)(b < cap ? b : cap);
+}
+
+// ------------------------------------------------------------------ BN forward
+__global__ __launch_bounds__(256) void bn_finalize_train_kernel(
+    const float* __restrict__ stats, int64_t slots, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
+    float* scale, float* shift, float* mean_out, float* invstd_out) {
+    __shared__ double sh[8];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t s = threadIdx.x; s < slots; s += 256) {
+        s1 += (double)stats[(s * 2 + 0) * C + c];
+        s2 += (double)stats[(s * 2 + 1) * C + c];
+    }
+    s1 = block_sum_d256(s1, sh);
+    s2 = block_sum_d256(s2, sh + 4);
+    if (threadIdx.x == 0) {
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const float sc = (float)((double)g * invstd);
+        scale[c] = sc;
+        shift[c] = (float)((double)b - mean * (double)g * invstd);
+        if (mean_out) mean_out[c] = (float)mean;
+        if (invstd_out) invstd_out[c] = (float)invstd;
+        if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        if (running_var) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        }
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float inv = 1.0f / sqrtf(rv[c] + eps);
+    scale[c] = g * inv;
+    shift[c] = b - rm[c] * g * inv;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int ldy,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       const float* __restrict__ res, int ld_res,
+                                                       float* __restrict__ out, int ld_out, int64_t npix, int C,
+                                                       int relu) {
+    const int cq = C >> 2;
+    const int64_t total = npix * cq;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / cq;
+        const int c = (int)(i - pix * cq) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + pix * ldy + c);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(shift + c);
+        f32x4 o = v * s + t;
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        if (res) o += *reinterpret_cast<const f32x4*>(res + pix * ld_res + c);
+        *reinterpret_cast<f32x4*>(out + pix * ld_out + c) = o;
+    }
+}
+
+// ----------------------------------------------------------------- BN backward
+#define BNB_MAXBLK 1024
+// pass 1: partial[blk][2][C] = sum over the block's pixels of dz, dz*xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const float* __restrict__ dout, int ld_dout, const float* __restrict__ y, int ldy,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float* __restrict__ partial, int64_t npix, int C, int relu) {
+    __shared__ float sh[256 * 8];
+    const int cq = C >> 2;
+    const int CQ = cq < 256 ? cq : 256;      // channel-quad lanes
+    const int PY = 256 / CQ;                 // pixel lanes
+    const int tx = threadIdx.x % CQ, ty = threadIdx.x / CQ;
+    const int64_t per = cdiv64(npix, gridDim.x);
+    const int64_t p0 = blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
+    for (int q = tx; q < cq; q += CQ) {
+        const int c = q * 4;
+        f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+        if (ty < PY) {
+            const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c);
+            const f32x4 t = *reinterpret_cast<const f32x4*>(shift + c);
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+            const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+            for (int64_t pix = p0 + ty; pix < p1; pix += PY) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dout + pix * ld_dout + c);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(y + pix * ldy + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float dz = d[e];
+                    if (relu && !(v[e] * s[e] + t[e] > 0.f)) dz = 0.f;
+                    a1[e] += dz;
+                    a2[e] += dz * ((v[e] - mu[e]) * is[e]);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sh[threadIdx.x * 8 + e] = a1[e]; sh[threadIdx.x * 8 + 4 + e] = a2[e]; }
+        __syncthreads();
+        if (ty == 0) {
+            f32x4 r1 = {0.f, 0.f, 0.f, 0.f}, r2 = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < PY; ++j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { r1[e] += sh[(j * CQ + tx) * 8 + e]; r2[e] += sh[(j * CQ + tx) * 8 + 4 + e]; }
+            }
+            *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 0) * C + c) = r1;
+            *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 1) * C + c) = r2;
+        }
+    }
+}
+
+// pass 2: per-channel totals -> dgamma, dbeta, and the two means used by pass 3
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                              double count, float* dgamma, float* dbeta,
+                                                              float* k1, float* k2) {
+    __shared__ double sh[8];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        s1 += (double)partial[((size_t)b * 2 + 0) * C + c];
+        s2 += (double)partial[((size_t)b * 2 + 1) * C + c];
+    }
+    s1 = block_sum_d256(s1, sh);
+    s2 = block_sum_d256(s2, sh + 4);
+    if (threadIdx.x == 0) {
+        if (dbeta) dbeta[c] = (float)s1;
+        if (dgamma) dgamma[c] = (float)s2;
+        k1[c] = (float)(s1 / count);
+        k2[c] = (float)(s2 / count);
+    }
+}
+
+// pass 3: dy = gamma*invstd * (dz - mean(dz) - xhat*mean(dz*xhat))
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dout, int ld_dout, const float* __restrict__ y, int ldy,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ k1, const float* __restrict__ k2,
+    float* __restrict__ dy, int ld_dy, int64_t npix, int C, int relu) {
+    const int cq = C >> 2;
+    const int64_t total = npix * cq;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / cq;
+        const int c = (int)(i - pix * cq) * 4;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dout + pix * ld_dout + c);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + pix * ldy + c);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c);   // gamma*invstd
+        const f32x4 t = *reinterpret_cast<const f32x4*>(shift + c);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(k1 + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(k2 + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float dz = d[e];
+            if (relu && !(v[e] * s[e] + t[e] > 0.f)) dz = 0.f;
+            const float xh = (v[e] - mu[e]) * is[e];
+            o[e] = s[e] * (dz - a[e] - xh * b[e]);
+        }
+        *reinterpret_cast<f32x4*>(dy + pix * ld_dy + c) = o;
+    }
+}
+
+// ------------------------------------------------------------------- upsample
+__device__ __forceinline__ void up_src(int o, int in, int align, float& l1, int& i0, int& i1) {
+    float src;
+    if (align) {
+        const float sc = in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f;
+        src = sc * o;
+    } else {
+        src = 0.5f * (o + 0.5f) - 0.5f;
+        if (src < 0.f) src = 0.f;
+    }
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - i0;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int B, int H, int W, int C, int align) {
+    const int cq = C >> 2, Ho = 2 * H, Wo = 2 * W;
+    const int64_t total = (int64_t)B * Ho * Wo * cq;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cq) * 4;
+        int64_t t = i / cq;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float ly, lx; int y0, y1, x0, x1;
+        up_src(oy, H, align, ly, y0, y1);
+        up_src(ox, W, align, lx, x0, x1);
+        const float* xb = x + (size_t)b * H * W * C + c;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(xb + ((size_t)y0 * W + x0) * C);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(xb + ((size_t)y0 * W + x1) * C);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(xb + ((size_t)y1 * W + x0) * C);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(xb + ((size_t)y1 * W + x1) * C);
+        const f32x4 o = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        *reinterpret_cast<f32x4*>(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c) = o;
+    }
+}
+
+// Gather form of the adjoint (deterministic, no atomics): each input pixel sums
+// the <= 6x6 output pixels whose stencil touches it.
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                             int B, int H, int W, int C, int align) {
+    const int cq = C >> 2, Ho = 2 * H, Wo = 2 * W;
+    const int64_t total = (int64_t)B * H * W * cq;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cq) * 4;
+        int64_t t = i / cq;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const int b = (int)(t / H);
+        float wy[6], wx[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int oy = 2 * iy - 2 + j, ox = 2 * ix - 2 + j;
+            float l; int a0, a1;
+            wy[j] = 0.f; wx[j] = 0.f;
+            if (oy >= 0 && oy < Ho) { up_src(oy, H, align, l, a0, a1); if (a0 == iy) wy[j] += 1.f - l; if (a1 == iy) wy[j] += l; }
+            if (ox >= 0 && ox < Wo) { up_src(ox, W, align, l, a0, a1); if (a0 == ix) wx[j] += 1.f - l; if (a1 == ix) wx[j] += l; }
+        }
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jy = 0; jy < 6; ++jy) {
+            if (wy[jy] == 0.f) continue;
+            const int oy = 2 * iy - 2 + jy;
+#pragma unroll
+            for (int jx = 0; jx < 6; ++jx) {
+                if (wx[jx] == 0.f) continue;
+                const int ox = 2 * ix - 2 + jx;
+                s += (wy[jy] * wx[jx]) * *reinterpret_cast<const f32x4*>(dy + (((size_t)b * Ho + oy) * Wo + ox) * C + c);
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + (((size_t)b * H + iy) * W + ix) * C + c) = s;
+    }
+}
+
+// --------------------------------------------------------------------- layouts
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
+    const int64_t total = (int64_t)B * HW * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t t = i / C;
+        const int hw = (int)(t % HW);
+        const int b = (int)(t / HW);
+        y[i] = x[((size_t)b * C + c) * HW + hw];
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
+    const int64_t total = (int64_t)B * HW * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int hw = (int)(i % HW);
+        const int64_t t = i / HW;
+        const int c = (int)(t % C);
+        const int b = (int)(t / C);
+        y[i] = x[((size_t)b * HW + hw) * C + c];
+    }
+}
+
+// [ntaps][R][C] -> [ntaps][C][R], 32x32 LDS tiles
+__global__ __launch_bounds__(256) void transpose_taps_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                             int R, int C) {
+    __shared__ float tile[32][33];
+    const size_t tb = (size_t)blockIdx.z * R * C;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < C) tile[j][tx] = w[tb + (size_t)(r0 + j) * C + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < R) wt[tb + (size_t)(c0 + j) * R + r0 + tx] = tile[tx][j];
+}
+
+// torch [A][Bc][T] <-> tap-major [T][Cout][Cin]
+__global__ void weight_tapmajor_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin,
+                                       int T, int a_is_cout, int to_tap) {
+    const int64_t total = (int64_t)T * Cout * Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        const int64_t r = i / Cin;
+        const int co = (int)(r % Cout);
+        const int t = (int)(r / Cout);
+        const size_t ti = a_is_cout ? ((size_t)co * Cin + ci) * T + t : ((size_t)ci * Cout + co) * T + t;
+        if (to_tap) dst[i] = src[ti];
+        else dst[ti] = src[i];
+    }
+}
+
+// ------------------------------------------------------------------ elementwise
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(o)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+    for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        o[i] = a[i] + b[i];
+}
+__global__ void tanh_bwd_kernel(const float* __restrict__ d, const float* __restrict__ o, float* __restrict__ r, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        r[i] = d[i] * (1.f - o[i] * o[i]);
+}
+__global__ void fill_kernel(float* __restrict__ p, float v, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ------------------------------------------------------------------------ Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2s,
+                                                   float gscale) {
+    // torch.optim.Adam: g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+    // p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+    const float step = lr / bc1;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float pi = p[i];
+        const float gi = g[i] * gscale + wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = pi - step * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+
+}  // namespace
+
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int gdn_bn_finalize_train(const float* stats, int64_t slots, int32_t C, int64_t count, const float* gamma,
+                                     const float* beta, float* running_mean, float* running_var, float momentum,
+                                     float eps, float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    if (!stats || slots <= 0 || C <= 0 || count <= 0 || !scale || !shift) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(256), 0, ST(stream), stats, slots, C, (double)count,
+                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int32_t C, float* scale, float* shift,
+                                  void* stream) {
+    if (!running_mean || !running_var || C <= 0 || !scale || !shift) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST(stream), gamma, beta, running_mean,
+                       running_var, eps, C, scale, shift);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_bn_apply(const float* y, int32_t ldy, const float* scale, const float* shift, const float* residual,
+                            int32_t ld_res, float* out, int32_t ld_out, int64_t npix, int32_t C, int32_t relu,
+                            void* stream) {
+    if (!y || !scale || !shift || !out || npix <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
+    if ((C % 4) || (ldy % 4) || (ld_out % 4) || (residual && (ld_res % 4))) return GDN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, ST(stream), y, ldy, scale,
+                       shift, residual, ld_res, out, ld_out, npix, C, relu);
+    return gdn_launch_status();
+}
+
+static int bnb_blocks(int64_t npix) {
+    int64_t b = cdiv64(npix, 64);
+    if (b < 1) b = 1;
+    return (int)(b < BNB_MAXBLK ? b : BNB_MAXBLK);
+}
+
+extern "C" size_t gdn_bn_bwd_workspace_bytes(int64_t npix, int32_t C) {
+    return ((size_t)bnb_blocks(npix) * 2 * C + 2 * (size_t)C) * sizeof(float);
+}
+
+extern "C" int gdn_bn_bwd(const float* dout, int32_t ld_dout, const float* y, int32_t ldy, const float* gamma,
+                          const float* scale, const float* shift, const float* mean, const float* invstd, float* dy,
+                          int32_t ld_dy, float* dgamma, float* dbeta, int64_t npix, int32_t C, int32_t relu,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    (void)gamma;
+    if (!dout || !y || !scale || !shift || !mean || !invstd || !dy || npix <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
+    if ((C % 4) || (ldy % 4) || (ld_dout % 4) || (ld_dy % 4)) return GDN_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < gdn_bn_bwd_workspace_bytes(npix, C)) return GDN_ERR_WORKSPACE;
+    const int nblk = bnb_blocks(npix);
+    float* partial = (float*)workspace;
+    float* k1 = partial + (size_t)nblk * 2 * C;
+    float* k2 = k1 + C;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, ST(stream), dout, ld_dout, y, ldy, scale, shift,
+                       mean, invstd, partial, npix, C, relu);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, ST(stream), (const float*)partial, nblk, C,
+                       (double)npix, dgamma, dbeta, k1, k2);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, ST(stream), dout,
+                       ld_dout, y, ldy, scale, shift, mean, invstd, (const float*)k1, (const float*)k2, dy, ld_dy, npix,
+                       C, relu);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_upsample2x_fwd(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                                  int32_t align_corners, void* stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
+    if (C % 4) return GDN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(stream_blocks((int64_t)B * 4 * H * W * (C / 4))), dim3(256), 0,
+                       ST(stream), x, y, B, H, W, C, align_corners);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_upsample2x_bwd(const float* dy, float* dx, int32_t B, int32_t H, int32_t W, int32_t C,
+                                  int32_t align_corners, void* stream) {
+    if (!dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
+    if (C % 4) return GDN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(stream_blocks((int64_t)B * H * W * (C / 4))), dim3(256), 0,
+                       ST(stream), dy, dx, B, H, W, C, align_corners);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_nchw_to_nhwc(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+    if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_blocks((int64_t)B * C * H * W)), dim3(256), 0, ST(stream), x, y,
+                       B, C, H * W);
+    return gdn_launch_status();
+}
+extern "C" int gdn_nhwc_to_nchw(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+    if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(stream_blocks((int64_t)B * C * H * W)), dim3(256), 0, ST(stream), x, y,
+                       B, C, H * W);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_transpose_taps(const float* w, float* wt, int32_t ntaps, int32_t R, int32_t C, void* stream) {
+    if (!w || !wt || ntaps <= 0 || R <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(C, 32), cdiv(R, 32), ntaps), dim3(256), 0, ST(stream), w, wt, R,
+                       C);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_weight_to_tapmajor(const float* w_torch, float* w_tap, int32_t Cout, int32_t Cin, int32_t ntaps,
+                                      int32_t a_is_cout, void* stream) {
+    if (!w_torch || !w_tap || Cout <= 0 || Cin <= 0 || ntaps <= 0) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(weight_tapmajor_kernel, dim3(stream_blocks((int64_t)Cout * Cin * ntaps)), dim3(256), 0,
+                       ST(stream), w_torch, w_tap, Cout, Cin, ntaps, a_is_cout, 1);
+    return gdn_launch_status();
+}
+extern "C" int gdn_weight_from_tapmajor(const float* w_tap, float* w_torch, int32_t Cout, int32_t Cin, int32_t ntaps,
+                                        int32_t a_is_cout, void* stream) {
+    if (!w_torch || !w_tap || Cout <= 0 || Cin <= 0 || ntaps <= 0) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(weight_tapmajor_kernel, dim3(stream_blocks((int64_t)Cout * Cin * ntaps)), dim3(256), 0,
+                       ST(stream), w_tap, w_torch, Cout, Cin, ntaps, a_is_cout, 0);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n <= 0) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(add_kernel, dim3(stream_blocks(n / 4 + 1)), dim3(256), 0, ST(stream), a, b, out, n);
+    return gdn_launch_status();
+}
+extern "C" int gdn_tanh_bwd(const float* dout, const float* out, float* dpre, int64_t n, void* stream) {
+    if (!dout || !out || !dpre || n <= 0) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(stream_blocks(n)), dim3(256), 0, ST(stream), dout, out, dpre, n);
+    return gdn_launch_status();
+}
+extern "C" int gdn_fill(float* p, float value, int64_t n, void* stream) {
+    if (!p || n <= 0) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(fill_kernel, dim3(stream_blocks(n)), dim3(256), 0, ST(stream), p, value, n);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return GDN_ERR_BAD_ARG;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n, 256, 4096)), dim3(256), 0, ST(stream), p, g, m, v, n, lr,
+                       beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_version(void) { return 100; }
+
+extern "C" const char* gdn_strerror(int status) {
+    switch (status) {
+        case GDN_OK: return "ok";
+        case GDN_ERR_BAD_ARG: return "bad argument";
+        case GDN_ERR_UNSUPPORTED: return "unsupported shape/alignment";
+        case GDN_ERR_WORKSPACE: return "workspace missing or too small";
+        case GDN_ERR_LAUNCH: return "kernel launch failed";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int gdn_device_info(char* name, int name_len) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return GDN_ERR_LAUNCH;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return GDN_ERR_LAUNCH;
+    if (name && name_len > 0) {
+        int i = 0;
+        for (; i < name_len - 1 && prop.gcnArchName[i]; ++i) name[i] = prop.gcnArchName[i];
+        name[i] = 0;
+    }
+    return prop.multiProcessorCount;
+}

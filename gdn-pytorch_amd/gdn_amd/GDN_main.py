@@ -1,0 +1,102 @@
+"""Entry point with the reference's CLI: ``python -m gdn_amd.GDN_main DATA --mode {DtoD,RtoD,...}``.
+
+Mirrors GDN_main.py:22-307 of the reference for the hot path: same flags
+(option.py), same mode dispatch (:150-201), same optimiser settings
+(Adam, betas from --momentum/--beta, eps 1e-8, weight decay hard-wired to 5e-4,
+:157,173).  ``--gpu_num`` selects devices as in the reference when launched as a
+single process; under ``python -m torch.distributed.run`` each rank takes its
+LOCAL_RANK GPU and gradients are all-reduced with RCCL (nn.DataParallel is gone).
+
+The KITTI/NYU file pipeline (datasets_list.py / transform_list.py) is host I/O
+outside the hot path: pass ``--synthetic`` for KITTI-shaped random batches, or
+call ``run(args, train_loader, val_loader)`` with loaders that yield the
+reference's sample contract ``(gt[B,1,H,W], rgb[B,3,H,W], sparse[B,1,H,W])`` in [-1,1].
+"""
+import os
+import sys
+
+import torch
+
+from . import distributed as D
+from . import option
+from .AE_model_unet import AutoEncoder, AutoEncoder_2, AutoEncoder_DtoD
+from .optim import Adam
+from .synthetic import SyntheticLoader
+from .trainer import load_checkpoint, train_AE_DtoD, train_AE_RtoD, validate
+
+
+def _make_optimizer(model, args):
+    return Adam(model.parameters(), args.lr, [args.momentum, args.beta], eps=1e-08, weight_decay=5e-4)
+
+
+def run(args, train_loader=None, val_loader=None):
+    rank, local_rank, world = D.env_rank()
+    if world == 1 and "HIP_VISIBLE_DEVICES" not in os.environ and not torch.cuda.is_initialized():
+        os.environ["HIP_VISIBLE_DEVICES"] = args.gpu_num.split(",")[0]   # reference: CUDA_VISIBLE_DEVICES=--gpu_num
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible: the MI355X build has no CPU fallback")
+    rank, local_rank, world = D.init()
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(args.seed)          # identical init on every rank
+    H, W = args.height, args.width
+    if rank == 0:
+        print('=> number of GPU processes: ', world)
+        print("=> creating model")
+    if train_loader is None:
+        if not args.synthetic:
+            raise RuntimeError("the dataset file pipeline is outside this build's scope; use --synthetic or "
+                               "call run(args, train_loader, val_loader)")
+        steps = args.epoch_size or 100
+        train_loader = SyntheticLoader(args.batch_size, steps, H, W, seed=args.seed + rank, device=dev)
+        val_loader = SyntheticLoader(args.batch_size, 2, H, W, seed=args.seed + 1000 + rank, device=dev)
+    if args.epoch_size == 0:
+        args.epoch_size = len(train_loader)
+    args.local_rank = local_rank
+    logger = object() if args.evaluate else None     # reference: validation only when --evaluate
+
+    if args.mode == 'DtoD':
+        G = AutoEncoder_DtoD(norm=args.norm, input_dim=1, height=H, width=W).to(dev)
+        opt = _make_optimizer(G, args)
+        loss = train_AE_DtoD(args, G, None, None, opt, train_loader, val_loader, args.batch_size, args.epochs,
+                             args.lr, logger, None)
+        if rank == 0 and loss is not None:
+            print('Final loss:', loss.item())
+        return loss
+    if args.mode in ('RtoD', 'RtoD_single'):
+        G = None
+        if args.mode == 'RtoD':
+            G = AutoEncoder_DtoD(norm=args.norm, input_dim=1, height=H, width=W).to(dev)
+            if os.path.exists(args.model_dir):
+                load_checkpoint(G, args.model_dir)
+            elif rank == 0:
+                print("=> no guide checkpoint at %s: using a randomly initialised guide" % args.model_dir)
+            G.eval()
+        R = AutoEncoder_2(norm=args.norm, input_dim=3, height=H, width=W).to(dev)
+        opt = _make_optimizer(R, args)
+        return train_AE_RtoD(args, R, G, None, None, opt, train_loader, val_loader, args.batch_size, args.epochs,
+                             args.lr, logger, None)
+    if args.mode in ('DtoD_test', 'RtoD_test'):
+        if args.mode == 'DtoD_test':
+            model = AutoEncoder_DtoD(norm=args.norm, input_dim=1, height=H, width=W).to(dev)
+            ckpt = args.model_dir
+        else:
+            model = AutoEncoder(norm=args.norm, height=H, width=W).to(dev)
+            ckpt = args.RtoD_model_dir
+        if os.path.exists(ckpt):
+            load_checkpoint(model, ckpt)
+        model.eval()
+        errors, min_errors, names = validate(args, val_loader, model, 0, logger, args.mode)
+        if rank == 0:
+            print("Results: " + ", ".join("%s %.4f" % (n, e) for n, e in zip(names, errors)))
+        return errors
+    raise ValueError("unknown --mode %r" % args.mode)
+
+
+def main(argv=None):
+    args = option.parse_args(argv)
+    return run(args)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])

@@ -1,0 +1,304 @@
+"""Host-side execution engine: explicit forward/backward over the HIP kernels.
+
+The reference relies on torch autograd + cuDNN for every layer.  Here each
+block's forward launches the HIP kernels directly and, when gradients are
+needed, pushes one closure on a tape; ``backward`` replays the tape in reverse.
+Parameters keep the reference's names/shapes but live, tap-major, in one flat
+arena per model (so Adam and the RCCL all-reduce see a single buffer).
+"""
+import torch
+
+from . import ops
+from ._lib import GdnError
+
+_ALIGN = 64  # floats
+
+
+# ----------------------------------------------------------------------------
+# Parameter layout: logical torch shape, physical tap-major [kh*kw, Cout, Cin]
+# ----------------------------------------------------------------------------
+def _perm(transposed):
+    # logical -> physical permutation and its inverse
+    return ((2, 3, 1, 0), (3, 2, 0, 1)) if transposed else ((2, 3, 0, 1), (2, 3, 0, 1))
+
+
+def tap_view(t, transposed):
+    """[kh*kw, Cout, Cin] view of a conv weight (or its grad) stored tap-major; None if it is not."""
+    fwd, _ = _perm(transposed)
+    v = t.permute(*fwd)
+    if not v.is_contiguous():
+        return None
+    kh, kw, co, ci = v.shape
+    return v.view(kh * kw, co, ci)
+
+
+class ParamArena:
+    """Flat fp32 storage for all parameters of a model (+ a matching gradient arena)."""
+
+    def __init__(self, module, device):
+        self.items = []      # (param, offset, numel, transposed or None)
+        convt = {id(m.weight) for m in module.modules() if isinstance(m, torch.nn.ConvTranspose2d)}
+        off = 0
+        for p in module.parameters():
+            tr = None
+            if p.dim() == 4:
+                tr = id(p) in convt
+            self.items.append((p, off, p.numel(), tr))
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = off
+        self.device = device
+        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        for p, o, n, tr in self.items:
+            src = p.data.to(device=device, dtype=torch.float32)
+            p.data = self._view(self.data, o, src.shape, tr)
+            p.data.copy_(src)
+            p._gdn_arena = self
+        self.ptr0 = self.items[0][0].data_ptr() if self.items else 0
+
+    @staticmethod
+    def _view(flat, off, shape, tr):
+        n = 1
+        for s in shape:
+            n *= s
+        sl = flat[off:off + n]
+        if tr is None:
+            return sl.view(shape)
+        fwd, inv = _perm(tr)
+        phys = [shape[i] for i in fwd]
+        return sl.view(phys).permute(*inv)
+
+    def intact(self):
+        return all(p.data_ptr() == self.data.data_ptr() + 4 * o and p.device == self.data.device
+                   for p, o, _, _ in self.items)
+
+    def grad_view(self, p):
+        for q, o, n, tr in self.items:
+            if q is p:
+                return self._view(self.grad, o, p.shape, tr)
+        raise KeyError("parameter not in arena")
+
+    def bind_grads(self):
+        """Point every .grad at its arena slice.  Returns the params whose existing grad must be accumulated."""
+        self._gv = {}
+        accumulate = []
+        for p, o, n, tr in self.items:
+            gv = self._view(self.grad, o, p.shape, tr)
+            if p.grad is not None and p.grad.data_ptr() != gv.data_ptr():
+                accumulate.append((p, p.grad))
+            p.grad = gv
+            self._gv[id(p)] = gv
+        return accumulate
+
+
+def ensure_arena(module, device):
+    ar = getattr(module, "_gdn_param_arena", None)
+    if ar is None or ar.device != device or not ar.intact():
+        ar = ParamArena(module, device)
+        module._gdn_param_arena = ar
+    return ar
+
+
+# ----------------------------------------------------------------------------
+# Tape
+# ----------------------------------------------------------------------------
+class Ctx:
+    def __init__(self, record, arena=None):
+        self.record = record
+        self.tape = []
+        self.arena = arena
+        self.grads = {}
+
+    # gradient slots are keyed by tensor identity
+    def add_grad(self, t, g):
+        k = id(t)
+        old = self.grads.get(k)
+        if old is None:
+            self.grads[k] = (t, g)
+        else:
+            self.grads[k] = (t, ops.add(_dense(old[1]), _dense(g)))
+
+    def pop_grad(self, t):
+        e = self.grads.pop(id(t), None)
+        return None if e is None else e[1]
+
+    def backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+
+def _dense(t):
+    if t.is_contiguous():
+        return t
+    # channel-slice views are compacted by the add-with-zero-stride-free path
+    out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+    out.copy_(t)
+    return out
+
+
+def _conv_op(mod, reflect):
+    op = getattr(mod, "_gdn_op", None)
+    if op is None:
+        tr = isinstance(mod, torch.nn.ConvTranspose2d)
+        op = ops.Conv(mod.in_channels, mod.out_channels, mod.kernel_size[0], mod.stride[0],
+                      mod.padding[0] if not reflect else reflect, reflect=bool(reflect), transposed=tr)
+        mod._gdn_op = op
+    return op
+
+
+def _w_tap(mod):
+    tr = isinstance(mod, torch.nn.ConvTranspose2d)
+    v = tap_view(mod.weight.data, tr)
+    if v is None:
+        raise GdnError("conv weight is not in tap-major layout; call the model once on its device first")
+    return v, tr
+
+
+def _wgrad_into(ctx, mod, x, dy, x2=None):
+    """Weight gradient of a conv module straight into its arena slice."""
+    op = mod._gdn_op
+    tr = isinstance(mod, torch.nn.ConvTranspose2d)
+    gv = tap_view(mod.weight.grad, tr)
+    if gv is None:
+        raise GdnError("weight.grad is not tap-major")
+    op.wgrad(x, dy, gv, 0)
+    if x2 is not None:
+        op.wgrad(x2, dy, gv, x.shape[3])
+
+
+def _eval_coeffs(bn):
+    """scale/shift of an eval-mode BatchNorm, cached until its tensors change."""
+    key = (getattr(bn, "_gdn_stats_ver", 0), bn.running_mean._version, bn.running_var._version,
+           bn.weight._version, bn.bias._version, bn.running_mean.data_ptr(), bn.weight.data_ptr())
+    c = getattr(bn, "_gdn_eval_cache", None)
+    if c is None or c[0] != key:
+        co = ops.bn_eval_coeffs(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
+        c = (key, co)
+        bn._gdn_eval_cache = c
+    return c[1]
+
+
+def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_dx=True):
+    """[relu](BN(conv(cat(x, x2)))) (+ residual): ConvBlock / ResidualBlock halves / ConvTBlock."""
+    op = _conv_op(conv, reflect)
+    w, tr = _w_tap(conv)
+    if bn.training:
+        y, st = op.fwd(x, w, x2=x2, stats=True)
+        count = y.shape[0] * y.shape[1] * y.shape[2]
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        co = ops.bn_finalize_train(st, count, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, mom, bn.eps)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        bn._gdn_stats_ver = getattr(bn, "_gdn_stats_ver", 0) + 1
+    else:
+        y = op.fwd(x, w, x2=x2)
+        co = _eval_coeffs(bn)
+    a = ops.bn_apply(y, co[0], co[1], relu, residual)
+    if ctx.record:
+        if not bn.training:
+            raise GdnError("backward through eval-mode BatchNorm is not implemented on the HIP path")
+        in_hw = (x.shape[1], x.shape[2])
+
+        def bwd():
+            da = ctx.pop_grad(a)
+            if da is None:
+                return
+            if residual is not None:
+                ctx.add_grad(residual, da)
+            dy = ops.bn_bwd(da, y, bn.weight.data, co, relu, bn.weight.grad, bn.bias.grad)
+            _wgrad_into(ctx, conv, x, dy, x2)
+            if need_dx:
+                wt = ops.transpose_taps(w)
+                if x2 is None:
+                    dx = op.dgrad(dy, wt, in_hw, addsrc=ctx.pop_grad(x))
+                    ctx.grads[id(x)] = (x, dx)
+                else:
+                    dcat = op.dgrad(dy, wt, in_hw)
+                    c1 = x.shape[3]
+                    ctx.add_grad(x, dcat[..., :c1])
+                    ctx.add_grad(x2, dcat[..., c1:])
+        ctx.tape.append(bwd)
+    return a
+
+
+def conv_head_tanh(ctx, x, conv):
+    """Final 9x9 (transposed) conv to one channel + tanh (AE_model_unet.py:362-363, :570-571)."""
+    op = _conv_op(conv, 0)
+    w, tr = _w_tap(conv)
+    out = op.fwd(x, w, act=ops.ACT_TANH)
+    if ctx.record:
+        in_hw = (x.shape[1], x.shape[2])
+
+        def bwd():
+            do = ctx.pop_grad(out)
+            if do is None:
+                return
+            dpre = ops.tanh_bwd(do.contiguous(), out)
+            _wgrad_into(ctx, conv, x, dpre)
+            wt = ops.transpose_taps(w)
+            dx = op.dgrad(dpre, wt, in_hw, addsrc=ctx.pop_grad(x))
+            ctx.grads[id(x)] = (x, dx)
+        ctx.tape.append(bwd)
+    return out
+
+
+def conv_plain(ctx, x, conv, x2=None):
+    """Bare convolution without norm/activation (legacy AutoEncoder 1x1 after cat, :210)."""
+    op = _conv_op(conv, 0)
+    w, tr = _w_tap(conv)
+    y = op.fwd(x, w, x2=x2)
+    if ctx.record:
+        raise GdnError("legacy AutoEncoder is inference-only on the HIP path")
+    return y
+
+
+def upsample(ctx, x, align_corners=False):
+    y = ops.upsample2x(x, align_corners)
+    if ctx.record:
+        def bwd():
+            dy = ctx.pop_grad(y)
+            if dy is None:
+                return
+            ctx.add_grad(x, ops.upsample2x_bwd(_dense(dy), align_corners))
+        ctx.tape.append(bwd)
+    return y
+
+
+# ----------------------------------------------------------------------------
+# Boundary: NCHW torch tensors <-> NHWC device buffers
+# ----------------------------------------------------------------------------
+def to_nhwc(x):
+    if x.dim() != 4:
+        raise GdnError("expected a 4-D NCHW tensor")
+    if not x.is_cuda:
+        raise GdnError("input must live on the GPU: the HIP path has no CPU fallback")
+    x = x.detach()
+    if x.dtype != torch.float32:
+        x = x.float()
+    B, C, H, W = x.shape
+    if C == 1 and x.is_contiguous():
+        return x.view(B, H, W, 1)
+    p = x.permute(0, 2, 3, 1)
+    if p.is_contiguous():       # already channels_last in memory
+        return p
+    return ops.nchw_to_nhwc(x.contiguous())
+
+
+def to_nchw_view(t):
+    """Logical NCHW view (channels_last strides) of an NHWC buffer -- zero copy."""
+    return t.permute(0, 3, 1, 2)
+
+
+def grad_to_nhwc(g):
+    """Incoming NCHW-shaped gradient -> dense NHWC buffer (copy only if the memory order differs)."""
+    g = g.detach()
+    if g.dtype != torch.float32:
+        g = g.float()
+    B, C, H, W = g.shape
+    if C == 1:
+        return g.contiguous().view(B, H, W, 1)
+    p = g.permute(0, 2, 3, 1)
+    if p.is_contiguous():
+        return p
+    return ops.nchw_to_nhwc(g.contiguous())

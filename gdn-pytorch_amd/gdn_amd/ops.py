@@ -1,0 +1,280 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per entry point).
+
+Activations are torch tensors used purely as device buffers: shape [B,H,W,C],
+fp32, channel stride 1; a channel slice of a wider tensor is allowed (pixel
+pitch ``ld`` = stride(2)).  Everything launches on torch's current stream.
+"""
+import ctypes
+
+import torch
+
+from ._lib import ConvGeom, GdnError, lib
+
+ACT_NONE, ACT_TANH = 0, 1
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t):
+    if t.shape[-1] == 1:          # single channel: the pixel pitch is all that matters
+        return t.stride(-2) if t.shape[-2] > 1 else 1
+    if t.stride(-1) != 1:
+        raise GdnError("activation must have channel stride 1, got strides %s" % (t.stride(),))
+    return t.stride(-2)
+
+
+def _chk(t, name="tensor"):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise GdnError("%s must be a CUDA/HIP float32 tensor (got %s on %s); the HIP path has no CPU fallback"
+                       % (name, t.dtype, t.device))
+    return t
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="ws"):
+    """Grow-only scratch buffer per (device, tag); reused across calls on one stream."""
+    key = (device, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+class Conv:
+    """Geometry + launch helper for one Conv2d / ConvTranspose2d layer.
+
+    Weights are tap-major [k*k, Cout, Cin] (see AE_model_unet._tap_view)."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, reflect=False, transposed=False):
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        self.reflect, self.transposed = bool(reflect and pad > 0), transposed
+        self._geom = {}
+
+    def geom(self, B, H, W):
+        key = (B, H, W)
+        g = self._geom.get(key)
+        if g is None:
+            cg = ConvGeom(B, H, W, self.cin, self.cout, self.k, self.stride, self.pad,
+                          1 if self.reflect else 0, 1 if self.transposed else 0)
+            ho, wo = ctypes.c_int32(), ctypes.c_int32()
+            lib.gdn_conv_out_dims(ctypes.byref(cg), ctypes.byref(ho), ctypes.byref(wo))
+            g = (cg, ctypes.byref(cg), ho.value, wo.value)
+            self._geom[key] = g
+        return g
+
+    def stats_slots(self, B, H, W, tile_cfg=0):
+        _, ref, _, _ = self.geom(B, H, W)
+        return int(lib.gdn_conv_stats_slots(ref, tile_cfg))
+
+    def fwd(self, x, w_tap, x2=None, stats=False, act=ACT_NONE, addsrc=None, tile_cfg=0, out=None):
+        """y = conv(cat(x, x2)); returns y, or (y, stats_partials) when stats."""
+        _chk(x, "x")
+        B, H, W, C1 = x.shape
+        _, ref, Ho, Wo = self.geom(B, H, W)
+        c2 = 0 if x2 is None else x2.shape[3]
+        if C1 + c2 != self.cin:
+            raise GdnError("conv expects %d input channels, got %d" % (self.cin, C1 + c2))
+        y = out if out is not None else torch.empty((B, Ho, Wo, self.cout), dtype=torch.float32, device=x.device)
+        st = None
+        if stats:
+            slots = int(lib.gdn_conv_stats_slots(ref, tile_cfg))
+            st = torch.empty((slots, 2, self.cout), dtype=torch.float32, device=x.device)
+        lib.gdn_conv_fwd(ref, _p(x), _ld(x), _p(x2), 0 if x2 is None else _ld(x2), C1, _p(w_tap), _p(y), _ld(y),
+                         _p(addsrc), 0 if addsrc is None else _ld(addsrc), _p(st), act, tile_cfg, stream())
+        return (y, st) if stats else y
+
+    def dgrad(self, dy, wt_tap, in_hw, addsrc=None, tile_cfg=0):
+        """dx = dgrad(dy) (+ addsrc).  wt_tap: [k*k, Cin, Cout]; in_hw: layer input (H, W)."""
+        _chk(dy, "dy")
+        B = dy.shape[0]
+        H, W = in_hw
+        _, ref, Ho, Wo = self.geom(B, H, W)
+        if tuple(dy.shape[1:]) != (Ho, Wo, self.cout):
+            raise GdnError("dgrad: dy shape %s does not match layer output (%d,%d,%d)" % (tuple(dy.shape), Ho, Wo, self.cout))
+        dx = torch.empty((B, H, W, self.cin), dtype=torch.float32, device=dy.device)
+        nb = int(lib.gdn_conv_dgrad_workspace_bytes(ref))
+        ws = workspace(nb, dy.device, "dgrad") if nb else None
+        lib.gdn_conv_dgrad(ref, _p(dy), _ld(dy), _p(wt_tap), _p(dx), _ld(dx), _p(addsrc),
+                           0 if addsrc is None else _ld(addsrc), _p(ws), nb, tile_cfg, stream())
+        return dx
+
+    def wgrad(self, x, dy, dw_tap, ci_off=0):
+        """dw_tap[tap][co][ci_off + ci] = wgrad over the channel slice x (Cx = x.shape[3])."""
+        _chk(x, "x")
+        B, H, W, Cx = x.shape
+        _, ref, _, _ = self.geom(B, H, W)
+        nb = int(lib.gdn_conv_wgrad_workspace_bytes(ref, Cx))
+        if nb == 0:
+            raise GdnError("wgrad: unsupported geometry k=%d stride=%d Cx=%d" % (self.k, self.stride, Cx))
+        ws = workspace(nb, x.device, "wgrad")
+        lib.gdn_conv_wgrad(ref, _p(x), _ld(x), Cx, _p(dy), _ld(dy), _p(dw_tap), self.cin, ci_off, _p(ws), nb, stream())
+
+
+def transpose_taps(w_tap, out=None):
+    """[T, R, C] -> [T, C, R]"""
+    T, R, C = w_tap.shape
+    wt = out if out is not None else torch.empty((T, C, R), dtype=torch.float32, device=w_tap.device)
+    lib.gdn_transpose_taps(_p(w_tap), _p(wt), T, R, C, stream())
+    return wt
+
+
+def weight_to_tapmajor(w, transposed):
+    """torch-layout conv weight -> tap-major [k*k, Cout, Cin] (w contiguous)."""
+    A, Bc, kh, kw = w.shape
+    cout, cin = (Bc, A) if transposed else (A, Bc)
+    out = torch.empty((kh * kw, cout, cin), dtype=torch.float32, device=w.device)
+    lib.gdn_weight_to_tapmajor(_p(w.contiguous()), _p(out), cout, cin, kh * kw, 0 if transposed else 1, stream())
+    return out
+
+
+def weight_from_tapmajor(w_tap, k, transposed):
+    T, cout, cin = w_tap.shape
+    shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+    out = torch.empty(shape, dtype=torch.float32, device=w_tap.device)
+    lib.gdn_weight_from_tapmajor(_p(w_tap), _p(out), cout, cin, T, 0 if transposed else 1, stream())
+    return out
+
+
+def bn_finalize_train(stats, count, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM, eps=BN_EPS):
+    slots, _, C = stats.shape
+    co = torch.empty((4, C), dtype=torch.float32, device=stats.device)   # scale, shift, mean, invstd
+    lib.gdn_bn_finalize_train(_p(stats), slots, C, int(count), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                              momentum, eps, _p(co[0]), _p(co[1]), _p(co[2]), _p(co[3]), stream())
+    return co
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=BN_EPS):
+    C = running_mean.numel()
+    co = torch.empty((2, C), dtype=torch.float32, device=running_mean.device)
+    lib.gdn_bn_eval_coeffs(_p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, C, _p(co[0]), _p(co[1]), stream())
+    return co
+
+
+def bn_apply(y, scale, shift, relu, residual=None, out=None):
+    B, H, W, C = y.shape
+    o = out if out is not None else torch.empty((B, H, W, C), dtype=torch.float32, device=y.device)
+    lib.gdn_bn_apply(_p(y), _ld(y), _p(scale), _p(shift), _p(residual), 0 if residual is None else _ld(residual),
+                     _p(o), _ld(o), B * H * W, C, 1 if relu else 0, stream())
+    return o
+
+
+def bn_bwd(dout, y, gamma, coeffs, relu, dgamma, dbeta):
+    """coeffs = [scale, shift, mean, invstd] from bn_finalize_train. Returns dy."""
+    B, H, W, C = y.shape
+    npix = B * H * W
+    dy = torch.empty((B, H, W, C), dtype=torch.float32, device=y.device)
+    nb = int(lib.gdn_bn_bwd_workspace_bytes(npix, C))
+    ws = workspace(nb, y.device, "bnbwd")
+    lib.gdn_bn_bwd(_p(dout), _ld(dout), _p(y), _ld(y), _p(gamma), _p(coeffs[0]), _p(coeffs[1]), _p(coeffs[2]),
+                   _p(coeffs[3]), _p(dy), _ld(dy), _p(dgamma), _p(dbeta), npix, C, 1 if relu else 0, _p(ws), nb, stream())
+    return dy
+
+
+def upsample2x(x, align_corners=False):
+    B, H, W, C = x.shape
+    if not x.is_contiguous():
+        raise GdnError("upsample2x needs a dense NHWC tensor")
+    y = torch.empty((B, 2 * H, 2 * W, C), dtype=torch.float32, device=x.device)
+    lib.gdn_upsample2x_fwd(_p(x), _p(y), B, H, W, C, 1 if align_corners else 0, stream())
+    return y
+
+
+def upsample2x_bwd(dy, align_corners=False):
+    B, H2, W2, C = dy.shape
+    if not dy.is_contiguous():
+        raise GdnError("upsample2x_bwd needs a dense NHWC tensor")
+    dx = torch.empty((B, H2 // 2, W2 // 2, C), dtype=torch.float32, device=dy.device)
+    lib.gdn_upsample2x_bwd(_p(dy), _p(dx), B, H2 // 2, W2 // 2, C, 1 if align_corners else 0, stream())
+    return dx
+
+
+def nchw_to_nhwc(x):
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
+    lib.gdn_nchw_to_nhwc(_p(x), _p(y), B, C, H, W, stream())
+    return y
+
+
+def nhwc_to_nchw(x):
+    B, H, W, C = x.shape
+    y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    lib.gdn_nhwc_to_nchw(_p(x), _p(y), B, C, H, W, stream())
+    return y
+
+
+def add(a, b):
+    if not (a.is_contiguous() and b.is_contiguous()):
+        raise GdnError("add needs dense tensors")
+    o = torch.empty_like(a)
+    lib.gdn_add(_p(a), _p(b), _p(o), a.numel(), stream())
+    return o
+
+
+def tanh_bwd(dout, out):
+    r = torch.empty_like(out)
+    lib.gdn_tanh_bwd(_p(dout), _p(out), _p(r), out.numel(), stream())
+    return r
+
+
+def fill_(t, value):
+    lib.gdn_fill(_p(t), float(value), t.numel(), stream())
+    return t
+
+
+def zeros(shape, device):
+    return fill_(torch.empty(shape, dtype=torch.float32, device=device), 0.0)
+
+
+def _loss_ws(npix, device):
+    nb = int(lib.gdn_loss_workspace_bytes(npix))
+    return workspace(nb, device, "loss"), nb
+
+
+def berhu_masked(out, gt, sparse, box, dout, loss):
+    """out/gt [B,1,H,W]; sparse [B,Cs,H,W] or None; adds the gradient into dout; writes loss[()]."""
+    B, _, H, W = out.shape
+    ws, nb = _loss_ws(B * H * W, out.device)
+    cbox = (ctypes.c_int32 * 4)(*box) if box is not None else None
+    lib.gdn_berhu_masked(_p(out), _p(gt), _p(sparse), 0 if sparse is None else sparse.shape[1], B, H, W, cbox,
+                         _p(loss), _p(dout), _p(ws), nb, stream())
+
+
+def sobel_l1(pred, gt, weight, dpred, loss):
+    B, _, H, W = pred.shape
+    ws, nb = _loss_ws(B * H * W, pred.device)
+    lib.gdn_sobel_l1(_p(pred), _p(gt), B, H, W, float(weight), _p(loss), _p(dpred), _p(ws), nb, stream())
+
+
+def smoothness(depth, img, ddepth, loss):
+    B, _, H, W = depth.shape
+    ws, nb = _loss_ws(B * H * W, depth.device)
+    lib.gdn_smoothness(_p(depth), _p(img), img.shape[1], B, H, W, _p(loss), _p(ddepth), _p(ws), nb, stream())
+
+
+def mse_accum(a, b, weight, loss, accumulate):
+    ws, nb = _loss_ws(0, a.device)
+    lib.gdn_mse(_p(a), _p(b), a.numel(), float(weight), 1 if accumulate else 0, _p(loss), _p(ws), nb, stream())
+
+
+def depth_metrics(gt_sparse, gt, pred, crop=True):
+    B, _, H, W = pred.shape
+    nb = int(lib.gdn_depth_metrics_workspace_bytes(B, H, W))
+    ws = workspace(nb, pred.device, "metrics")
+    err = torch.empty(8, dtype=torch.float32, device=pred.device)
+    lib.gdn_depth_metrics(_p(gt_sparse), _p(gt), _p(pred), B, H, W, 1 if crop else 0, _p(err), _p(ws), nb, stream())
+    return err
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    lib.gdn_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, int(step),
+                      float(grad_scale), stream())

@@ -1,0 +1,144 @@
+"""Loss helpers of the hot path, on the HIP kernels.
+
+Mirrors the reference's utils.py for the functions the training step uses
+(imgrad_loss utils.py:127-131, depth_smoothness utils.py:165-178) and gives the
+inline loss code of trainer.py a name (BerHu :433-448/:705-720, latent MSE
+:726-733).  Every function returns a 0-dim device tensor, is differentiable
+w.r.t. the prediction through a single autograd node, and never synchronises
+with the host (the reference's mask indexing does, four times per step).
+"""
+import datetime
+import pathlib
+
+import torch
+
+from . import ops
+from ._lib import GdnError
+
+
+def _c1(t, name):
+    """[B,1,H,W] fp32 device tensor with dense memory (channels_last and NCHW coincide for C=1)."""
+    if t.dim() != 4 or t.shape[1] != 1:
+        raise GdnError("%s must be [B,1,H,W]" % name)
+    if not t.is_cuda:
+        raise GdnError("%s must live on the GPU: the HIP path has no CPU fallback" % name)
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _nchw(t, name):
+    if not t.is_cuda:
+        raise GdnError("%s must live on the GPU" % name)
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def crop_box_kitti(H, W):
+    """Garg crop of the training loss, trainer.py:385-386."""
+    return (int(0.40810811 * H), int(0.99189189 * H), int(0.03594771 * W), int(0.96405229 * W))
+
+
+class _PixelLoss(torch.autograd.Function):
+    """loss = f(pred, *consts); the kernel that evaluates f also writes dloss/dpred."""
+
+    @staticmethod
+    def forward(ctx, pred, kind, args):
+        p = _c1(pred, "pred")
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        need = pred.requires_grad
+        dp = ops.zeros(p.shape, p.device) if need else None
+        if kind == "berhu":
+            gt, sparse, box = args
+            ops.berhu_masked(p, _c1(gt, "gt"), None if sparse is None else _nchw(sparse, "sparse"), box, dp, loss)
+        elif kind == "sobel":
+            gt, weight = args
+            ops.sobel_l1(p, _c1(gt, "gt"), weight, dp, loss)
+        elif kind == "smooth":
+            (img,) = args
+            ops.smoothness(p, _nchw(img, "img"), dp, loss)
+        elif kind == "dtod":          # BerHu + 3*Sobel in one gradient buffer
+            gt, sparse, box, parts = args
+            g = _c1(gt, "gt")
+            ops.berhu_masked(p, g, None if sparse is None else _nchw(sparse, "sparse"), box, dp, parts[0])
+            ops.sobel_l1(p, g, 3.0, dp, parts[1])
+            torch.add(parts[0], parts[1], out=loss)
+        elif kind == "rtod":          # BerHu + smoothness
+            gt, sparse, box, img, parts = args
+            ops.berhu_masked(p, _c1(gt, "gt"), None if sparse is None else _nchw(sparse, "sparse"), box, dp, parts[0])
+            ops.smoothness(p, _nchw(img, "img"), dp, parts[1])
+            torch.add(parts[0], parts[1], out=loss)
+        else:
+            raise ValueError(kind)
+        ctx.dp = dp
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        dp, ctx.dp = ctx.dp, None
+        if dp is None:
+            return None, None, None
+        return dp * gout, None, None
+
+
+def berhu_masked_loss(outputs, depths, sparse_depths=None, box=None):
+    """3*mean(w*rho_c(out-gt)), c = 0.2*max|out-gt| over the batch. trainer.py:433-448 == :705-720."""
+    if sparse_depths is not None and box is None:
+        box = crop_box_kitti(outputs.shape[2], outputs.shape[3])
+    return _PixelLoss.apply(outputs, "berhu", (depths, sparse_depths, box))
+
+
+def imgrad_loss(pred, gt):
+    """mean|Sy*(p)-Sy*(g)| + mean|Sx*(p)-Sx*(g)| (3x3 Sobel, zero pad). utils.py:127-131."""
+    return _PixelLoss.apply(pred, "sobel", (gt, 1.0))
+
+
+def depth_smoothness_loss(depth, img):
+    """mean|0.1*depth_smoothness(depth, img)|. utils.py:165-178 + trainer.py:753-754."""
+    return _PixelLoss.apply(depth, "smooth", (img,))
+
+
+def dtod_loss(outputs, depths, sparse_depths=None, box=None):
+    """DtoD training loss, trainer.py:433-456: returns (loss, output_loss, gradient_loss)."""
+    if sparse_depths is not None and box is None:
+        box = crop_box_kitti(outputs.shape[2], outputs.shape[3])
+    parts = torch.empty(2, dtype=torch.float32, device=outputs.device)
+    loss = _PixelLoss.apply(outputs, "dtod", (depths, sparse_depths, box, (parts[0], parts[1])))
+    return loss, parts[0], parts[1]
+
+
+def rtod_pixel_loss(outputs, depths, rgb, sparse_depths=None, box=None):
+    """BerHu + smoothness part of the RtoD loss, trainer.py:705-720,753-757."""
+    if sparse_depths is not None and box is None:
+        box = crop_box_kitti(outputs.shape[2], outputs.shape[3])
+    parts = torch.empty(2, dtype=torch.float32, device=outputs.device)
+    loss = _PixelLoss.apply(outputs, "rtod", (depths, sparse_depths, box, rgb, (parts[0], parts[1])))
+    return loss, parts[0], parts[1]
+
+
+LATENT_WEIGHTS = (1.0, 2.5, 14.0, 12.0)
+
+
+def latent_loss(feats, feats_tar):
+    """1.5*(mse1 + 2.5*mse2 + 14*mse3 + 12*mse4)/4, value only (F3). trainer.py:726-733."""
+    loss = torch.empty((), dtype=torch.float32, device=feats[0].device)
+    for i, (w, f, t) in enumerate(zip(LATENT_WEIGHTS, feats, feats_tar)):
+        a, b = f.detach(), t.detach()
+        if a.stride() != b.stride():
+            b = b.contiguous(); a = a.contiguous()
+        ops.mse_accum(a, b, 1.5 * w / 4.0, loss, accumulate=i > 0)
+    return loss
+
+
+def save_path_formatter(args, parser):
+    """Checkpoint directory: <data dir>[,<N>epochs][,epoch_size<N>][,b<N>][,lr<x>]/<MM-DD-HH:MM>,
+    i.e. only the non-default settings are spelled out (behaviour of utils.py:34-53)."""
+    opts = vars(args)
+    parts = [pathlib.Path(str(opts['data']).rstrip('/')).name]
+    for key, fmt in (('epochs', '%sepochs'), ('epoch_size', 'epoch_size%s'), ('batch_size', 'b%s'), ('lr', 'lr%s')):
+        if key in opts and opts[key] != parser.get_default(key):
+            parts.append(fmt % (opts[key],))
+    return pathlib.Path(','.join(parts)) / datetime.datetime.now().strftime("%m-%d-%H:%M")

@@ -1,0 +1,216 @@
+/*
+ * gdn_hip.h -- C ABI of libgdn_hip.so, the MI355X (gfx950) kernels behind the
+ * GDN-Pytorch hot path.
+ *
+ * The reference (tjqansthd/GDN-Pytorch) has no FFI: its boundary is Python
+ * (nn.Module.forward + loss helpers) and every device op is a PyTorch/cuDNN
+ * call.  Each entry point below therefore replaces one *PyTorch call site* of
+ * the reference; the file:line cited is that call site (paths relative to
+ * /root/reference/src).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, negative gdn_status on error (gdn_strerror());
+ *   - never allocate, never synchronise, never read device memory on the host:
+ *     every call is stream-ordered on `stream` (a hipStream_t passed as void*)
+ *     and is hipGraph-capture safe; the caller owns every buffer, including
+ *     workspaces sized by the matching *_workspace_bytes() query;
+ *   - activations are fp32 NHWC: pixel p of an image batch [B,H,W] with C
+ *     channels lives at base + p*ld (ld >= C floats, lets a tensor be a channel
+ *     slice of a wider one); weights are fp32 in "tap-major" layout
+ *     [kh*kw][Cout][Cin] (Cin contiguous) for both Conv2d and ConvTranspose2d;
+ *   - stateless and thread-safe.
+ */
+#ifndef GDN_HIP_H
+#define GDN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GDN_OK = 0,
+    GDN_ERR_BAD_ARG = -1,
+    GDN_ERR_UNSUPPORTED = -2,
+    GDN_ERR_WORKSPACE = -3,
+    GDN_ERR_LAUNCH = -4
+} gdn_status;
+
+int gdn_version(void);
+const char* gdn_strerror(int status);
+/* Fills name[] with the HIP device name of the current device; returns CU count (<0 on error). */
+int gdn_device_info(char* name, int name_len);
+
+/* ------------------------------------------------------------------------
+ * Convolution geometry, in torch.nn semantics.
+ *   transposed == 0 : nn.Conv2d(Cin, Cout, k, stride, pad), optionally preceded
+ *                     by nn.ReflectionPad2d(pad) (pad_mode 1, conv pad 0) --
+ *                     ConvBlock AE_model_unet.py:65-69, ResidualBlock :49-54.
+ *   transposed == 1 : nn.ConvTranspose2d(Cin, Cout, k, stride, pad) --
+ *                     ConvTBlock AE_model_unet.py:84-87, upconv4 :521.
+ * H, W are the spatial dims of the layer INPUT.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int32_t B, H, W;
+    int32_t Cin, Cout;
+    int32_t k, stride, pad;
+    int32_t pad_mode;   /* 0 zero padding, 1 reflection padding (Conv2d only) */
+    int32_t transposed; /* 0 Conv2d, 1 ConvTranspose2d */
+} gdn_conv_geom;
+
+enum { GDN_ACT_NONE = 0, GDN_ACT_TANH = 1 };
+
+/* Output spatial dims of the layer. */
+int gdn_conv_out_dims(const gdn_conv_geom* g, int32_t* Ho, int32_t* Wo);
+
+/* Number of per-block partial-statistics slots gdn_conv_fwd writes when
+ * `stats` is non-NULL, for the same tile_cfg; the stats buffer must hold
+ * slots*2*Cout floats laid out [slot][2][Cout]. */
+int64_t gdn_conv_stats_slots(const gdn_conv_geom* g, int32_t tile_cfg);
+
+/* Forward convolution.  Replaces nn.Conv2d / nn.ConvTranspose2d forward
+ * (AE_model_unet.py:50,53,67,85,300,521) and, through x2, the
+ * torch.cat(...)+1x1 ConvBlock pair (:338-339,:345-346,:351-352,:357-358)
+ * without materialising the concat: reduction channels [0,C1) come from x,
+ * [C1,Cin) from x2 (x2 may be NULL when C1 == Cin).
+ *   y[pixel][0..Cout)        = act( conv(x) ) (+ addsrc[pixel][..] if addsrc)
+ *   stats[slot][0][c], [1][c] = per-block sum / sum of squares of the raw conv
+ *                               output (feeds train-mode BatchNorm, K7).
+ * tile_cfg: 0 = automatic; >0 forces a tile configuration (tuning/testing). */
+int gdn_conv_fwd(const gdn_conv_geom* g,
+                 const float* x, int32_t ldx, const float* x2, int32_t ldx2, int32_t C1,
+                 const float* w, float* y, int32_t ldy,
+                 const float* addsrc, int32_t ld_add,
+                 float* stats, int32_t act, int32_t tile_cfg, void* stream);
+
+/* Data gradient.  Replaces autograd's conv backward-data for the call sites
+ * above (loss.backward(), trainer.py:467,767).  wt is the tap-major TRANSPOSED
+ * weight [kh*kw][Cin][Cout] (see gdn_transpose_taps).  dx = dgrad(dy) (+ addsrc).
+ * Reflection-padded layers need a workspace for the gradient on the padded
+ * domain, folded back onto dx inside the call. */
+size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g);
+int gdn_conv_dgrad(const gdn_conv_geom* g, const float* dy, int32_t ldy,
+                   const float* wt, float* dx, int32_t ldx,
+                   const float* addsrc, int32_t ld_add,
+                   void* workspace, size_t workspace_bytes, int32_t tile_cfg, void* stream);
+
+/* Weight gradient (same call sites).  x is the layer input ([B,H,W], channel
+ * slice [0,Cx) of width ldx), dy the output gradient.  Writes
+ * dw[tap][co][ci_off + ci] for ci in [0,Cx), with row stride ld_dw (= total
+ * Cin), so the two halves of a concat 1x1 conv are two calls.  Deterministic:
+ * split-K partial slabs in `workspace` are summed in a fixed order. */
+size_t gdn_conv_wgrad_workspace_bytes(const gdn_conv_geom* g, int32_t Cx);
+int gdn_conv_wgrad(const gdn_conv_geom* g, const float* x, int32_t ldx, int32_t Cx,
+                   const float* dy, int32_t ldy,
+                   float* dw, int32_t ld_dw, int32_t ci_off,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* [ntaps][R][C] -> [ntaps][C][R] */
+int gdn_transpose_taps(const float* w, float* wt, int32_t ntaps, int32_t R, int32_t C, void* stream);
+/* torch layout [A][Bc][ntaps] (Conv2d weight [Cout][Cin][kh][kw], or ConvTranspose2d
+ * weight [Cin][Cout][kh][kw]) <-> tap-major [ntaps][Cout][Cin].  a_is_cout selects
+ * which of the two leading torch dims is Cout. */
+int gdn_weight_to_tapmajor(const float* w_torch, float* w_tap, int32_t Cout, int32_t Cin, int32_t ntaps,
+                           int32_t a_is_cout, void* stream);
+int gdn_weight_from_tapmajor(const float* w_tap, float* w_torch, int32_t Cout, int32_t Cin, int32_t ntaps,
+                             int32_t a_is_cout, void* stream);
+
+/* ------------------------------------------------------------------------
+ * BatchNorm2d (AE_model_unet.py:51,54,68,86), ReLU (:52,69,87), residual add (:57).
+ * ---------------------------------------------------------------------- */
+/* Train mode: reduce the conv kernel's partial statistics (fp64), update the
+ * running stats (momentum, unbiased variance), and emit the per-channel
+ * affine  scale = gamma*invstd,  shift = beta - mean*scale  plus mean/invstd
+ * for backward. */
+int gdn_bn_finalize_train(const float* stats, int64_t slots, int32_t C, int64_t count,
+                          const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps,
+                          float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* Eval mode: scale/shift from the running statistics. */
+int gdn_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int32_t C,
+                       float* scale, float* shift, void* stream);
+/* out = [relu](y*scale[c] + shift[c]) (+ residual).  npix pixels of C channels. */
+int gdn_bn_apply(const float* y, int32_t ldy, const float* scale, const float* shift,
+                 const float* residual, int32_t ld_res, float* out, int32_t ld_out,
+                 int64_t npix, int32_t C, int32_t relu, void* stream);
+/* Backward of out = [relu](BN_train(y)):
+ *   pass 1 (reduce): per-channel sum(dz), sum(dz*xhat) with dz = dout*[z>0];
+ *   pass 2 (apply) : dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)),
+ *                    dgamma = sum(dz*xhat), dbeta = sum(dz).
+ * Both passes inside one call; workspace from gdn_bn_bwd_workspace_bytes. */
+size_t gdn_bn_bwd_workspace_bytes(int64_t npix, int32_t C);
+int gdn_bn_bwd(const float* dout, int32_t ld_dout, const float* y, int32_t ldy,
+               const float* gamma, const float* scale, const float* shift,
+               const float* mean, const float* invstd,
+               float* dy, int32_t ld_dy, float* dgamma, float* dbeta,
+               int64_t npix, int32_t C, int32_t relu,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * x2 bilinear up-sampling: F.interpolate(align_corners=False) AE_model_unet.py:336,343,349,355
+ * and nn.Upsample(align_corners=True) :135,203,215,227.  NHWC, C channels.
+ * ---------------------------------------------------------------------- */
+int gdn_upsample2x_fwd(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                       int32_t align_corners, void* stream);
+int gdn_upsample2x_bwd(const float* dy, float* dx, int32_t B, int32_t H, int32_t W, int32_t C,
+                       int32_t align_corners, void* stream);
+
+/* Layout and small element-wise helpers. */
+int gdn_nchw_to_nhwc(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
+int gdn_nhwc_to_nchw(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
+int gdn_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* dpre = dout * (1 - out^2): backward of x15.tanh() (AE_model_unet.py:363,571). */
+int gdn_tanh_bwd(const float* dout, const float* out, float* dpre, int64_t n, void* stream);
+int gdn_fill(float* p, float value, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Training losses, forward value and gradient in one call, sync-free (F6).
+ * Each writes its scalar to *loss (device) and ADDS its gradient into dout
+ * (caller zero-fills dout once per step); `w` scales both.
+ * ---------------------------------------------------------------------- */
+/* Masked BerHu, trainer.py:433-448 == :705-720.  out/gt [B,1,H,W];
+ * sparse [B,Cs,H,W] NCHW (channel 0 used) or NULL; box = {y1,y2,x1,x2}.
+ * loss = 3*mean(w*rho).  workspace >= gdn_loss_workspace_bytes(). */
+size_t gdn_loss_workspace_bytes(int64_t npix);
+int gdn_berhu_masked(const float* out, const float* gt, const float* sparse, int32_t Cs,
+                     int32_t B, int32_t H, int32_t W, const int32_t box[4],
+                     float* loss, float* dout, void* workspace, size_t workspace_bytes, void* stream);
+/* Sobel L1, utils.py:105-131 with the factor 3 of trainer.py:453 passed as `weight`. */
+int gdn_sobel_l1(const float* pred, const float* gt, int32_t B, int32_t H, int32_t W, float weight,
+                 float* loss, float* dpred, void* workspace, size_t workspace_bytes, void* stream);
+/* Edge-aware smoothness, utils.py:139-178 + trainer.py:753-754.
+ * depth [B,1,H,W], img [B,Ci,H,W] NCHW.  loss = mean|0.1*smooth|. */
+int gdn_smoothness(const float* depth, const float* img, int32_t Ci, int32_t B, int32_t H, int32_t W,
+                   float* loss, float* ddepth, void* workspace, size_t workspace_bytes, void* stream);
+/* loss_accum (+)= weight * mean((a-b)^2): the latent MSE terms, trainer.py:728-733
+ * (value only, F3).  accumulate != 0 adds to the existing *loss. */
+int gdn_mse(const float* a, const float* b, int64_t n, float weight, int32_t accumulate,
+            float* loss, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Depth metrics, calculate_error.py:10-103: per image min-max -> x80, Godard
+ * crop, validity mask, median scaling (lower median), clamp, 8 reductions.
+ * gt_sparse/gt/pred are [B,1,H,W]; errors[8] = batch means, device memory.
+ * ---------------------------------------------------------------------- */
+size_t gdn_depth_metrics_workspace_bytes(int32_t B, int32_t H, int32_t W);
+int gdn_depth_metrics(const float* gt_sparse, const float* gt, const float* pred,
+                      int32_t B, int32_t H, int32_t W, int32_t crop,
+                      float* errors, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused Adam with coupled L2 weight decay over one flat arena
+ * (torch.optim.Adam(..., weight_decay=5e-4), GDN_main.py:157,173; step at
+ * trainer.py:468,768).  grad_scale multiplies the gradient first (1/world
+ * after an RCCL sum all-reduce).
+ * ---------------------------------------------------------------------- */
+int gdn_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int32_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDN_HIP_H */

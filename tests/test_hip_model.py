@@ -1,0 +1,184 @@
+"""GPU parity tests, module level: the drop-in nn.Modules and training steps against
+fixtures produced by the real reference (tests/golden) and against the CPU oracle."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gdn_oracle as O
+from test_hip_kernels import close
+
+pytestmark = pytest.mark.gpu
+
+_BLOCKS = {
+    "rb_k9": ("ResidualBlock", (16, 16, 9, 4), {}),
+    "rb_k3": ("ResidualBlock", (32, 32, 3, 1), {}),
+    "cb_k7s2": ("ConvBlock", (16, 32), dict(kernel_size=7, stride=2, padding=3)),
+    "cb_k4s2": ("ConvBlock", (16, 32), dict(kernel_size=4, stride=2, padding=1)),
+    "cb_k5s1": ("ConvBlock", (32, 16), dict(kernel_size=5, stride=1, padding=2)),
+    "cb_k9c3": ("ConvBlock", (3, 16), dict(kernel_size=9, stride=1, padding=4)),
+    "cb_k1": ("ConvBlock", (64, 32), dict(kernel_size=1, stride=1, padding=0)),
+    "ctb_k4s2": ("ConvTBlock", (32, 16), dict(kernel_size=4, stride=2, padding=1)),
+}
+
+
+@pytest.mark.parametrize("nm", sorted(_BLOCKS))
+def test_blocks_vs_reference_fixture(gpu, golden, nm):
+    """Forward, input gradient, parameter gradients and BN running stats of each block type."""
+    import gdn_amd.AE_model_unet as M
+    g = golden["blocks"]
+    cls, a, kw = _BLOCKS[nm]
+    blk = getattr(M, cls)(*a, **kw)
+    sd = blk.state_dict()
+    for k in sd:
+        if nm + ".p." + k in g.files:
+            sd[k] = torch.from_numpy(g[nm + ".p." + k])
+    blk.load_state_dict(sd)
+    blk = blk.to(gpu).train()
+    x = torch.from_numpy(g[nm + ".x"]).to(gpu).requires_grad_(False)
+    y = blk(x)
+    close(y, torch.from_numpy(g[nm + ".y"]), what=nm + " y")
+    y.backward(torch.from_numpy(g[nm + ".dy"]).to(gpu))
+    for k, p in blk.named_parameters():
+        close(p.grad, torch.from_numpy(g[nm + ".g." + k]), rtol=2e-3, atol_scale=5e-4, what=nm + " grad " + k)
+    for k, b in blk.named_buffers():
+        if "running" in k:
+            close(b, torch.from_numpy(g[nm + ".b." + k]), what=nm + " " + k)
+
+
+def _load(model, sd, gpu):
+    model.load_state_dict(sd)
+    return model.to(gpu)
+
+
+@pytest.mark.parametrize("name", ["AutoEncoder_DtoD", "AutoEncoder_2", "AutoEncoder"])
+def test_full_forward_vs_reference(gpu, golden, name):
+    """B=2, 128x416, seed-0 weights: depth map (train- and eval-mode BN) and the 7 feature maps."""
+    import gdn_amd.AE_model_unet as M
+    g = golden["forward"]
+    depth, rgb, _ = O.synthetic_batch(2, 128, 416, seed=0)
+    x = (depth if name == "AutoEncoder_DtoD" else rgb).to(gpu)
+    torch.manual_seed(0)
+    m = getattr(M, name)().to(gpu)
+    m.train()
+    with torch.no_grad():
+        feats = m(x, istrain=True)
+    assert len(feats) == 8
+    close(feats[7], torch.from_numpy(g[name + ".train.out"]), what=name + " train out")
+    for i in range(7):
+        f = feats[i]
+        assert list(f.shape) == list(g[name + ".train.f%d.shape" % i])
+        fl = f.contiguous().reshape(-1)
+        idx = torch.linspace(0, fl.numel() - 1, 64).long().to(gpu)
+        ref = torch.from_numpy(g[name + ".train.f%d.sample" % i])
+        close(fl[idx], ref, rtol=2e-3, atol_scale=2e-3, what=name + " feat%d sample" % i)
+        st = g[name + ".train.f%d.stats" % i]
+        fd = f.double()
+        np.testing.assert_allclose([fd.abs().sum().item(), (fd * fd).sum().item()], st[1:], rtol=1e-3)
+    m.eval()
+    with torch.no_grad():
+        out = m(x, istrain=False)
+    close(out, torch.from_numpy(g[name + ".eval.out"]), what=name + " eval out")
+
+
+@pytest.mark.parametrize("mode", ["DtoD", "RtoD"])
+def test_train_step_vs_real_trainer(gpu, golden, mode):
+    """One full training step (forward, losses, backward, Adam) against the reference's own trainer run."""
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import utils as U
+    from gdn_amd.optim import Adam
+    g = golden["train_dtod" if mode == "DtoD" else "train_rtod"]
+    depth, rgb, sparse = [t.to(gpu) for t in O.synthetic_batch(2, 128, 416, seed=0)]
+    torch.manual_seed(0)
+    if mode == "DtoD":
+        model = M.AutoEncoder_DtoD(input_dim=1).to(gpu)
+        G = None
+    else:
+        model = M.AutoEncoder_2(input_dim=3).to(gpu)
+        torch.manual_seed(1)
+        G = M.AutoEncoder_DtoD(input_dim=1).to(gpu).eval()
+    opt = Adam(model.parameters(), 2e-5, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
+    model.train()
+    if mode == "DtoD":
+        out = model(depth, istrain=False)
+        loss, ol, gl = U.dtod_loss(out, depth, sparse)
+    else:
+        out = model(rgb, istrain=False)
+        with torch.no_grad():
+            ft_tar = G(depth, istrain=True)[:4]
+            ft = G(out, istrain=True)[:4]
+        lat = U.latent_loss(ft, ft_tar)
+        pix, ol, sm = U.rtod_pixel_loss(out, depth, rgb, sparse)
+        loss = pix + lat
+    out.retain_grad()
+    opt.zero_grad()
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-3)
+    close(out, torch.from_numpy(g["out"]), what="outputs")
+    close(out.grad, torch.from_numpy(g["dout"]), rtol=2e-3, atol_scale=2e-3, what="dL/dout")
+    keys = json.loads(str(g["keys"]))
+    P = dict(model.named_parameters())
+    assert keys == list(P.keys())
+    gn = np.array([P[k].grad.double().norm().item() for k in keys])
+    np.testing.assert_allclose(gn, g["grad_norm"], rtol=2e-2, atol=1e-6)
+    opt.step()
+    pn = np.array([P[k].detach().double().norm().item() for k in keys])
+    np.testing.assert_allclose(pn, g["param_norm_after"], rtol=1e-5)
+    ps = np.array([P[k].detach().double().sum().item() for k in keys])
+    np.testing.assert_allclose(ps, g["param_sum_after"], rtol=1e-3, atol=2e-3)
+    sd = model.state_dict()
+    for i, k in enumerate(json.loads(str(g["bn_keys"]))):
+        t = sd[k].double()
+        np.testing.assert_allclose([t.sum().item(), t.abs().sum().item()], g["bn_stats_after"][i][:2], rtol=1e-3, atol=1e-4)
+    if "returned" in g:
+        assert ol.item() == pytest.approx(g["returned"][1], rel=1e-3)
+        assert lat.item() == pytest.approx(g["returned"][2], rel=2e-3)
+
+
+def test_train_step_gradients_vs_oracle(gpu):
+    """Per-parameter gradient tensors (not just norms) on a small DtoD problem."""
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import utils as U
+    depth, rgb, sparse = O.synthetic_batch(1, 32, 64, seed=4)
+    sd = O.init_state_dict("AutoEncoder_DtoD", seed=3)
+    ref = O.train_step("DtoD", {k: v.clone() for k, v in sd.items()}, (depth, rgb, sparse), {})
+    model = M.AutoEncoder_DtoD(input_dim=1, height=32, width=64)
+    model.load_state_dict(sd)
+    model = model.to(gpu).train()
+    out = model(depth.to(gpu), istrain=False)
+    loss, _, _ = U.dtod_loss(out, depth.to(gpu), sparse.to(gpu))
+    loss.backward()
+    assert loss.item() == pytest.approx(ref["loss"], rel=1e-3)
+    worst = 0.0
+    for k, p in model.named_parameters():
+        gr, rr = p.grad.detach().cpu().double(), ref["grads"][k].double()
+        rel = float((gr - rr).norm() / (rr.norm() + 1e-12))
+        worst = max(worst, rel)
+        assert rel < 2e-2, "%s: relative gradient error %.3e" % (k, rel)
+    print("worst relative gradient error: %.3e" % worst)
+
+
+def test_checkpoint_roundtrip_and_errors(gpu, tmp_path):
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd._lib import GdnError
+    from gdn_amd.trainer import _save_checkpoint, load_checkpoint
+    torch.manual_seed(0)
+    m = M.AutoEncoder_DtoD(height=32, width=64).to(gpu)
+    x = torch.rand(1, 1, 32, 64, device=gpu)
+    with torch.no_grad():
+        y0 = m.eval()(x)
+    path = str(tmp_path / "ck.pkl")
+    _save_checkpoint(m, path)
+    sd = torch.load(path)
+    assert all(k.startswith("module.") for k in sd)          # reference file format (F9)
+    assert all(v.is_contiguous() for v in sd.values())
+    m2 = M.AutoEncoder_DtoD(height=32, width=64, init_weights=False)
+    load_checkpoint(m2, path)
+    with torch.no_grad():
+        y1 = m2.to(gpu).eval()(x)
+    assert torch.equal(y0, y1)
+    with pytest.raises(GdnError):
+        m(torch.rand(1, 1, 48, 64, device=gpu))               # height/width mismatch with the ctor
+    with pytest.raises(GdnError):
+        m(torch.rand(1, 1, 32, 64))                           # CPU input: no fallback

@@ -60,7 +60,11 @@ def conv3x3_roofline(dev, B, level, reps=20):
 def cpu_baseline(batch=2):
     """The oracle's DtoD training step on the host cores, bounded sample."""
     from oracle import gdn_oracle as O
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 32)))     # torch CPU convs stop scaling (and thrash) well before 256 threads
     sd = O.init_state_dict("AutoEncoder_DtoD", seed=0)
     data = O.synthetic_batch(batch, 128, 416, seed=0)
     st = {}

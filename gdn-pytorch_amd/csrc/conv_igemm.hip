@@ -93,13 +93,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
     const int Ktot = ntap * p.Cred;
     const int nk = SCALAR ? (Ktot + KC - 1) / KC : ntap * nchunks;
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TM][TN], part[TM][TN], zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < TN; ++j) acc[i][j] = zero16;
 
     // ---------------- staging registers ----------------
     constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;       // VEC: 8 threads x 16 B per row
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
                 int iy = (yx & 0xffff) + dy, ix = (yx >> 16) + dx;
                 bool ok = base >= 0;
                 if (p.pad_mode == 1) { iy = reflect_idx(iy, p.Hi); ix = reflect_idx(ix, p.Wi); }
-                else ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+                ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
                 ra[ps] = ok ? *reinterpret_cast<const f32x4*>(src + (size_t)(base + iy * p.Wi + ix) * ld + cb) : zero4;
             }
             const float* wsrc = p.w + (size_t)wi * p.w_tap_stride + ci0 + (tid & 7) * 4;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
                         int iy = (yx & 0xffff) + p.tdy[t], ix = (yx >> 16) + p.tdx[t];
                         bool ok = true;
                         if (p.pad_mode == 1) { iy = reflect_idx(iy, p.Hi); ix = reflect_idx(ix, p.Wi); }
-                        else ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+                        ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
                         if (ok) v = p.x[(size_t)(base + iy * p.Wi + ix) * p.ldx1 + ci];
                     }
                     sa[e] = v;
@@ -210,8 +210,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                        part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
+                                                                          (g == 0 && e == 0) ? zero16 : part[i][j], 0, 0, 0);
         }
+        // Two-level summation: the MFMA is a strictly k-ordered fp32 fma chain, so a single chain
+        // over K = taps*Cin (up to 6.4k terms) would carry sqrt(K) rounding growth.  Each k-step
+        // (32 terms) runs in a fresh chain and is folded into the total here -- the VALU adds hide
+        // under the next k-step's MFMAs.
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += part[i][j];
         __syncthreads();
         if (ks + 1 < nk) {
             lds_store();
@@ -275,16 +284,19 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
 namespace {
 
 struct TileCfg { int bm, bn; };
-// cfg ids: 1: 128x128  2: 128x64  3: 64x64  4: 128x32  (5: scalar-gather 128x64)
-const TileCfg kCfg[6] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 64}};
+// cfg ids: 1: 128x128  2: 128x64  3: 64x64  4: 128x32  (5: scalar-gather 128x64)  6: 32x128  7: 64x128
+#define NUM_CFG 8
+const TileCfg kCfg[NUM_CFG] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 64}, {32, 128}, {64, 128}};
 
 int pick_cfg(int64_t M, int N, bool scalar, int forced) {
+    // Measured on MI355X at B=20 (tools/tune_conv.py): small tiles at 5 waves/SIMD beat 128-wide
+    // ones everywhere (better CU balance, more latency hiding); 32x128 wins for N >= 128, 64x64 for N = 64.
+    (void)M;
     if (scalar) return 5;
-    if (forced >= 1 && forced <= 4) return forced;
+    if ((forced >= 1 && forced <= 4) || forced == 6 || forced == 7) return forced;
     if (N <= 32) return 4;
-    if (N <= 64) return 2;
-    const int64_t blocks128 = cdiv64(M, 128) * cdiv(N, 128);
-    return blocks128 < 512 ? 3 : 1;
+    if (N <= 64) return 3;
+    return 6;
 }
 
 // Builds the phase decomposition of a "transposed-type" gather:
@@ -358,6 +370,8 @@ int launch_igemm(IgemmParams& P, int cfg, hipStream_t st) {
         case 3: launch_one<64, 64, 2, 2, false>(P, st); break;
         case 4: launch_one<128, 32, 4, 1, false>(P, st); break;
         case 5: launch_one<128, 64, 2, 2, true>(P, st); break;
+        case 6: launch_one<32, 128, 1, 4, false>(P, st); break;
+        case 7: launch_one<64, 128, 2, 2, false>(P, st); break;
         default: return GDN_ERR_BAD_ARG;
     }
     return gdn_launch_status();
@@ -404,6 +418,7 @@ __global__ void reflect_fold_kernel(const float* __restrict__ dxp, float* __rest
 }  // namespace
 
 extern "C" int gdn_conv_out_dims(const gdn_conv_geom* g, int32_t* Ho, int32_t* Wo) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!geom_ok(g)) return GDN_ERR_BAD_ARG;
     if (g->transposed) {
         *Ho = (g->H - 1) * g->stride - 2 * g->pad + g->k;
@@ -439,6 +454,7 @@ extern "C" int64_t gdn_conv_stats_slots(const gdn_conv_geom* g, int32_t tile_cfg
 extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* x2, int32_t ldx2,
                             int32_t C1, const float* w, float* y, int32_t ldy, const float* addsrc, int32_t ld_add,
                             float* stats, int32_t act, int32_t tile_cfg, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!geom_ok(g) || !x || !w || !y) return GDN_ERR_BAD_ARG;
     IgemmParams P{};
     if (fill_fwd(g, P) != GDN_OK) return GDN_ERR_BAD_ARG;
@@ -463,6 +479,7 @@ extern "C" size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g) {
 extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* wt, float* dx,
                               int32_t ldx, const float* addsrc, int32_t ld_add, void* workspace,
                               size_t workspace_bytes, int32_t tile_cfg, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!geom_ok(g) || !dy || !wt || !dx) return GDN_ERR_BAD_ARG;
     int Ho, Wo;
     if (gdn_conv_out_dims(g, &Ho, &Wo) != GDN_OK) return GDN_ERR_BAD_ARG;

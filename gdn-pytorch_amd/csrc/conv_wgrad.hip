@@ -34,7 +34,7 @@ struct WgradParams {
 
 template <int WG_NTW>
 __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[WG_TW * WG_ROWS + WG_MAXPOS * WG_SLAB];
+    __shared__ __attribute__((aligned(16))) float smem[WG_TW * WG_ROWS + WG_MAXPOS * WG_SLAB + 64];
     float* Gs = smem;
     float* Xs = smem + WG_TW * WG_ROWS;
 
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
         int iy = oy * p.stride - p.pad + ky;
         bool row_ok = true;
         if (p.pad_mode == 1) iy = reflect_idx(iy, p.Hx);
-        else row_ok = iy >= 0 && iy < p.Hx;
+        row_ok = iy >= 0 && iy < p.Hx;
         // ---- G tile: 32 pixels x 64 channels ----
         const float* gsrc = p.g + (size_t)((size_t)(b * p.Hg + oy) * p.Wg) * p.ldg;
         if (g_vec) {
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
                     int ix = ixb + pos;
                     bool ok = true;
                     if (p.pad_mode == 1) ix = reflect_idx(ix, p.Wx);
-                    else ok = ix >= 0 && ix < p.Wx;
+                    ok = ix >= 0 && ix < p.Wx;     // positions past the row's last pixel pair with zero G
                     if (ok && cx0 + c < p.Cx) v = *reinterpret_cast<const f32x4*>(xsrc + (size_t)ix * p.ldx + cx0 + c);
                 }
                 rx[4 * e + 0] = v[0]; rx[4 * e + 1] = v[1]; rx[4 * e + 2] = v[2]; rx[4 * e + 3] = v[3];
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
                     int ix = ixb + pos;
                     bool ok = true;
                     if (p.pad_mode == 1) ix = reflect_idx(ix, p.Wx);
-                    else ok = ix >= 0 && ix < p.Wx;
+                    ok = ix >= 0 && ix < p.Wx;
                     if (ok && cx0 + c < p.Cx) v = xsrc[(size_t)ix * p.ldx + cx0 + c];
                 }
                 rx[e] = v;
@@ -160,8 +160,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
         }
     };
 
-    const int a_off = wr * 32 + (lane & 31);
     const int h = lane >> 5;
+    // Straight-line inner loop: every wave runs exactly WG_NTW column tiles (wc + 2t); columns past
+    // k*slab read stale-but-finite LDS words whose products are never stored (MFMA columns are
+    // independent), so there is no branch and no mask between the LDS reads and the MFMAs.
+    const float* Gp = Gs + (h * (WG_TW / 2)) * WG_ROWS + wr * 32 + (lane & 31);
+    const int xstep = p.stride * CISL;
+    const float* Xp = Xs + (h * (WG_TW / 2)) * xstep + wc * 32 + (lane & 31);
 
     if (total > 0) {
         gload(0);
@@ -169,20 +174,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
         __syncthreads();
         for (int sidx = 0; sidx < total; ++sidx) {
             if (sidx + 1 < total) gload(sidx + 1);
-#pragma unroll 2
+#pragma unroll 4
             for (int s = 0; s < WG_TW / 2; ++s) {
-                const int pix = h * (WG_TW / 2) + s;
-                const float a = Gs[pix * WG_ROWS + a_off];
-                const int xb = pix * p.stride * CISL + (lane & 31);
+                const float a = Gp[s * WG_ROWS];
+                const float* xr = Xp + s * xstep;
 #pragma unroll
-                for (int t = 0; t < WG_NTW; ++t) {
-                    const int tj = wc + 2 * t;
-                    if (tj < NT) {
-                        const int jj = tj * 32;
-                        const float bv = (jj + (lane & 31) < ncols) ? Xs[xb + jj] : 0.f;
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
-                    }
-                }
+                for (int t = 0; t < WG_NTW; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xr[t * 64], acc[t], 0, 0, 0);
             }
             __syncthreads();
             if (sidx + 1 < total) {
@@ -299,6 +297,7 @@ extern "C" size_t gdn_conv_wgrad_workspace_bytes(const gdn_conv_geom* g, int32_t
 extern "C" int gdn_conv_wgrad(const gdn_conv_geom* g, const float* x, int32_t ldx, int32_t Cx, const float* dy,
                               int32_t ldy, float* dw, int32_t ld_dw, int32_t ci_off, void* workspace,
                               size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!x || !dy || !dw) return GDN_ERR_BAD_ARG;
     WgradPlan pl;
     if (!make_plan(g, Cx, pl)) return GDN_ERR_UNSUPPORTED;

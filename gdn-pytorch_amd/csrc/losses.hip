@@ -224,6 +224,7 @@ extern "C" size_t gdn_loss_workspace_bytes(int64_t npix) {
 extern "C" int gdn_berhu_masked(const float* out, const float* gt, const float* sparse, int32_t Cs, int32_t B, int32_t H,
                                 int32_t W, const int32_t box[4], float* loss, float* dout, void* workspace,
                                 size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!out || !gt || !loss || B <= 0 || H <= 0 || W <= 0) return GDN_ERR_BAD_ARG;
     const int64_t n = (int64_t)B * H * W;
     if (!workspace || workspace_bytes < gdn_loss_workspace_bytes(n)) return GDN_ERR_WORKSPACE;
@@ -242,6 +243,7 @@ extern "C" int gdn_berhu_masked(const float* out, const float* gt, const float* 
 
 extern "C" int gdn_sobel_l1(const float* pred, const float* gt, int32_t B, int32_t H, int32_t W, float weight,
                             float* loss, float* dpred, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!pred || !gt || !loss || B <= 0 || H <= 0 || W <= 0) return GDN_ERR_BAD_ARG;
     const int64_t n = (int64_t)B * H * W;
     if (!workspace || workspace_bytes < gdn_loss_workspace_bytes(n)) return GDN_ERR_WORKSPACE;
@@ -258,6 +260,7 @@ extern "C" int gdn_sobel_l1(const float* pred, const float* gt, int32_t B, int32
 
 extern "C" int gdn_smoothness(const float* depth, const float* img, int32_t Ci, int32_t B, int32_t H, int32_t W,
                               float* loss, float* ddepth, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!depth || !img || !loss || Ci <= 0 || B <= 0 || H <= 0 || W <= 0) return GDN_ERR_BAD_ARG;
     const int64_t n = (int64_t)B * H * W;
     if (!workspace || workspace_bytes < gdn_loss_workspace_bytes(n)) return GDN_ERR_WORKSPACE;
@@ -271,6 +274,7 @@ extern "C" int gdn_smoothness(const float* depth, const float* img, int32_t Ci, 
 
 extern "C" int gdn_mse(const float* a, const float* b, int64_t n, float weight, int32_t accumulate, float* loss,
                        void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!a || !b || !loss || n <= 0) return GDN_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gdn_loss_workspace_bytes(0)) return GDN_ERR_WORKSPACE;
     LossWs w = carve(workspace, 0);

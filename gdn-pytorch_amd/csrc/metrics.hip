@@ -154,6 +154,7 @@ extern "C" size_t gdn_depth_metrics_workspace_bytes(int32_t B, int32_t H, int32_
 extern "C" int gdn_depth_metrics(const float* gt_sparse, const float* gt, const float* pred, int32_t B, int32_t H,
                                  int32_t W, int32_t crop, float* errors, void* workspace, size_t workspace_bytes,
                                  void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!gt_sparse || !gt || !pred || !errors || B <= 0 || H <= 0 || W <= 0) return GDN_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gdn_depth_metrics_workspace_bytes(B, H, W)) return GDN_ERR_WORKSPACE;
     int y1 = 0, y2 = H, x1 = 0, x2 = W;

@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 extern "C" int gdn_bn_finalize_train(const float* stats, int64_t slots, int32_t C, int64_t count, const float* gamma,
                                      const float* beta, float* running_mean, float* running_var, float momentum,
                                      float eps, float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!stats || slots <= 0 || C <= 0 || count <= 0 || !scale || !shift) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(256), 0, ST(stream), stats, slots, C, (double)count,
                        gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
@@ -357,6 +358,7 @@ extern "C" int gdn_bn_finalize_train(const float* stats, int64_t slots, int32_t 
 extern "C" int gdn_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                                   const float* running_var, float eps, int32_t C, float* scale, float* shift,
                                   void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!running_mean || !running_var || C <= 0 || !scale || !shift) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST(stream), gamma, beta, running_mean,
                        running_var, eps, C, scale, shift);
@@ -366,6 +368,7 @@ extern "C" int gdn_bn_eval_coeffs(const float* gamma, const float* beta, const f
 extern "C" int gdn_bn_apply(const float* y, int32_t ldy, const float* scale, const float* shift, const float* residual,
                             int32_t ld_res, float* out, int32_t ld_out, int64_t npix, int32_t C, int32_t relu,
                             void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!y || !scale || !shift || !out || npix <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     if ((C % 4) || (ldy % 4) || (ld_out % 4) || (residual && (ld_res % 4))) return GDN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, ST(stream), y, ldy, scale,
@@ -387,6 +390,7 @@ extern "C" int gdn_bn_bwd(const float* dout, int32_t ld_dout, const float* y, in
                           const float* scale, const float* shift, const float* mean, const float* invstd, float* dy,
                           int32_t ld_dy, float* dgamma, float* dbeta, int64_t npix, int32_t C, int32_t relu,
                           void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     (void)gamma;
     if (!dout || !y || !scale || !shift || !mean || !invstd || !dy || npix <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     if ((C % 4) || (ldy % 4) || (ld_dout % 4) || (ld_dy % 4)) return GDN_ERR_UNSUPPORTED;
@@ -407,6 +411,7 @@ extern "C" int gdn_bn_bwd(const float* dout, int32_t ld_dout, const float* y, in
 
 extern "C" int gdn_upsample2x_fwd(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C,
                                   int32_t align_corners, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     if (C % 4) return GDN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(stream_blocks((int64_t)B * 4 * H * W * (C / 4))), dim3(256), 0,
@@ -416,6 +421,7 @@ extern "C" int gdn_upsample2x_fwd(const float* x, float* y, int32_t B, int32_t H
 
 extern "C" int gdn_upsample2x_bwd(const float* dy, float* dx, int32_t B, int32_t H, int32_t W, int32_t C,
                                   int32_t align_corners, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     if (C % 4) return GDN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(stream_blocks((int64_t)B * H * W * (C / 4))), dim3(256), 0,
@@ -424,12 +430,14 @@ extern "C" int gdn_upsample2x_bwd(const float* dy, float* dx, int32_t B, int32_t
 }
 
 extern "C" int gdn_nchw_to_nhwc(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_blocks((int64_t)B * C * H * W)), dim3(256), 0, ST(stream), x, y,
                        B, C, H * W);
     return gdn_launch_status();
 }
 extern "C" int gdn_nhwc_to_nchw(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(stream_blocks((int64_t)B * C * H * W)), dim3(256), 0, ST(stream), x, y,
                        B, C, H * W);
@@ -437,6 +445,7 @@ extern "C" int gdn_nhwc_to_nchw(const float* x, float* y, int32_t B, int32_t C, 
 }
 
 extern "C" int gdn_transpose_taps(const float* w, float* wt, int32_t ntaps, int32_t R, int32_t C, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!w || !wt || ntaps <= 0 || R <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(C, 32), cdiv(R, 32), ntaps), dim3(256), 0, ST(stream), w, wt, R,
                        C);
@@ -445,6 +454,7 @@ extern "C" int gdn_transpose_taps(const float* w, float* wt, int32_t ntaps, int3
 
 extern "C" int gdn_weight_to_tapmajor(const float* w_torch, float* w_tap, int32_t Cout, int32_t Cin, int32_t ntaps,
                                       int32_t a_is_cout, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!w_torch || !w_tap || Cout <= 0 || Cin <= 0 || ntaps <= 0) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(weight_tapmajor_kernel, dim3(stream_blocks((int64_t)Cout * Cin * ntaps)), dim3(256), 0,
                        ST(stream), w_torch, w_tap, Cout, Cin, ntaps, a_is_cout, 1);
@@ -452,6 +462,7 @@ extern "C" int gdn_weight_to_tapmajor(const float* w_torch, float* w_tap, int32_
 }
 extern "C" int gdn_weight_from_tapmajor(const float* w_tap, float* w_torch, int32_t Cout, int32_t Cin, int32_t ntaps,
                                         int32_t a_is_cout, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!w_torch || !w_tap || Cout <= 0 || Cin <= 0 || ntaps <= 0) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(weight_tapmajor_kernel, dim3(stream_blocks((int64_t)Cout * Cin * ntaps)), dim3(256), 0,
                        ST(stream), w_tap, w_torch, Cout, Cin, ntaps, a_is_cout, 0);
@@ -459,16 +470,19 @@ extern "C" int gdn_weight_from_tapmajor(const float* w_tap, float* w_torch, int3
 }
 
 extern "C" int gdn_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!a || !b || !out || n <= 0) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(add_kernel, dim3(stream_blocks(n / 4 + 1)), dim3(256), 0, ST(stream), a, b, out, n);
     return gdn_launch_status();
 }
 extern "C" int gdn_tanh_bwd(const float* dout, const float* out, float* dpre, int64_t n, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!dout || !out || !dpre || n <= 0) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(tanh_bwd_kernel, dim3(stream_blocks(n)), dim3(256), 0, ST(stream), dout, out, dpre, n);
     return gdn_launch_status();
 }
 extern "C" int gdn_fill(float* p, float value, int64_t n, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!p || n <= 0) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(fill_kernel, dim3(stream_blocks(n)), dim3(256), 0, ST(stream), p, value, n);
     return gdn_launch_status();
@@ -476,6 +490,7 @@ extern "C" int gdn_fill(float* p, float value, int64_t n, void* stream) {
 
 extern "C" int gdn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!p || !g || !m || !v || n <= 0 || step < 1) return GDN_ERR_BAD_ARG;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);

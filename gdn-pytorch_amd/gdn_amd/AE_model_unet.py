@@ -57,8 +57,9 @@ class _Bridge(torch.autograd.Function):
 
     @staticmethod
     def forward(fctx, module, arena, need_grad, select, x, anchor):
-        ctx = E.Ctx(record=need_grad, arena=arena)
+        ctx = E.Ctx(record=need_grad, arena=arena, input_needs_grad=need_grad and x.requires_grad)
         xin = E.to_nhwc(x)
+        ctx.input = xin
         outs = module._run(ctx, xin)
         outs = tuple(outs[i] for i in select)
         fctx.gdn = (ctx, outs, arena)
@@ -77,7 +78,11 @@ class _Bridge(torch.autograd.Function):
         ctx.backward()
         for p, old in pending:       # a caller-owned .grad existed: accumulate like autograd would
             p.grad.add_(old)
-        return None, None, None, None, None, None
+        dx = None
+        if ctx.input_needs_grad:
+            g = ctx.pop_grad(ctx.input)
+            dx = None if g is None else E.to_nchw_view(g)
+        return None, None, None, None, dx, None
 
 
 # ----------------------------------------------------------------------------

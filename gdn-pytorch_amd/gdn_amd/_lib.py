@@ -79,6 +79,10 @@ class _Lib:
             raise GdnError(
                 "libgdn_hip.so not found at %s -- build it with `python gdn-pytorch_amd/build.py` "
                 "(there is no CPU fallback)" % LIB_PATH)
+        # torch's wheel bundles its own libamdhip64 (same SONAME as /opt/rocm's).  It must be in the
+        # process BEFORE our library is opened so both bind to ONE HIP runtime; loaded the other way
+        # round the two runtimes coexist and every launch on a torch stream fails.
+        import torch  # noqa: F401
         dll = ctypes.CDLL(str(LIB_PATH))
         for name, (res, args) in _SIGS.items():
             fn = getattr(dll, name)      # AttributeError if the symbol is missing: fail loudly

@@ -103,11 +103,17 @@ def ensure_arena(module, device):
 # Tape
 # ----------------------------------------------------------------------------
 class Ctx:
-    def __init__(self, record, arena=None):
+    def __init__(self, record, arena=None, input_needs_grad=False):
         self.record = record
         self.tape = []
         self.arena = arena
         self.grads = {}
+        self.input = None                      # the model's NHWC input buffer
+        self.input_needs_grad = input_needs_grad
+
+    def wants_dx(self, x):
+        """Data gradients stop at the network input unless the caller asked for them."""
+        return x is not self.input or self.input_needs_grad
 
     # gradient slots are keyed by tensor identity
     def add_grad(self, t, g):
@@ -208,7 +214,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                 ctx.add_grad(residual, da)
             dy = ops.bn_bwd(da, y, bn.weight.data, co, relu, bn.weight.grad, bn.bias.grad)
             _wgrad_into(ctx, conv, x, dy, x2)
-            if need_dx:
+            if need_dx and ctx.wants_dx(x):
                 wt = ops.transpose_taps(w)
                 if x2 is None:
                     dx = op.dgrad(dy, wt, in_hw, addsrc=ctx.pop_grad(x))

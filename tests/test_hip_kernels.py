@@ -15,7 +15,9 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-3
 
 
-def close(got, ref, rtol=RTOL, atol_scale=1e-4, what=""):
+def close(got, ref, rtol=RTOL, atol_scale=1e-4, what="", outliers=0.0):
+    """|got-ref| <= atol_scale*max|ref| + rtol*|ref| element-wise.  `outliers` is the fraction of
+    elements allowed to miss (sign flips of L1-type gradients where the argument crosses zero)."""
     got = got.detach().cpu().double()
     ref = ref.detach().cpu().double()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
@@ -23,7 +25,7 @@ def close(got, ref, rtol=RTOL, atol_scale=1e-4, what=""):
     err = (got - ref).abs()
     tol = atol_scale * scale + rtol * ref.abs()
     bad = err > tol
-    assert not bool(bad.any()), "%s: %d/%d elements off, max err %.3e (scale %.3e)" % (
+    assert int(bad.sum()) <= outliers * bad.numel(), "%s: %d/%d elements off, max err %.3e (scale %.3e)" % (
         what, int(bad.sum()), bad.numel(), float(err.max()), scale)
 
 
@@ -121,7 +123,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, case):
     close(dw, tapmajor(w.grad, tr), rtol=2e-3, atol_scale=2e-4, what=name + " wgrad")
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 6, 7])
 def test_conv_tile_configs_agree(gpu, cfg):
     from gdn_amd import ops
     case = ("t", 128, 256, 3, 1, 1, False, False, 2, 16, 20)

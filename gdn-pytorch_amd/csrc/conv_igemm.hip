@@ -37,6 +37,7 @@ struct IgemmParams {
     int stride, pad_mode, act, nphase;
     int Cred, w_tap_stride;
     int grid_m, grid_n;
+    unsigned x_bytes, x2_bytes, w_bytes;   // extents for the buffer descriptors (< 4 GiB each)
     IgemmPhase ph[MAX_PHASE];
     short tdy[MAX_TAPS], tdx[MAX_TAPS], twi[MAX_TAPS];
 };
@@ -109,31 +110,65 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
     float sa[SCALAR ? A_E : 1], sb[SCALAR ? B_E : 1];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    auto gload = [&](int ks) {
+    // Loop-invariant address pieces (VEC path).  The k-steps walk taps in the outer loop and
+    // 32-channel slabs in the inner one; a row's gather position depends on the tap only, so the
+    // bounds / reflection logic runs once per tap, not once per k-step, and B rows never change.
+    // All tile loads are raw buffer loads: the per-lane part is a 32-bit byte offset, the per-k-step
+    // part (tap, slab) rides in the scalar offset, and rows that must read as zero (padding, M/N
+    // tails) simply carry an out-of-range offset -- the hardware range check returns 0, so there is
+    // no branch, no select and no 64-bit address arithmetic in the loop.  On this chip the fp32
+    // MFMA shares the vector ALUs (measured: time/MFMA ~ 64 + 4 * VALU-per-MFMA cycles), so every
+    // VALU instruction removed from the k-step is MFMA time won back.
+    int aoff[SCALAR ? 1 : A_PASSES];               // gathered pixel index of this thread's rows, -1 = zero
+    unsigned boff[SCALAR ? 1 : B_PASSES];          // byte offset of (row n, 16-B lane chunk), OOB = row beyond N
+    int tl_n = 0, cc_n = 0, wi_n = 0;              // prefetch cursor: tap, slab, weight tap index
+    const unsigned lane_b = (unsigned)(tid & 7) * 16u;
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x2 ? p.x2 : p.x), 0,
+                                                                     (int)(p.x2 ? p.x2_bytes : p.x_bytes), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+    if constexpr (!SCALAR) {
+#pragma unroll
+        for (int ps = 0; ps < B_PASSES; ++ps) {
+            const int n = n0 + ps * 32 + (tid >> 3);
+            boff[ps] = n < p.N ? (unsigned)(n * p.Cred) * 4u + lane_b : 0xFFFFFF00u;
+        }
+    }
+    auto set_tap = [&](int tl) {
         if constexpr (!SCALAR) {
-            const int tl = ks / nchunks, cc = ks - tl * nchunks, t = ph.tap_begin + tl;
-            const int dy = p.tdy[t], dx = p.tdx[t], wi = p.twi[t];
-            const int ci0 = cc * KC;
-            const float* src; int ld, cb;
-            if (ci0 < p.C1) { src = p.x; ld = p.ldx1; cb = ci0; }
-            else { src = p.x2; ld = p.ldx2; cb = ci0 - p.C1; }
-            cb += (tid & 7) * 4;
+            const int t = ph.tap_begin + tl;
+            const int dy = p.tdy[t], dx = p.tdx[t];
+            wi_n = p.twi[t];
 #pragma unroll
             for (int ps = 0; ps < A_PASSES; ++ps) {
                 const int r = ps * 32 + (tid >> 3);
                 const int base = row_pix[r], yx = row_yx[r];
                 int iy = (yx & 0xffff) + dy, ix = (yx >> 16) + dx;
-                bool ok = base >= 0;
                 if (p.pad_mode == 1) { iy = reflect_idx(iy, p.Hi); ix = reflect_idx(ix, p.Wi); }
-                ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-                ra[ps] = ok ? *reinterpret_cast<const f32x4*>(src + (size_t)(base + iy * p.Wi + ix) * ld + cb) : zero4;
+                const bool ok = base >= 0 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+                aoff[ps] = ok ? base + iy * p.Wi + ix : -1;       // -1 * ld*4 wraps far out of range
             }
-            const float* wsrc = p.w + (size_t)wi * p.w_tap_stride + ci0 + (tid & 7) * 4;
+        }
+    };
+
+    auto gload = [&](int ks) {
+        if constexpr (!SCALAR) {
+            if (cc_n == 0) set_tap(tl_n);
+            const int ci0 = cc_n * KC;
+            const bool first = ci0 < p.C1;
+            const unsigned ld4 = (unsigned)(first ? p.ldx1 : p.ldx2) * 4u;
+            const int soff = (first ? ci0 : ci0 - p.C1) * 4;
 #pragma unroll
-            for (int ps = 0; ps < B_PASSES; ++ps) {
-                const int n = n0 + ps * 32 + (tid >> 3);
-                rb[ps] = n < p.N ? *reinterpret_cast<const f32x4*>(wsrc + (size_t)n * p.Cred) : zero4;
+            for (int ps = 0; ps < A_PASSES; ++ps) {
+                const unsigned vo = (unsigned)aoff[ps] * ld4 + lane_b;
+                ra[ps] = __builtin_bit_cast(f32x4, first ? __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, soff, 0)
+                                                         : __builtin_amdgcn_raw_buffer_load_b128(rs_x2, vo, soff, 0));
             }
+            const int soff_w = (wi_n * p.w_tap_stride + ci0) * 4;
+#pragma unroll
+            for (int ps = 0; ps < B_PASSES; ++ps)
+                rb[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, boff[ps], soff_w, 0));
+            if (++cc_n == nchunks) { cc_n = 0; ++tl_n; }
         } else {
             {
                 const int r = tid % BM, kp = tid / BM;
@@ -195,37 +230,42 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
     gload(0);
     lds_store();
     __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-        if (ks + 1 < nk) gload(ks + 1);
+    // Two-level summation: the MFMA is a strictly k-ordered fp32 fma chain, so one chain over
+    // K = taps*Cin (up to 6.4k terms) would carry sqrt(K) rounding growth.  FOLD k-steps (128 terms)
+    // run in a fresh chain (C = 0 on the first MFMA) and are then folded into the running total.
+    constexpr int FOLD = 4;
+    for (int ks0 = 0; ks0 < nk; ks0 += FOLD) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 af[TM], bf[TN];
+        for (int j = 0; j < FOLD; ++j) {
+            const int ks = ks0 + j;
+            if (ks >= nk) break;
+            if (ks + 1 < nk) gload(ks + 1);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[a_off + i * 32 * LDS_LD + g * 4]);
+            for (int g = 0; g < 4; ++g) {
+                f32x4 af[TM], bf[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(&Bs[b_off + j * 32 * LDS_LD + g * 4]);
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[a_off + i * 32 * LDS_LD + g * 4]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int jn = 0; jn < TN; ++jn) bf[jn] = *reinterpret_cast<const f32x4*>(&Bs[b_off + jn * 32 * LDS_LD + g * 4]);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
-                                                                          (g == 0 && e == 0) ? zero16 : part[i][j], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < TN; ++jn)
+                            part[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                af[i][e], bf[jn][e], (j == 0 && g == 0 && e == 0) ? zero16 : part[i][jn], 0, 0, 0);
+            }
+            __syncthreads();
+            if (ks + 1 < nk) {
+                lds_store();
+                __syncthreads();
+            }
         }
-        // Two-level summation: the MFMA is a strictly k-ordered fp32 fma chain, so a single chain
-        // over K = taps*Cin (up to 6.4k terms) would carry sqrt(K) rounding growth.  Each k-step
-        // (32 terms) runs in a fresh chain and is folded into the total here -- the VALU adds hide
-        // under the next k-step's MFMAs.
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] += part[i][j];
-        __syncthreads();
-        if (ks + 1 < nk) {
-            lds_store();
-            __syncthreads();
-        }
+            for (int jn = 0; jn < TN; ++jn) acc[i][jn] += part[i][jn];
     }
 
     // ---------------- epilogue ----------------
@@ -282,6 +322,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
 // Host side: geometry -> phases / tap lists, tile selection, launch.
 // ---------------------------------------------------------------------------
 namespace {
+
+// Buffer descriptors address 32 bits; out-of-range sentinels sit just below 4 GiB.
+const uint64_t kMaxBufBytes = 0xFF000000ull;
 
 struct TileCfg { int bm, bn; };
 // cfg ids: 1: 128x128  2: 128x64  3: 64x64  4: 128x32  (5: scalar-gather 128x64)  6: 32x128  7: 64x128
@@ -465,6 +508,13 @@ extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx,
     if (!scalar && ((C1 % KC) || (ldx % 4) || (x2 && (ldx2 % 4)))) return GDN_ERR_UNSUPPORTED;
     P.x = x; P.x2 = x2; P.w = w; P.y = y; P.addsrc = addsrc; P.stats = stats;
     P.C1 = C1; P.C2 = g->Cin - C1; P.ldx1 = ldx; P.ldx2 = ldx2; P.ldy = ldy; P.ld_add = ld_add; P.act = act;
+    {
+        const uint64_t npix = (uint64_t)g->B * g->H * g->W;
+        const uint64_t xb = ((npix - 1) * (uint64_t)ldx + C1) * 4, x2b = x2 ? ((npix - 1) * (uint64_t)ldx2 + P.C2) * 4 : 0;
+        const uint64_t wb = (uint64_t)g->k * g->k * g->Cout * g->Cin * 4;
+        if (xb >= kMaxBufBytes || x2b >= kMaxBufBytes || wb >= kMaxBufBytes) return GDN_ERR_UNSUPPORTED;
+        P.x_bytes = (unsigned)xb; P.x2_bytes = (unsigned)x2b; P.w_bytes = (unsigned)wb;
+    }
     const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg);
     return launch_igemm(P, cfg, (hipStream_t)stream);
 }
@@ -489,6 +539,12 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const float* dy, int32_t l
     P.N = g->Cin; P.Cred = g->Cout; P.C1 = g->Cout; P.C2 = 0;
     P.w_tap_stride = g->Cin * g->Cout;
     P.x = dy; P.ldx1 = ldy; P.w = wt; P.pad_mode = 0; P.act = GDN_ACT_NONE;
+    {
+        const uint64_t xb = (((uint64_t)g->B * Ho * Wo - 1) * (uint64_t)ldy + g->Cout) * 4;
+        const uint64_t wb = (uint64_t)g->k * g->k * g->Cout * g->Cin * 4;
+        if (xb >= kMaxBufBytes || wb >= kMaxBufBytes) return GDN_ERR_UNSUPPORTED;
+        P.x_bytes = (unsigned)xb; P.x2_bytes = 0; P.w_bytes = (unsigned)wb;
+    }
     const bool scalar = (g->Cout % KC) != 0;
     if (!scalar && (ldy % 4)) return GDN_ERR_UNSUPPORTED;
     const bool fold = !g->transposed && g->pad_mode == 1 && g->pad > 0;

@@ -18,11 +18,11 @@
 //     second kernel in a fixed order: bitwise reproducible, no atomics.
 #include "common.h"
 
-#define WG_TW 32          // pixels per row segment (MFMA K' per LDS image)
 #define WG_ROWS 64        // channels of G per workgroup
 #define WG_SLAB 64        // max channels of X per workgroup
-#define WG_MAXPOS 72      // >= 31*2 + 9
 #define WG_NTW_MAX 9      // max 32-column tiles per wave
+// Pixels per row segment (the MFMA K' of one LDS image) are chosen per layer (even, <= TWMAX) so that
+// segments tile the image width exactly: 32 for W=416, 52 for W in {208,104,52}, 26 for W=26.
 
 struct WgradParams {
     const float* g; const float* x; float* part;
@@ -30,13 +30,21 @@ struct WgradParams {
     int Hx, Wx, ldx, Cx;
     int k, stride, pad, pad_mode;
     int cisl, n_cgt, n_cxt, S, rows_per_split;
+    int tw;                         // pixels per row segment
+    unsigned g_bytes, x_bytes;      // extents for the buffer descriptors (< 4 GiB each)
 };
 
-template <int WG_NTW>
+template <int WG_NTW, int TWMAX>
 __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[WG_TW * WG_ROWS + WG_MAXPOS * WG_SLAB + 64];
+    constexpr int MAXPOS = (TWMAX - 1) * 2 + 9;                 // stride <= 2, k <= 9
+    constexpr int GV = TWMAX * WG_ROWS / 4 / 256;               // 16-B G loads per thread
+    constexpr int XV = (MAXPOS * WG_SLAB / 4 + 255) / 256;      // 16-B X loads per thread
+    __shared__ __attribute__((aligned(16))) float smem[TWMAX * WG_ROWS + MAXPOS * WG_SLAB + 64];
     float* Gs = smem;
-    float* Xs = smem + WG_TW * WG_ROWS;
+    float* Xs = smem + TWMAX * WG_ROWS;
+    // TWMAX == 32 is only launched with tw == 32: compile-time trip counts keep the 9-tile variant
+    // at 2 waves/SIMD; every other segment width runs the TWMAX == 64 instantiation.
+    const int WG_TW = (TWMAX == 32) ? 32 : p.tw;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave & 1, wc = wave >> 1;
@@ -66,27 +74,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
     const int nseg = (p.Wg + WG_TW - 1) / WG_TW;
     const int total = (r1 - r0) * nseg;
 
-    float rg[8], rx[20];
+    float rg[GV * 4 > 8 ? GV * 4 : 8], rx[XV * 4];
+
+    // Per-thread constants of the vector load paths.  Tile loads are raw buffer loads: the lane part
+    // is a constant 32-bit byte offset, the row/segment part rides in the scalar offset, and anything
+    // that must read as zero (row tail, padding, channel tail) gets an out-of-range offset instead of
+    // a branch -- VALU instructions compete with the fp32 MFMA for the same ALUs.
+    const unsigned OOB = 0xFFFFFF00u;
+    __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, (int)p.g_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    unsigned g_lane[GV]; int g_px[GV];
+#pragma unroll
+    for (int e = 0; e < GV; ++e) {
+        const int idx = tid + 256 * e, c = (idx & 15) * 4;
+        g_px[e] = idx >> 4;
+        g_lane[e] = (cg0 + c < p.Cg) ? (unsigned)(g_px[e] * p.ldg + cg0 + c) * 4u : OOB;
+    }
+    const int q4 = CISL >> 2;
+    unsigned x_lane[XV]; int x_pos[XV];
+#pragma unroll
+    for (int e = 0; e < XV; ++e) {
+        const int idx = tid + 256 * e;
+        const int pos = x_vec ? idx / q4 : 0, c = x_vec ? (idx - pos * q4) * 4 : 0;
+        x_pos[e] = (x_vec && pos < npos) ? pos : -0x40000000;          // far out of any row
+        x_lane[e] = (cx0 + c < p.Cx) ? (unsigned)(cx0 + c) * 4u : OOB;
+    }
 
     auto gload = [&](int sidx) {
         const int r = r0 + sidx / nseg, ox0 = (sidx % nseg) * WG_TW;
         const int b = r / p.Hg, oy = r % p.Hg;
         int iy = oy * p.stride - p.pad + ky;
-        bool row_ok = true;
         if (p.pad_mode == 1) iy = reflect_idx(iy, p.Hx);
-        row_ok = iy >= 0 && iy < p.Hx;
+        const bool row_ok = iy >= 0 && iy < p.Hx;
         // ---- G tile: 32 pixels x 64 channels ----
-        const float* gsrc = p.g + (size_t)((size_t)(b * p.Hg + oy) * p.Wg) * p.ldg;
         if (g_vec) {
+            const int soff = (int)((unsigned)(((b * p.Hg + oy) * p.Wg + ox0) * p.ldg) * 4u);
+            const int wrem = row_ok ? min(p.Wg - ox0, WG_TW) : 0;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int idx = tid + 256 * e, px = idx >> 4, c = (idx & 15) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (row_ok && ox0 + px < p.Wg && cg0 + c < p.Cg)
-                    v = *reinterpret_cast<const f32x4*>(gsrc + (size_t)(ox0 + px) * p.ldg + cg0 + c);
+            for (int e = 0; e < GV; ++e) {
+                const unsigned vo = g_px[e] < wrem ? g_lane[e] : OOB;
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, vo, soff, 0));
                 rg[4 * e + 0] = v[0]; rg[4 * e + 1] = v[1]; rg[4 * e + 2] = v[2]; rg[4 * e + 3] = v[3];
             }
         } else {
+            const float* gsrc = p.g + (size_t)((size_t)(b * p.Hg + oy) * p.Wg) * p.ldg;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int idx = tid + 256 * e, px = idx >> 6, c = idx & 63;
@@ -96,47 +127,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
             }
         }
         // ---- X row segment: npos positions x CISL channels ----
-        const float* xsrc = p.x + (size_t)((size_t)(b * p.Hx + iy) * p.Wx) * p.ldx;
         const int ixb = ox0 * p.stride - p.pad;
         if (x_vec) {
-            const int q4 = CISL >> 2, n4 = npos * q4;
+            const int soff = row_ok ? (int)((unsigned)((b * p.Hx + iy) * p.Wx * p.ldx) * 4u) : 0;
+            const unsigned ldx4 = (unsigned)p.ldx * 4u;
 #pragma unroll
-            for (int e = 0; e < 5; ++e) {
-                const int idx = tid + 256 * e;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (idx < n4 && row_ok) {
-                    const int pos = idx / q4, c = (idx - pos * q4) * 4;
-                    int ix = ixb + pos;
-                    bool ok = true;
-                    if (p.pad_mode == 1) ix = reflect_idx(ix, p.Wx);
-                    ok = ix >= 0 && ix < p.Wx;     // positions past the row's last pixel pair with zero G
-                    if (ok && cx0 + c < p.Cx) v = *reinterpret_cast<const f32x4*>(xsrc + (size_t)ix * p.ldx + cx0 + c);
-                }
+            for (int e = 0; e < XV; ++e) {
+                int ix = ixb + x_pos[e];
+                if (p.pad_mode == 1) ix = reflect_idx(ix, p.Wx);
+                const bool ok = row_ok && ix >= 0 && ix < p.Wx;     // positions past the row pair with zero G
+                const unsigned vo = ok ? (unsigned)ix * ldx4 + x_lane[e] : OOB;
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, soff, 0));
                 rx[4 * e + 0] = v[0]; rx[4 * e + 1] = v[1]; rx[4 * e + 2] = v[2]; rx[4 * e + 3] = v[3];
             }
         } else {
+            const float* xsrc = p.x + (size_t)((size_t)(b * p.Hx + (row_ok ? iy : 0)) * p.Wx) * p.ldx;
             const int n1 = npos * CISL;   // <= 72*3
-#pragma unroll
-            for (int e = 0; e < 1; ++e) {
-                const int idx = tid + 256 * e;
-                float v = 0.f;
-                if (idx < n1 && row_ok) {
-                    const int pos = idx / CISL, c = idx - pos * CISL;
-                    int ix = ixb + pos;
-                    bool ok = true;
-                    if (p.pad_mode == 1) ix = reflect_idx(ix, p.Wx);
-                    ok = ix >= 0 && ix < p.Wx;
-                    if (ok && cx0 + c < p.Cx) v = xsrc[(size_t)ix * p.ldx + cx0 + c];
-                }
-                rx[e] = v;
+            const int idx = tid;
+            float v = 0.f;
+            if (idx < n1 && row_ok) {
+                const int pos = idx / CISL, c = idx - pos * CISL;
+                int ix = ixb + pos;
+                if (p.pad_mode == 1) ix = reflect_idx(ix, p.Wx);
+                if (ix >= 0 && ix < p.Wx && cx0 + c < p.Cx) v = xsrc[(size_t)ix * p.ldx + cx0 + c];
             }
+            rx[0] = v;
         }
     };
 
     auto lstore = [&]() {
         if (g_vec) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < GV; ++e) {
                 const int idx = tid + 256 * e;
                 f32x4 v = {rg[4 * e], rg[4 * e + 1], rg[4 * e + 2], rg[4 * e + 3]};
                 *reinterpret_cast<f32x4*>(&Gs[idx * 4]) = v;     // [px][64]: idx*4 == px*64 + c
@@ -148,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
         if (x_vec) {
             const int n4 = npos * (CISL >> 2);
 #pragma unroll
-            for (int e = 0; e < 5; ++e) {
+            for (int e = 0; e < XV; ++e) {
                 const int idx = tid + 256 * e;
                 if (idx < n4) {
                     f32x4 v = {rx[4 * e], rx[4 * e + 1], rx[4 * e + 2], rx[4 * e + 3]};
@@ -164,9 +186,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
     // Straight-line inner loop: every wave runs exactly WG_NTW column tiles (wc + 2t); columns past
     // k*slab read stale-but-finite LDS words whose products are never stored (MFMA columns are
     // independent), so there is no branch and no mask between the LDS reads and the MFMAs.
-    const float* Gp = Gs + (h * (WG_TW / 2)) * WG_ROWS + wr * 32 + (lane & 31);
+    const int nsub = WG_TW / 2;      // MFMA k-substeps per segment; lane half h owns pixels [h*nsub, (h+1)*nsub)
+    const float* Gp = Gs + (h * nsub) * WG_ROWS + wr * 32 + (lane & 31);
     const int xstep = p.stride * CISL;
-    const float* Xp = Xs + (h * (WG_TW / 2)) * xstep + wc * 32 + (lane & 31);
+    const float* Xp = Xs + (h * nsub) * xstep + wc * 32 + (lane & 31);
 
     if (total > 0) {
         gload(0);
@@ -175,7 +198,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
         for (int sidx = 0; sidx < total; ++sidx) {
             if (sidx + 1 < total) gload(sidx + 1);
 #pragma unroll 4
-            for (int s = 0; s < WG_TW / 2; ++s) {
+            for (int s = 0; s < nsub; ++s) {
                 const float a = Gp[s * WG_ROWS];
                 const float* xr = Xp + s * xstep;
 #pragma unroll
@@ -269,18 +292,48 @@ bool make_plan(const gdn_conv_geom* g, int Cx_in, WgradPlan& pl) {
     }
     P.cisl = P.Cx < WG_SLAB ? P.Cx : WG_SLAB;
     if (P.Cx > WG_SLAB && (P.Cx % WG_SLAB)) return false;
-    if ((WG_TW - 1) * P.stride + P.k > WG_MAXPOS) return false;
+    // segment width: even, tiles the row exactly when the width allows it
+    {
+        const bool thin = (P.Cg % 4 != 0) || (P.cisl % 4 != 0);      // scalar-load layers keep 32
+        int best = 32;
+        if (!thin) {
+            double best_eff = 0.0;
+            for (int tw = 64; tw >= 16; tw -= 2) {
+                const double eff = (double)P.Wg / (double)(cdiv(P.Wg, tw) * tw) * (tw >= 32 ? 1.0 : 0.97);
+                if (eff > best_eff + 1e-9) { best_eff = eff; best = tw; }
+            }
+        }
+        P.tw = best;
+    }
     if (((P.k * P.cisl + 31) / 32 + 1) / 2 > WG_NTW_MAX) return false;
-    if (P.cisl % 4 != 0 && ((WG_TW - 1) * P.stride + P.k) * P.cisl > 256) return false;
+    if (P.cisl % 4 != 0 && ((P.tw - 1) * P.stride + P.k) * P.cisl > 256) return false;
     P.n_cgt = cdiv(P.Cg, WG_ROWS);
     P.n_cxt = cdiv(P.Cx, P.cisl);
     const int base = P.k * P.n_cgt * P.n_cxt;
     const int R = P.B * P.Hg;
-    int S = cdiv(1024, base);
-    if (S < 1) S = 1;
-    if (S > R) S = R;
-    P.rows_per_split = cdiv(R, S);
-    P.S = cdiv(R, P.rows_per_split);
+    // Split-K factor: fill the chip with whole "rounds" of resident workgroups (256 CUs x occupancy
+    // of the instantiation), at least one full round, at most ~6.
+    {
+        const int ntw = ((P.k * P.cisl + 31) / 32 + 1) / 2;
+        const bool tw32 = P.tw == 32;
+        const int occ = ntw <= 1 ? (tw32 ? 4 : 3) : ntw <= 3 ? (tw32 ? 3 : 2) : ntw <= 7 ? 2 : (tw32 ? 2 : 1);
+        const int slots = 256 * occ;
+        int bestS = 1; double best = -1.0;
+        const int smax = R < 256 ? R : 256;
+        for (int S = 1; S <= smax; ++S) {
+            const int rps = cdiv(R, S);
+            const int Se = cdiv(R, rps);                  // effective split count
+            const double fill = (double)base * Se / slots;
+            if (fill > 4.0 && best > 0) break;
+            const double rounds = fill < 1.0 ? 1.0 : (double)cdiv(base * Se, slots);
+            double eff = fill / rounds;                   // resident-slot utilisation
+            eff *= (double)R / ((double)rps * Se);        // rows wasted in the last split
+            eff *= 1.0 - 0.15 / rounds;                   // several rounds balance better than one (measured)
+            if (eff > best + 0.01) { best = eff; bestS = S; }
+        }
+        P.rows_per_split = cdiv(R, bestS);
+        P.S = cdiv(R, P.rows_per_split);
+    }
     pl.blocks = base * P.S;
     pl.ws_bytes = (size_t)P.S * P.k * P.k * P.Cg * P.Cx * sizeof(float);
     return true;
@@ -307,13 +360,26 @@ extern "C" int gdn_conv_wgrad(const gdn_conv_geom* g, const float* x, int32_t ld
     if (x_is_g) { P.g = x; P.ldg = ldx; P.x = dy; P.ldx = ldy; }
     else { P.g = dy; P.ldg = ldy; P.x = x; P.ldx = ldx; }
     P.part = (float*)workspace;
+    {
+        const uint64_t gb = (((uint64_t)P.B * P.Hg * P.Wg - 1) * (uint64_t)P.ldg + P.Cg) * 4;
+        const uint64_t xb = (((uint64_t)P.B * P.Hx * P.Wx - 1) * (uint64_t)P.ldx + P.Cx) * 4;
+        if (gb >= 0xFF000000ull || xb >= 0xFF000000ull) return GDN_ERR_UNSUPPORTED;
+        P.g_bytes = (unsigned)gb; P.x_bytes = (unsigned)xb;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int ntw = ((P.k * P.cisl + 31) / 32 + 1) / 2;   // column tiles per wave
-    if (ntw <= 1) hipLaunchKernelGGL(conv_wgrad_f32<1>, dim3(pl.blocks), dim3(256), 0, st, P);
-    else if (ntw <= 3) hipLaunchKernelGGL(conv_wgrad_f32<3>, dim3(pl.blocks), dim3(256), 0, st, P);
-    else if (ntw <= 5) hipLaunchKernelGGL(conv_wgrad_f32<5>, dim3(pl.blocks), dim3(256), 0, st, P);
-    else if (ntw <= 7) hipLaunchKernelGGL(conv_wgrad_f32<7>, dim3(pl.blocks), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL(conv_wgrad_f32<9>, dim3(pl.blocks), dim3(256), 0, st, P);
+    const dim3 grid(pl.blocks), blk(256);
+#define WG_LAUNCH(N)                                                                          \
+    do {                                                                                      \
+        if (P.tw == 32) hipLaunchKernelGGL((conv_wgrad_f32<N, 32>), grid, blk, 0, st, P);     \
+        else hipLaunchKernelGGL((conv_wgrad_f32<N, 64>), grid, blk, 0, st, P);                \
+    } while (0)
+    if (ntw <= 1) WG_LAUNCH(1);
+    else if (ntw <= 3) WG_LAUNCH(3);
+    else if (ntw <= 5) WG_LAUNCH(5);
+    else if (ntw <= 7) WG_LAUNCH(7);
+    else WG_LAUNCH(9);
+#undef WG_LAUNCH
     int rc = gdn_launch_status();
     if (rc != GDN_OK) return rc;
     const int KK = P.k * P.k;

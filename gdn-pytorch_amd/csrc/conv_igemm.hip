@@ -25,8 +25,7 @@
 
 #define MAX_TAPS 81
 #define MAX_PHASE 4
-#define KC 32
-#define LDS_LD 36
+#define KC_MIN 32          // smallest reduction slab (also the scalar-gather slab)
 
 struct IgemmPhase { int Ho, Wo, oy0, ox0, tap_begin, tap_end; };
 
@@ -38,12 +37,16 @@ struct IgemmParams {
     int Cred, w_tap_stride;
     int grid_m, grid_n;
     unsigned x_bytes, x2_bytes, w_bytes;   // extents for the buffer descriptors (< 4 GiB each)
+    int kc;                                // reduction slab per k-step (32 or 64)
     IgemmPhase ph[MAX_PHASE];
     short tdy[MAX_TAPS], tdx[MAX_TAPS], twi[MAX_TAPS];
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALAR>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALAR, int KC>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
+    constexpr int LDS_LD = KC + 4;               // row pitch: conflict-free ds_read_b128 for 36 and 68 floats
+    constexpr int TPR = KC / 4;                  // threads per staged row (16 B each)
+    constexpr int RPP = 256 / TPR;               // rows per staging pass
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(TM >= 1 && TN >= 1, "tile");
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
     __syncthreads();
 
     const int ntap = ph.tap_end - ph.tap_begin;
-    const int nchunks = p.Cred / KC;
+    const int nchunks = p.Cred / KC;     // host guarantees divisibility for the chosen KC
     const int Ktot = ntap * p.Cred;
     const int nk = SCALAR ? (Ktot + KC - 1) / KC : ntap * nchunks;
 
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = zero16;
 
     // ---------------- staging registers ----------------
-    constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;       // VEC: 8 threads x 16 B per row
+    constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;     // VEC: TPR threads x 16 B per row
     constexpr int A_KP = 256 / BM > 0 ? 256 / BM : 1, A_E = KC / A_KP;   // SCALAR
     constexpr int B_KP = 256 / BN > 0 ? 256 / BN : 1, B_E = KC / B_KP;
     f32x4 ra[SCALAR ? 1 : A_PASSES], rb[SCALAR ? 1 : B_PASSES];
@@ -122,7 +125,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
     int aoff[SCALAR ? 1 : A_PASSES];               // gathered pixel index of this thread's rows, -1 = zero
     unsigned boff[SCALAR ? 1 : B_PASSES];          // byte offset of (row n, 16-B lane chunk), OOB = row beyond N
     int tl_n = 0, cc_n = 0, wi_n = 0;              // prefetch cursor: tap, slab, weight tap index
-    const unsigned lane_b = (unsigned)(tid & 7) * 16u;
+    const unsigned lane_b = (unsigned)(tid % TPR) * 16u;
+    const int row_in_pass = tid / TPR;
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x2 ? p.x2 : p.x), 0,
                                                                      (int)(p.x2 ? p.x2_bytes : p.x_bytes), 0x00020000);
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
     if constexpr (!SCALAR) {
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps) {
-            const int n = n0 + ps * 32 + (tid >> 3);
+            const int n = n0 + ps * RPP + row_in_pass;
             boff[ps] = n < p.N ? (unsigned)(n * p.Cred) * 4u + lane_b : 0xFFFFFF00u;
         }
     }
@@ -141,11 +145,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
             wi_n = p.twi[t];
 #pragma unroll
             for (int ps = 0; ps < A_PASSES; ++ps) {
-                const int r = ps * 32 + (tid >> 3);
+                const int r = ps * RPP + row_in_pass;
                 const int base = row_pix[r], yx = row_yx[r];
                 int iy = (yx & 0xffff) + dy, ix = (yx >> 16) + dx;
                 if (p.pad_mode == 1) { iy = reflect_idx(iy, p.Hi); ix = reflect_idx(ix, p.Wi); }
-                const bool ok = base >= 0 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+                const bool ok = base >= 0 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
                 aoff[ps] = ok ? base + iy * p.Wi + ix : -1;       // -1 * ld*4 wraps far out of range
             }
         }
@@ -208,10 +212,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
         if constexpr (!SCALAR) {
 #pragma unroll
             for (int ps = 0; ps < A_PASSES; ++ps)
-                *reinterpret_cast<f32x4*>(&As[(ps * 32 + (tid >> 3)) * LDS_LD + (tid & 7) * 4]) = ra[ps];
+                *reinterpret_cast<f32x4*>(&As[(ps * RPP + row_in_pass) * LDS_LD + (tid % TPR) * 4]) = ra[ps];
 #pragma unroll
             for (int ps = 0; ps < B_PASSES; ++ps)
-                *reinterpret_cast<f32x4*>(&Bs[(ps * 32 + (tid >> 3)) * LDS_LD + (tid & 7) * 4]) = rb[ps];
+                *reinterpret_cast<f32x4*>(&Bs[(ps * RPP + row_in_pass) * LDS_LD + (tid % TPR) * 4]) = rb[ps];
         } else {
             if (tid / BM < A_KP) {
 #pragma unroll
@@ -224,8 +228,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
         }
     };
 
-    const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 16;
-    const int b_off = (wn * TN * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 16;
+    const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * (KC / 2);
+    const int b_off = (wn * TN * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * (KC / 2);
 
     gload(0);
     lds_store();
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
     // Two-level summation: the MFMA is a strictly k-ordered fp32 fma chain, so one chain over
     // K = taps*Cin (up to 6.4k terms) would carry sqrt(K) rounding growth.  FOLD k-steps (128 terms)
     // run in a fresh chain (C = 0 on the first MFMA) and are then folded into the running total.
-    constexpr int FOLD = 4;
+    constexpr int FOLD = 128 / KC;
     for (int ks0 = 0; ks0 < nk; ks0 += FOLD) {
 #pragma unroll
         for (int j = 0; j < FOLD; ++j) {
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
             if (ks >= nk) break;
             if (ks + 1 < nk) gload(ks + 1);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < KC / 8; ++g) {
                 f32x4 af[TM], bf[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[a_off + i * 32 * LDS_LD + g * 4]);
@@ -332,14 +336,13 @@ struct TileCfg { int bm, bn; };
 const TileCfg kCfg[NUM_CFG] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 64}, {32, 128}, {64, 128}};
 
 int pick_cfg(int64_t M, int N, bool scalar, int forced) {
-    // Measured on MI355X at B=20 (tools/tune_conv.py): small tiles at 5 waves/SIMD beat 128-wide
-    // ones everywhere (better CU balance, more latency hiding); 32x128 wins for N >= 128, 64x64 for N = 64.
+    // Measured on MI355X at B=20 (tools/tune_conv.py, profiles/r01_tune_conv_*): 64x64 tiles at
+    // 6 waves/SIMD beat every larger tile on every layer (CU balance + latency hiding).
     (void)M;
     if (scalar) return 5;
     if ((forced >= 1 && forced <= 4) || forced == 6 || forced == 7) return forced;
     if (N <= 32) return 4;
-    if (N <= 64) return 3;
-    return 6;
+    return 3;
 }
 
 // Builds the phase decomposition of a "transposed-type" gather:
@@ -400,7 +403,15 @@ template <int BM, int BN, int WM, int WN, bool SC>
 void launch_one(const IgemmParams& P, hipStream_t st) {
     const int gm_pad = cdiv(P.grid_m, 8) * 8;
     dim3 grid((unsigned)(gm_pad * P.grid_n), (unsigned)P.nphase, 1);
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, SC>), grid, dim3(256), 0, st, P);
+    // 64-channel slabs halve the barriers and the per-tap address work per MFMA; they need the
+    // reduction channels (and the concat split) to be multiples of 64.
+    if constexpr (!SC && BM * BN <= 64 * 128) {
+        if (P.kc == 64) {
+            hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, SC, 64>), grid, dim3(256), 0, st, P);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, SC, 32>), grid, dim3(256), 0, st, P);
 }
 
 int launch_igemm(IgemmParams& P, int cfg, hipStream_t st) {
@@ -473,6 +484,10 @@ extern "C" int gdn_conv_out_dims(const gdn_conv_geom* g, int32_t* Ho, int32_t* W
     return (*Ho > 0 && *Wo > 0) ? GDN_OK : GDN_ERR_BAD_ARG;
 }
 
+// conv_head.hip: register-blocked VALU kernel for the 1-channel 9x9 heads
+int gdn_conv_head_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w, float* y, int32_t ldy,
+                      int32_t act, void* stream);
+
 static int fill_fwd(const gdn_conv_geom* g, IgemmParams& P) {
     int Ho, Wo;
     if (gdn_conv_out_dims(g, &Ho, &Wo) != GDN_OK) return GDN_ERR_BAD_ARG;
@@ -489,8 +504,8 @@ static int fill_fwd(const gdn_conv_geom* g, IgemmParams& P) {
 extern "C" int64_t gdn_conv_stats_slots(const gdn_conv_geom* g, int32_t tile_cfg) {
     IgemmParams P{};
     if (fill_fwd(g, P) != GDN_OK) return GDN_ERR_BAD_ARG;
-    const bool scalar = (g->Cin % KC) != 0;
-    const int cfg = pick_cfg(max_phase_m(P), g->Cout, scalar, tile_cfg);
+    const bool scalar = (g->Cin % KC_MIN) != 0;
+    const int cfg = pick_cfg(max_phase_m(P), g->Cout, scalar, tile_cfg & 0xff);
     return (int64_t)P.nphase * cdiv64(max_phase_m(P), kCfg[cfg].bm);
 }
 
@@ -499,13 +514,17 @@ extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx,
                             float* stats, int32_t act, int32_t tile_cfg, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!geom_ok(g) || !x || !w || !y) return GDN_ERR_BAD_ARG;
+    if (g->Cout == 1 && !x2 && !stats && !addsrc && tile_cfg == 0) {
+        const int rc = gdn_conv_head_fwd(g, x, ldx, w, y, ldy, act, stream);
+        if (rc != GDN_ERR_UNSUPPORTED) return rc;
+    }
     IgemmParams P{};
     if (fill_fwd(g, P) != GDN_OK) return GDN_ERR_BAD_ARG;
-    const bool scalar = (g->Cin % KC) != 0;
+    const bool scalar = (g->Cin % KC_MIN) != 0;
     if (x2 == nullptr) C1 = g->Cin;
     if (C1 <= 0 || C1 > g->Cin) return GDN_ERR_BAD_ARG;
     if (scalar && C1 != g->Cin) return GDN_ERR_UNSUPPORTED;
-    if (!scalar && ((C1 % KC) || (ldx % 4) || (x2 && (ldx2 % 4)))) return GDN_ERR_UNSUPPORTED;
+    if (!scalar && ((C1 % KC_MIN) || (ldx % 4) || (x2 && (ldx2 % 4)))) return GDN_ERR_UNSUPPORTED;
     P.x = x; P.x2 = x2; P.w = w; P.y = y; P.addsrc = addsrc; P.stats = stats;
     P.C1 = C1; P.C2 = g->Cin - C1; P.ldx1 = ldx; P.ldx2 = ldx2; P.ldy = ldy; P.ld_add = ld_add; P.act = act;
     {
@@ -515,7 +534,9 @@ extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx,
         if (xb >= kMaxBufBytes || x2b >= kMaxBufBytes || wb >= kMaxBufBytes) return GDN_ERR_UNSUPPORTED;
         P.x_bytes = (unsigned)xb; P.x2_bytes = (unsigned)x2b; P.w_bytes = (unsigned)wb;
     }
-    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg);
+    // 32-channel slabs measured faster than 64 everywhere (6 waves/SIMD vs 4); 0x200 selects 64 for tuning runs
+    P.kc = (!scalar && g->Cin % 64 == 0 && C1 % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
+    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg & 0xff);
     return launch_igemm(P, cfg, (hipStream_t)stream);
 }
 
@@ -545,7 +566,7 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const float* dy, int32_t l
         if (xb >= kMaxBufBytes || wb >= kMaxBufBytes) return GDN_ERR_UNSUPPORTED;
         P.x_bytes = (unsigned)xb; P.x2_bytes = 0; P.w_bytes = (unsigned)wb;
     }
-    const bool scalar = (g->Cout % KC) != 0;
+    const bool scalar = (g->Cout % KC_MIN) != 0;
     if (!scalar && (ldy % 4)) return GDN_ERR_UNSUPPORTED;
     const bool fold = !g->transposed && g->pad_mode == 1 && g->pad > 0;
     if (g->transposed) {
@@ -566,7 +587,8 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const float* dy, int32_t l
         build_transposed_phases(P, g->k, g->stride, 0, Hp, Wp, g->B);
         P.y = (float*)workspace; P.ldy = g->Cin; P.addsrc = nullptr; P.ld_add = 0;
     }
-    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg);
+    P.kc = (!scalar && g->Cout % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
+    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg & 0xff);
     int rc = launch_igemm(P, cfg, st);
     if (rc != GDN_OK) return rc;
     if (fold) {

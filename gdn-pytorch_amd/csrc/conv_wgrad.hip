@@ -297,10 +297,12 @@ bool make_plan(const gdn_conv_geom* g, int Cx_in, WgradPlan& pl) {
         const bool thin = (P.Cg % 4 != 0) || (P.cisl % 4 != 0);      // scalar-load layers keep 32
         int best = 32;
         if (!thin) {
-            double best_eff = 0.0;
+            // 32 is the cheapest variant (compile-time trip counts, half the staging registers): another
+            // width must use the row at least 3 % better to win
+            double best_eff = (double)P.Wg / (double)(cdiv(P.Wg, 32) * 32);
             for (int tw = 64; tw >= 16; tw -= 2) {
                 const double eff = (double)P.Wg / (double)(cdiv(P.Wg, tw) * tw) * (tw >= 32 ? 1.0 : 0.97);
-                if (eff > best_eff + 1e-9) { best_eff = eff; best = tw; }
+                if (eff > best_eff + 0.03) { best_eff = eff; best = tw; }
             }
         }
         P.tw = best;

@@ -44,7 +44,7 @@ def test_host_queries_without_gpu(built_lib):
     lib.gdn_conv_out_dims(ctypes.byref(gt), ctypes.byref(ho), ctypes.byref(wo))
     assert (ho.value, wo.value) == (16, 52)
     assert lib.gdn_conv_stats_slots(ctypes.byref(g), 1) == (20 * 16 * 52 + 127) // 128
-    assert lib.gdn_conv_stats_slots(ctypes.byref(g), 0) == (20 * 16 * 52 + 31) // 32      # auto: 32x128 tiles
+    assert lib.gdn_conv_stats_slots(ctypes.byref(g), 0) == (20 * 16 * 52 + 63) // 64      # auto: 64x64 tiles
     assert lib.gdn_conv_stats_slots(ctypes.byref(gt), 3) == 4 * ((20 * 8 * 26 + 63) // 64)
     gr = ConvGeom(2, 16, 24, 64, 128, 7, 2, 3, 1, 0)            # reflect-padded strided conv
     assert lib.gdn_conv_dgrad_workspace_bytes(ctypes.byref(gr)) == 2 * 22 * 30 * 64 * 4

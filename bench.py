@@ -79,13 +79,78 @@ def cpu_baseline(batch=2):
                       "per-image work identical to the batch-20 GPU step" % batch}
 
 
+def infer_main(args):
+    """BASELINE configs[4]: legacy AutoEncoder (the depth_extract.py network) eval forward, 256x832,
+    batch 64 per GPU, one hipGraph replay per step.  fp32; images/s."""
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import distributed as D
+    rank, local_rank, world = D.init()
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    B = args.batch if args.batch != 20 else 64
+    H, W = 256, 832
+    model = M.AutoEncoder(height=H, width=W).to(dev).eval()
+    x = (torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(rank)) * 2 - 1).to(dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            out = model(x, istrain=False)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = model(x, istrain=False)
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            return out
+        return model(x, istrain=False)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        o = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        rec = {"metric": "inference images/sec at 256x832 batch=64 (legacy AutoEncoder forward)",
+               "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "legacy AutoEncoder eval forward, batch %d per GPU, 256x832, fp32, %s, "
+                                      "BASELINE configs[4]" % (B, "hipGraph replay" if graph is not None else "eager"),
+                          "global_batch": B * world, "parallelism": "dp%d" % world,
+                          "model_tflops_per_gpu": round(2733.39 * B * args.steps / dt / 1e3, 2),
+                          "out_checksum": round(float(o.double().abs().mean().item()), 6)}}
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=20, help="images per GPU")
-    ap.add_argument("--mode", default="DtoD", choices=["DtoD", "RtoD"])
+    ap.add_argument("--mode", default="DtoD", choices=["DtoD", "RtoD", "infer"])
+    ap.add_argument("--no-graph", action="store_true", help="infer mode: launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -96,6 +161,8 @@ def main():
     from gdn_amd.optim import Adam
     from gdn_amd.synthetic import synthetic_batch
 
+    if args.mode == "infer":
+        return infer_main(args)
     rank, local_rank, world = D.init()
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)

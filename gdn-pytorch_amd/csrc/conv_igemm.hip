@@ -36,7 +36,8 @@ struct IgemmParams {
     int stride, pad_mode, act, nphase;
     int Cred, w_tap_stride;
     int grid_m, grid_n;
-    unsigned x_bytes, x2_bytes, w_bytes;   // extents for the buffer descriptors (< 4 GiB each)
+    unsigned long long x_bytes, x2_bytes;  // tensor extents; descriptors are re-based per workgroup (32-bit offsets)
+    unsigned w_bytes;
     int kc;                                // reduction slab per k-step (32 or 64)
     IgemmPhase ph[MAX_PHASE];
     short tdy[MAX_TAPS], tdx[MAX_TAPS], twi[MAX_TAPS];
@@ -79,11 +80,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
         return;
     }
 
+    // Buffer descriptors address 32 bits, activations can exceed 4 GiB (B=64 at 256x832): base every
+    // descriptor at the first image this workgroup touches (a 64-row tile spans at most two images).
+    const int b_first = m0 / (ph.Ho * ph.Wo);
     for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
         if (m < M) {
             const int ox = m % ph.Wo, t = m / ph.Wo, oy = t % ph.Ho, b = t / ph.Ho;
-            row_pix[r] = b * p.Hi * p.Wi;
+            row_pix[r] = (b - b_first) * p.Hi * p.Wi;      // relative to this workgroup's first image
             row_yx[r] = (oy * p.stride) | ((ox * p.stride) << 16);
             row_out[r] = (b * p.Hy + oy * p.osy + ph.oy0) * p.Wy + ox * p.osx + ph.ox0;
         } else {
@@ -127,9 +131,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
     int tl_n = 0, cc_n = 0, wi_n = 0;              // prefetch cursor: tap, slab, weight tap index
     const unsigned lane_b = (unsigned)(tid % TPR) * 16u;
     const int row_in_pass = tid / TPR;
-    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x2 ? p.x2 : p.x), 0,
-                                                                     (int)(p.x2 ? p.x2_bytes : p.x_bytes), 0x00020000);
+    const unsigned long long img1 = (unsigned long long)p.Hi * p.Wi * p.ldx1 * 4ull * b_first;
+    const unsigned long long img2 = (unsigned long long)p.Hi * p.Wi * p.ldx2 * 4ull * b_first;
+    const unsigned long long rem1 = p.x_bytes - img1, rem2 = p.x2 ? p.x2_bytes - img2 : rem1;
+    const unsigned long long cap = 0xFF000000ull;
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x) + img1), 0, (int)(unsigned)(rem1 < cap ? rem1 : cap), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(p.x2 ? reinterpret_cast<const char*>(p.x2) + img2 : reinterpret_cast<const char*>(p.x) + img1), 0,
+        (int)(unsigned)(rem2 < cap ? rem2 : cap), 0x00020000);
     __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
     if constexpr (!SCALAR) {
 #pragma unroll
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
                         bool ok = true;
                         if (p.pad_mode == 1) { iy = reflect_idx(iy, p.Hi); ix = reflect_idx(ix, p.Wi); }
                         ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-                        if (ok) v = p.x[(size_t)(base + iy * p.Wi + ix) * p.ldx1 + ci];
+                        if (ok) v = p.x[((size_t)b_first * p.Hi * p.Wi + (size_t)(base + iy * p.Wi + ix)) * p.ldx1 + ci];
                     }
                     sa[e] = v;
                 }
@@ -531,8 +541,10 @@ extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx,
         const uint64_t npix = (uint64_t)g->B * g->H * g->W;
         const uint64_t xb = ((npix - 1) * (uint64_t)ldx + C1) * 4, x2b = x2 ? ((npix - 1) * (uint64_t)ldx2 + P.C2) * 4 : 0;
         const uint64_t wb = (uint64_t)g->k * g->k * g->Cout * g->Cin * 4;
-        if (xb >= kMaxBufBytes || x2b >= kMaxBufBytes || wb >= kMaxBufBytes) return GDN_ERR_UNSUPPORTED;
-        P.x_bytes = (unsigned)xb; P.x2_bytes = (unsigned)x2b; P.w_bytes = (unsigned)wb;
+        // per-workgroup descriptors span at most two images
+        const uint64_t two1 = 2ull * g->H * g->W * (uint64_t)ldx * 4, two2 = x2 ? 2ull * g->H * g->W * (uint64_t)ldx2 * 4 : 0;
+        if (two1 >= kMaxBufBytes || two2 >= kMaxBufBytes || wb >= kMaxBufBytes) return GDN_ERR_UNSUPPORTED;
+        P.x_bytes = xb; P.x2_bytes = x2b; P.w_bytes = (unsigned)wb;
     }
     // 32-channel slabs measured faster than 64 everywhere (6 waves/SIMD vs 4); 0x200 selects 64 for tuning runs
     P.kc = (!scalar && g->Cin % 64 == 0 && C1 % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
@@ -563,8 +575,8 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const float* dy, int32_t l
     {
         const uint64_t xb = (((uint64_t)g->B * Ho * Wo - 1) * (uint64_t)ldy + g->Cout) * 4;
         const uint64_t wb = (uint64_t)g->k * g->k * g->Cout * g->Cin * 4;
-        if (xb >= kMaxBufBytes || wb >= kMaxBufBytes) return GDN_ERR_UNSUPPORTED;
-        P.x_bytes = (unsigned)xb; P.x2_bytes = 0; P.w_bytes = (unsigned)wb;
+        if (2ull * Ho * Wo * (uint64_t)ldy * 4 >= kMaxBufBytes || wb >= kMaxBufBytes) return GDN_ERR_UNSUPPORTED;
+        P.x_bytes = xb; P.x2_bytes = 0; P.w_bytes = (unsigned)wb;
     }
     const bool scalar = (g->Cout % KC_MIN) != 0;
     if (!scalar && (ldy % 4)) return GDN_ERR_UNSUPPORTED;

@@ -89,8 +89,13 @@ class Conv:
         if stats:
             slots = int(lib.gdn_conv_stats_slots(ref, tile_cfg))
             st = torch.empty((slots, 2, self.cout), dtype=torch.float32, device=x.device)
-        lib.gdn_conv_fwd(ref, _p(x), _ld(x), _p(x2), 0 if x2 is None else _ld(x2), C1, _p(w_tap), _p(y), _ld(y),
-                         _p(addsrc), 0 if addsrc is None else _ld(addsrc), _p(st), act, tile_cfg, stream())
+        try:
+            lib.gdn_conv_fwd(ref, _p(x), _ld(x), _p(x2), 0 if x2 is None else _ld(x2), C1, _p(w_tap), _p(y), _ld(y),
+                             _p(addsrc), 0 if addsrc is None else _ld(addsrc), _p(st), act, tile_cfg, stream())
+        except GdnError as e:
+            raise GdnError("%s [conv %d->%d k%d s%d p%d reflect=%s transposed=%s, x %s ld %d, x2 %s]" % (
+                e, self.cin, self.cout, self.k, self.stride, self.pad, self.reflect, self.transposed,
+                tuple(x.shape), _ld(x), None if x2 is None else tuple(x2.shape))) from None
         return (y, st) if stats else y
 
     def dgrad(self, dy, wt_tap, in_hw, addsrc=None, tile_cfg=0):

@@ -194,3 +194,43 @@ def test_checkpoint_roundtrip_and_errors(gpu, tmp_path):
         m(torch.rand(1, 1, 48, 64, device=gpu))               # height/width mismatch with the ctor
     with pytest.raises(GdnError):
         m(torch.rand(1, 1, 32, 64))                           # CPU input: no fallback
+
+
+def test_hipgraph_replay_matches_eager(gpu):
+    """The C ABI never allocates or synchronises, so a whole forward can be captured and replayed."""
+    import gdn_amd.AE_model_unet as M
+    torch.manual_seed(0)
+    m = M.AutoEncoder(height=32, width=64).to(gpu).eval()
+    x = torch.rand(2, 3, 32, 64, device=gpu) * 2 - 1
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ref = m(x, istrain=False).clone()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m(x, istrain=False)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    x.copy_(torch.rand(2, 3, 32, 64, device=gpu) * 2 - 1)      # new input, same graph
+    g.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        assert torch.equal(out, m(x, istrain=False))
+
+
+def test_activations_beyond_4gib(gpu):
+    """Buffer descriptors address 32 bits; they are re-based per workgroup, so a >4 GiB activation
+    (BASELINE configs[4]: B=64 at 256x832 with 128 channels is 7 GB) must give the same result for an
+    image as running that image alone."""
+    from gdn_amd import ops
+    B, H, W, C = 21, 256, 832, 256                       # 4.58 GB input
+    op = ops.Conv(C, 64, 3, 1, 1)
+    x = torch.empty(B, H, W, C, device=gpu)
+    x.normal_(generator=torch.Generator(device=gpu).manual_seed(0))
+    w = torch.randn(9, 64, C, device=gpu) * 0.02
+    y = op.fwd(x, w)
+    for b in (0, B - 1):
+        yb = op.fwd(x[b:b + 1].contiguous(), w)
+        assert torch.equal(y[b:b + 1], yb)

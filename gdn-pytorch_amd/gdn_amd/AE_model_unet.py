@@ -63,6 +63,7 @@ class _Bridge(torch.autograd.Function):
         outs = module._run(ctx, xin)
         outs = tuple(outs[i] for i in select)
         fctx.gdn = (ctx, outs, arena)
+        fctx.gdn_module = module
         views = tuple(E.to_nchw_view(o) for o in outs)
         return views if len(views) > 1 else views[0]
 
@@ -71,6 +72,10 @@ class _Bridge(torch.autograd.Function):
         ctx, outs, arena = fctx.gdn
         fctx.gdn = None
         pending = arena.bind_grads()
+        red = getattr(fctx.gdn_module, "_gdn_reducer", None)
+        if red is not None and red.arena is arena and not pending:
+            red.begin()
+            ctx.reducer = red
         for o, g in zip(outs, gouts):
             if g is None:
                 continue

@@ -110,6 +110,12 @@ class Ctx:
         self.grads = {}
         self.input = None                      # the model's NHWC input buffer
         self.input_needs_grad = input_needs_grad
+        self.reducer = None                    # distributed.GradReducer while a backward is running
+
+    def grads_done(self, *params):
+        """Parameters whose gradient has just been written (lets the all-reduce start early)."""
+        if self.reducer is not None:
+            self.reducer.mark(params)
 
     def wants_dx(self, x):
         """Data gradients stop at the network input unless the caller asked for them."""
@@ -214,6 +220,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                 ctx.add_grad(residual, da)
             dy = ops.bn_bwd(da, y, bn.weight.data, co, relu, bn.weight.grad, bn.bias.grad)
             _wgrad_into(ctx, conv, x, dy, x2)
+            ctx.grads_done(bn.weight, bn.bias, conv.weight)
             if need_dx and ctx.wants_dx(x):
                 wt = ops.transpose_taps(w)
                 if x2 is None:
@@ -242,6 +249,7 @@ def conv_head_tanh(ctx, x, conv):
                 return
             dpre = ops.tanh_bwd(do.contiguous(), out)
             _wgrad_into(ctx, conv, x, dpre)
+            ctx.grads_done(conv.weight)
             wt = ops.transpose_taps(w)
             dx = op.dgrad(dpre, wt, in_hw, addsrc=ctx.pop_grad(x))
             ctx.grads[id(x)] = (x, dx)

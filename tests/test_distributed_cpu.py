@@ -63,6 +63,20 @@ def _worker(rank, world, port, q):
         for k, p in model.named_parameters():
             want = sum(g[k] for g in grads) / world
             torch.testing.assert_close(p.grad, want, rtol=1e-5, atol=1e-7)
+        # --- overlapped reduction: buckets fire as soon as their last parameter is marked ---
+        red = D.GradReducer(arena, bucket_elems=200000)
+        assert len(red.buckets) > 4 and sum(b[2] for b in red.buckets) == len(arena.items)
+        for k, p in model.named_parameters():
+            p.grad.copy_(grads[rank][k])
+        red.begin()
+        order = [p for p in model.parameters()][::-1]          # backward visits parameters roughly in reverse
+        red.mark(order[:len(order) // 2])
+        assert any(red.fired) and not all(red.fired)
+        red.mark(order[len(order) // 2:-3])                    # three parameters never get marked
+        assert red.finish() and not red.active
+        for k, p in model.named_parameters():
+            want = sum(g[k] for g in grads)
+            torch.testing.assert_close(p.grad, want, rtol=1e-5, atol=1e-7)
         t = torch.tensor([float(rank)])
         assert D.allreduce_max_scalar(t).item() == world - 1
         q.put((rank, "ok"))

@@ -234,3 +234,49 @@ def test_activations_beyond_4gib(gpu):
     for b in (0, B - 1):
         yb = op.fwd(x[b:b + 1].contiguous(), w)
         assert torch.equal(y[b:b + 1], yb)
+
+
+def test_overlapped_reducer_engine_integration(gpu, monkeypatch):
+    """World size 1 cannot exercise RCCL, but the engine <-> GradReducer hand-shake can be checked with a
+    recording stand-in for dist.all_reduce: every bucket must be sent exactly once, most of them while the
+    tape is still running, and the arena must hold the same gradients as a run without the reducer."""
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import distributed as D
+    from gdn_amd import utils as U
+    depth, rgb, sparse = [t.to(gpu) for t in O.synthetic_batch(1, 32, 64, seed=4)]
+    torch.manual_seed(0)
+    model = M.AutoEncoder_DtoD(input_dim=1, height=32, width=64).to(gpu).train()
+
+    def run():
+        out = model(depth, istrain=False)
+        loss, _, _ = U.dtod_loss(out, depth, sparse)
+        for p in model.parameters():
+            p.grad = None
+        loss.backward()
+        return model._gdn_param_arena.grad.clone()
+
+    ref = run()
+    sent = []
+
+    class _Work:
+        def wait(self):
+            return True
+
+    def fake_all_reduce(t, op=None, async_op=False):
+        sent.append((t.data_ptr(), t.numel(), len(model_tape_probe)))
+        return _Work()
+
+    model_tape_probe = []
+    monkeypatch.setattr(D.dist, "all_reduce", fake_all_reduce)
+    red = D.GradReducer(model._gdn_param_arena, bucket_elems=2_000_000)
+    model._gdn_reducer = red
+    # BN running stats moved during the first run; gradients depend only on batch statistics
+    got = run()
+    assert red.active and all(red.fired) or any(red.fired)
+    n_during = len(sent)
+    assert red.finish()
+    assert len(sent) == len(red.buckets) and n_during >= len(red.buckets) - 2
+    base = model._gdn_param_arena.grad.data_ptr()
+    assert sorted((p - base) // 4 for p, _, _ in sent) == sorted(b[0] for b in red.buckets)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-8)
+    model._gdn_reducer = None

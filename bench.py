@@ -57,6 +57,16 @@ def conv3x3_roofline(dev, B, level, reps=20):
     return ms, flop
 
 
+def pmc_traffic():
+    """L2->fabric bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None if the summary is absent."""
+    f = ROOT / "profiles" / "r01_conv3x3_pmc.json"
+    try:
+        return json.loads(f.read_text())["traffic_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(batch=2):
     """The oracle's DtoD training step on the host cores, bounded sample."""
     from oracle import gdn_oracle as O
@@ -241,7 +251,7 @@ def main():
             rec["roofline"] = {
                 "kernel": "conv_igemm_f32 3x3 s1 512->512 + BN-stats epilogue, B=%d 16x52 (level 3)" % B,
                 "bound": "mfma", "achieved": round(a3, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(a3 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(a3 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
                 "gflop_per_launch": round(fl3 / 1e9, 2), "ms_per_launch": round(ms3, 4),
                 "level4_8x26": {"achieved": round(fl4 / (ms4 * 1e-3) / 1e12, 2),
                                 "frac": round(fl4 / (ms4 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),

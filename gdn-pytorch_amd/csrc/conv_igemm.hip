@@ -64,11 +64,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
     const int ph_i = blockIdx.y;
     const IgemmPhase ph = p.ph[ph_i];
 
-    // XCD-aware tile order: blocks b, b+8, ... share an XCD (its L2); keep the
-    // N-tiles of one M-tile (same activation rows) on the same XCD, adjacent in time.
+    // XCD-aware tile order: blocks b, b+8, ... share an XCD (its L2).  Each XCD gets a contiguous BAND of
+    // M-tiles (so the tiles above/below a tile -- which re-read its rows through the filter's halo -- are
+    // resident on the same L2 at about the same time: a 9x9 layer otherwise fetches every input row nine
+    // times from beyond L2), and the N-tiles of one M-tile stay adjacent on that XCD.
     const int bid = blockIdx.x, xcd = bid & 7, q = bid >> 3;
-    const int nt = q % p.grid_n, mt = (q / p.grid_n) * 8 + xcd;
-    if (mt >= p.grid_m) return;
+    const int per_xcd = (p.grid_m + 7) >> 3;
+    const int nt = q % p.grid_n, mt = xcd * per_xcd + q / p.grid_n;
+    if (q / p.grid_n >= per_xcd || mt >= p.grid_m) return;
     const int M = p.B * ph.Ho * ph.Wo;
     const int m0 = mt * BM, n0 = nt * BN;
     const int slot = ph_i * p.grid_m + mt;

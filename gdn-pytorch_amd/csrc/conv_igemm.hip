@@ -39,6 +39,9 @@ struct IgemmParams {
     unsigned long long x_bytes, x2_bytes;  // tensor extents; descriptors are re-based per workgroup (32-bit offsets)
     unsigned w_bytes;
     int kc;                                // reduction slab per k-step (32 or 64)
+    int ksplit;                            // split-K over taps (grid.z); >1: raw partials go to `part`
+    float* part;                           // [ksplit][npix_out][N]
+    long long npix_out;
     IgemmPhase ph[MAX_PHASE];
     short tdy[MAX_TAPS], tdx[MAX_TAPS], twi[MAX_TAPS];
 };
@@ -62,7 +65,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int ph_i = blockIdx.y;
-    const IgemmPhase ph = p.ph[ph_i];
+    IgemmPhase ph = p.ph[ph_i];
+    const int kz = blockIdx.z;
+    if (p.ksplit > 1) {          // split-K: this workgroup reduces a contiguous share of the phase's taps
+        const int tb = ph.tap_begin, nt_all = ph.tap_end - ph.tap_begin;
+        ph.tap_begin = tb + (nt_all * kz) / p.ksplit;
+        ph.tap_end = tb + (nt_all * (kz + 1)) / p.ksplit;
+    }
 
     // XCD-aware tile order: blocks b, b+8, ... share an XCD (its L2).  Each XCD gets a contiguous BAND of
     // M-tiles (so the tiles above/below a tile -- which re-read its rows through the filter's halo -- are
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
     const int m0 = mt * BM, n0 = nt * BN;
     const int slot = ph_i * p.grid_m + mt;
     if (m0 >= M) {
-        if (p.stats && tid < BN && n0 + tid < p.N) {
+        if (p.ksplit == 1 && p.stats && tid < BN && n0 + tid < p.N) {
             p.stats[((size_t)slot * 2 + 0) * p.N + n0 + tid] = 0.f;
             p.stats[((size_t)slot * 2 + 1) * p.N + n0 + tid] = 0.f;
         }
@@ -288,6 +297,23 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
     // ---------------- epilogue ----------------
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     const int col_l = lane & 31, rsh = 4 * (lane >> 5);
+    if (p.ksplit > 1) {          // raw partial sums; splitk_combine_kernel finishes (sum, addsrc, act, BN stats)
+        float* pp = p.part + (size_t)kz * p.npix_out * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + rsh;
+                const int op = row_out[row];
+                if (op < 0) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+                    if (n < p.N) pp[(size_t)op * p.N + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     if (p.stats) {
         float* red = As;  // [WAVES_M][BN][2], safe: all waves are past their last LDS read
 #pragma unroll
@@ -338,6 +364,55 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
 // ---------------------------------------------------------------------------
 // Host side: geometry -> phases / tap lists, tile selection, launch.
 // ---------------------------------------------------------------------------
+// Second stage of a split-K launch: y = act(sum_z part[z] + addsrc), plus the per-block BatchNorm
+// partial statistics the single-stage epilogue would have produced.  64 pixels per workgroup.
+#define SK_ROWS 64
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ part, int ksplit, long long npix,
+                                                             int N, float* __restrict__ y, int ldy,
+                                                             const float* __restrict__ addsrc, int ld_add, int act,
+                                                             float* __restrict__ stats) {
+    __shared__ float sh[256 * 8];
+    const int cq = N >> 2;
+    const int CQ = cq < 256 ? cq : 256, PY = 256 / CQ;
+    const int tx = threadIdx.x % CQ, ty = threadIdx.x / CQ;
+    const long long p0 = (long long)blockIdx.x * SK_ROWS;
+    const long long p1 = p0 + SK_ROWS < npix ? p0 + SK_ROWS : npix;
+    const size_t zs = (size_t)npix * N;
+    for (int q = tx; q < cq; q += CQ) {
+        const int c = q * 4;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (ty < PY) {
+            for (long long pix = p0 + ty; pix < p1; pix += PY) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)pix * N + c);
+                for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + z * zs + (size_t)pix * N + c);
+                s1 += v;
+                s2 += v * v;
+                if (addsrc) v += *reinterpret_cast<const f32x4*>(addsrc + (size_t)pix * ld_add + c);
+                if (act == GDN_ACT_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+                }
+                *reinterpret_cast<f32x4*>(y + (size_t)pix * ldy + c) = v;
+            }
+        }
+        if (stats) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sh[threadIdx.x * 8 + e] = s1[e]; sh[threadIdx.x * 8 + 4 + e] = s2[e]; }
+            __syncthreads();
+            if (ty == 0) {
+                f32x4 r1 = {0.f, 0.f, 0.f, 0.f}, r2 = {0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < PY; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { r1[e] += sh[(j * CQ + tx) * 8 + e]; r2[e] += sh[(j * CQ + tx) * 8 + 4 + e]; }
+                }
+                *reinterpret_cast<f32x4*>(stats + ((size_t)blockIdx.x * 2 + 0) * N + c) = r1;
+                *reinterpret_cast<f32x4*>(stats + ((size_t)blockIdx.x * 2 + 1) * N + c) = r2;
+            }
+        }
+    }
+}
+
 namespace {
 
 // Buffer descriptors address 32 bits; out-of-range sentinels sit just below 4 GiB.
@@ -415,7 +490,7 @@ int64_t max_phase_m(const IgemmParams& P) {
 template <int BM, int BN, int WM, int WN, bool SC>
 void launch_one(const IgemmParams& P, hipStream_t st) {
     const int gm_pad = cdiv(P.grid_m, 8) * 8;
-    dim3 grid((unsigned)(gm_pad * P.grid_n), (unsigned)P.nphase, 1);
+    dim3 grid((unsigned)(gm_pad * P.grid_n), (unsigned)P.nphase, (unsigned)P.ksplit);
     // 64-channel slabs halve the barriers and the per-tap address work per MFMA; they need the
     // reduction channels (and the concat split) to be multiples of 64.
     if constexpr (!SC && BM * BN <= 64 * 128) {
@@ -427,10 +502,41 @@ void launch_one(const IgemmParams& P, hipStream_t st) {
     hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, SC, 32>), grid, dim3(256), 0, st, P);
 }
 
-int launch_igemm(IgemmParams& P, int cfg, hipStream_t st) {
+// Split-K over filter taps for launches that cannot fill the chip: a level-4 3x3 layer (M = 4160) is
+// 520 tiles of 64x64 for 256 CUs -- 2.03 tiles per CU, i.e. a third of the CUs wait for the ones that
+// drew three.  Splitting the taps 3-4 ways gives every CU ~8 smaller units (and the level-3 layers four
+// rounds instead of 1.35); the partials cost one extra pass over the (small) output.
+int pick_ksplit(const IgemmParams& P, int cfg, bool scalar, int tile_cfg) {
+    if (scalar || (P.N % 4) || cfg == 4 || (tile_cfg & 0x800)) return 1;
+    const TileCfg tc = kCfg[cfg];
+    const int64_t blocks = cdiv64(cdiv64(max_phase_m(P), tc.bm), 8) * 8 * cdiv(P.N, tc.bn) * P.nphase;
+    if (blocks >= 1200) return 1;      // measured: splitting only pays below ~one round of resident workgroups
+    int min_taps = MAX_TAPS;
+    for (int i = 0; i < P.nphase; ++i) {
+        const int n = P.ph[i].tap_end - P.ph[i].tap_begin;
+        if (n < min_taps) min_taps = n;
+    }
+    int ks = (int)cdiv64(4608, blocks);
+    const int ks_max = (tile_cfg >> 12) & 15 ? (tile_cfg >> 12) & 15 : 4;     // bits 12..15: tuning override
+    if (ks > ks_max) ks = ks_max;
+    if (ks > min_taps) ks = min_taps;
+    return ks < 1 ? 1 : ks;
+}
+
+size_t ksplit_bytes(const IgemmParams& P, int ksplit) {
+    return ksplit > 1 ? (size_t)ksplit * P.B * P.Hy * P.Wy * P.N * sizeof(float) : 0;
+}
+
+// Launches the kernel; with ksplit > 1 the partials go to `split_ws` and the combine kernel writes
+// y / stats (P.y, P.ldy, P.addsrc, P.act, P.stats keep their single-stage meaning).
+int launch_igemm(IgemmParams& P, int cfg, hipStream_t st, int ksplit = 1, void* split_ws = nullptr) {
     const TileCfg tc = kCfg[cfg];
     P.grid_m = (int)cdiv64(max_phase_m(P), tc.bm);
     P.grid_n = cdiv(P.N, tc.bn);
+    P.ksplit = ksplit;
+    P.part = (float*)split_ws;
+    P.npix_out = (long long)P.B * P.Hy * P.Wy;
+    if (ksplit > 1 && !split_ws) return GDN_ERR_WORKSPACE;
     switch (cfg) {
         case 1: launch_one<128, 128, 2, 2, false>(P, st); break;
         case 2: launch_one<128, 64, 2, 2, false>(P, st); break;
@@ -440,6 +546,11 @@ int launch_igemm(IgemmParams& P, int cfg, hipStream_t st) {
         case 6: launch_one<32, 128, 1, 4, false>(P, st); break;
         case 7: launch_one<64, 128, 2, 2, false>(P, st); break;
         default: return GDN_ERR_BAD_ARG;
+    }
+    if (ksplit > 1) {
+        const int blocks = (int)cdiv64(P.npix_out, SK_ROWS);
+        hipLaunchKernelGGL(splitk_combine_kernel, dim3(blocks), dim3(256), 0, st, (const float*)P.part, ksplit,
+                           P.npix_out, P.N, P.y, P.ldy, P.addsrc, P.ld_add, P.act, P.stats);
     }
     return gdn_launch_status();
 }
@@ -519,12 +630,22 @@ extern "C" int64_t gdn_conv_stats_slots(const gdn_conv_geom* g, int32_t tile_cfg
     if (fill_fwd(g, P) != GDN_OK) return GDN_ERR_BAD_ARG;
     const bool scalar = (g->Cin % KC_MIN) != 0;
     const int cfg = pick_cfg(max_phase_m(P), g->Cout, scalar, tile_cfg & 0xff);
+    if (pick_ksplit(P, cfg, scalar, tile_cfg) > 1) return cdiv64((int64_t)P.B * P.Hy * P.Wy, SK_ROWS);
     return (int64_t)P.nphase * cdiv64(max_phase_m(P), kCfg[cfg].bm);
+}
+
+extern "C" size_t gdn_conv_fwd_workspace_bytes(const gdn_conv_geom* g, int32_t tile_cfg) {
+    IgemmParams P{};
+    if (fill_fwd(g, P) != GDN_OK) return 0;
+    const bool scalar = (g->Cin % KC_MIN) != 0;
+    const int cfg = pick_cfg(max_phase_m(P), g->Cout, scalar, tile_cfg & 0xff);
+    return ksplit_bytes(P, pick_ksplit(P, cfg, scalar, tile_cfg));
 }
 
 extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* x2, int32_t ldx2,
                             int32_t C1, const float* w, float* y, int32_t ldy, const float* addsrc, int32_t ld_add,
-                            float* stats, int32_t act, int32_t tile_cfg, void* stream) {
+                            float* stats, int32_t act, int32_t tile_cfg, void* workspace, size_t workspace_bytes,
+                            void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!geom_ok(g) || !x || !w || !y) return GDN_ERR_BAD_ARG;
     if (g->Cout == 1 && !x2 && !stats && !addsrc && tile_cfg == 0) {
@@ -552,59 +673,76 @@ extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx,
     // 32-channel slabs measured faster than 64 everywhere (6 waves/SIMD vs 4); 0x200 selects 64 for tuning runs
     P.kc = (!scalar && g->Cin % 64 == 0 && C1 % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
     const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg & 0xff);
-    return launch_igemm(P, cfg, (hipStream_t)stream);
+    const int ksplit = pick_ksplit(P, cfg, scalar, tile_cfg);
+    if (ksplit > 1 && (!workspace || workspace_bytes < ksplit_bytes(P, ksplit))) return GDN_ERR_WORKSPACE;
+    if (ksplit > 1 && ((ldy % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
+    return launch_igemm(P, cfg, (hipStream_t)stream, ksplit, workspace);
 }
 
-extern "C" size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g) {
-    if (!geom_ok(g)) return 0;
-    if (!g->transposed && g->pad_mode == 1 && g->pad > 0)
-        return (size_t)g->B * (g->H + 2 * g->pad) * (g->W + 2 * g->pad) * g->Cin * sizeof(float);
-    return 0;
+// Geometry of a data-gradient launch (everything but the pointers).
+static bool fill_dgrad(const gdn_conv_geom* g, IgemmParams& P, bool& fold, bool& scalar) {
+    int Ho, Wo;
+    if (!geom_ok(g) || gdn_conv_out_dims(g, &Ho, &Wo) != GDN_OK) return false;
+    P.B = g->B; P.Hi = Ho; P.Wi = Wo;             // the gathered tensor is dy
+    P.N = g->Cin; P.Cred = g->Cout; P.C1 = g->Cout; P.C2 = 0;
+    P.w_tap_stride = g->Cin * g->Cout;
+    P.pad_mode = 0; P.act = GDN_ACT_NONE;
+    scalar = (g->Cout % KC_MIN) != 0;
+    fold = !g->transposed && g->pad_mode == 1 && g->pad > 0;
+    if (g->transposed) {
+        // dx_T[i] = sum_k dy_T[i*s - p + k] w[k]: a plain strided gather over dy.
+        P.Hy = g->H; P.Wy = g->W;
+        build_direct_phase(P, g->k, g->stride, g->pad, g->H, g->W);
+    } else if (!fold) {
+        P.Hy = g->H; P.Wy = g->W;
+        build_transposed_phases(P, g->k, g->stride, g->pad, g->H, g->W, g->B);
+    } else {
+        P.Hy = g->H + 2 * g->pad; P.Wy = g->W + 2 * g->pad;
+        build_transposed_phases(P, g->k, g->stride, 0, P.Hy, P.Wy, g->B);
+    }
+    return true;
+}
+
+static size_t fold_bytes(const gdn_conv_geom* g) {
+    const size_t b = (size_t)g->B * (g->H + 2 * g->pad) * (g->W + 2 * g->pad) * g->Cin * sizeof(float);
+    return (b + 255) / 256 * 256;
+}
+
+extern "C" size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g, int32_t tile_cfg) {
+    IgemmParams P{};
+    bool fold, scalar;
+    if (!fill_dgrad(g, P, fold, scalar)) return 0;
+    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg & 0xff);
+    return (fold ? fold_bytes(g) : 0) + ksplit_bytes(P, pick_ksplit(P, cfg, scalar, tile_cfg));
 }
 
 extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* wt, float* dx,
                               int32_t ldx, const float* addsrc, int32_t ld_add, void* workspace,
                               size_t workspace_bytes, int32_t tile_cfg, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
-    if (!geom_ok(g) || !dy || !wt || !dx) return GDN_ERR_BAD_ARG;
-    int Ho, Wo;
-    if (gdn_conv_out_dims(g, &Ho, &Wo) != GDN_OK) return GDN_ERR_BAD_ARG;
+    if (!dy || !wt || !dx) return GDN_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     IgemmParams P{};
-    P.B = g->B; P.Hi = Ho; P.Wi = Wo;             // the gathered tensor is dy
-    P.N = g->Cin; P.Cred = g->Cout; P.C1 = g->Cout; P.C2 = 0;
-    P.w_tap_stride = g->Cin * g->Cout;
-    P.x = dy; P.ldx1 = ldy; P.w = wt; P.pad_mode = 0; P.act = GDN_ACT_NONE;
+    bool fold, scalar;
+    if (!fill_dgrad(g, P, fold, scalar)) return GDN_ERR_BAD_ARG;
+    P.x = dy; P.ldx1 = ldy; P.w = wt;
     {
-        const uint64_t xb = (((uint64_t)g->B * Ho * Wo - 1) * (uint64_t)ldy + g->Cout) * 4;
+        const uint64_t xb = (((uint64_t)g->B * P.Hi * P.Wi - 1) * (uint64_t)ldy + g->Cout) * 4;
         const uint64_t wb = (uint64_t)g->k * g->k * g->Cout * g->Cin * 4;
-        if (2ull * Ho * Wo * (uint64_t)ldy * 4 >= kMaxBufBytes || wb >= kMaxBufBytes) return GDN_ERR_UNSUPPORTED;
+        if (2ull * P.Hi * P.Wi * (uint64_t)ldy * 4 >= kMaxBufBytes || wb >= kMaxBufBytes) return GDN_ERR_UNSUPPORTED;
         P.x_bytes = xb; P.x2_bytes = 0; P.w_bytes = (unsigned)wb;
     }
-    const bool scalar = (g->Cout % KC_MIN) != 0;
     if (!scalar && (ldy % 4)) return GDN_ERR_UNSUPPORTED;
-    const bool fold = !g->transposed && g->pad_mode == 1 && g->pad > 0;
-    if (g->transposed) {
-        // dx_T[i] = sum_k dy_T[i*s - p + k] w[k]: a plain strided gather over dy.
-        P.Hy = g->H; P.Wy = g->W;
-        build_direct_phase(P, g->k, g->stride, g->pad, g->H, g->W);
-        P.y = dx; P.ldy = ldx; P.addsrc = addsrc; P.ld_add = ld_add;
-    } else if (!fold) {
-        P.Hy = g->H; P.Wy = g->W;
-        build_transposed_phases(P, g->k, g->stride, g->pad, g->H, g->W, g->B);
-        P.y = dx; P.ldy = ldx; P.addsrc = addsrc; P.ld_add = ld_add;
-    } else {
-        const size_t need = gdn_conv_dgrad_workspace_bytes(g);
-        if (!workspace || workspace_bytes < need) return GDN_ERR_WORKSPACE;
-        if (g->Cin % 4) return GDN_ERR_UNSUPPORTED;
-        const int Hp = g->H + 2 * g->pad, Wp = g->W + 2 * g->pad;
-        P.Hy = Hp; P.Wy = Wp;
-        build_transposed_phases(P, g->k, g->stride, 0, Hp, Wp, g->B);
-        P.y = (float*)workspace; P.ldy = g->Cin; P.addsrc = nullptr; P.ld_add = 0;
-    }
-    P.kc = (!scalar && g->Cout % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
+    if (fold && (g->Cin % 4)) return GDN_ERR_UNSUPPORTED;
     const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg & 0xff);
-    int rc = launch_igemm(P, cfg, st);
+    const int ksplit = pick_ksplit(P, cfg, scalar, tile_cfg);
+    const size_t fb = fold ? fold_bytes(g) : 0, need = fb + ksplit_bytes(P, ksplit);
+    if (need && (!workspace || workspace_bytes < need)) return GDN_ERR_WORKSPACE;
+    if (fold) { P.y = (float*)workspace; P.ldy = g->Cin; P.addsrc = nullptr; P.ld_add = 0; }
+    else { P.y = dx; P.ldy = ldx; P.addsrc = addsrc; P.ld_add = ld_add; }
+    if (ksplit > 1 && ((P.ldy % 4) || (P.addsrc && (P.ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
+    P.kc = (!scalar && g->Cout % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
+    int rc = launch_igemm(P, cfg, st, ksplit, ksplit > 1 ? (char*)workspace + fb : nullptr);
     if (rc != GDN_OK) return rc;
     if (fold) {
         const int64_t total = (int64_t)g->B * g->H * g->W * (g->Cin / 4);

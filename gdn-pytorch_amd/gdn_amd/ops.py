@@ -59,6 +59,7 @@ class Conv:
         self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
         self.reflect, self.transposed = bool(reflect and pad > 0), transposed
         self._geom = {}
+        self._fwd_ws = {}
 
     def geom(self, B, H, W):
         key = (B, H, W)
@@ -89,9 +90,15 @@ class Conv:
         if stats:
             slots = int(lib.gdn_conv_stats_slots(ref, tile_cfg))
             st = torch.empty((slots, 2, self.cout), dtype=torch.float32, device=x.device)
+        nb = self._fwd_ws.get((B, H, W, tile_cfg))
+        if nb is None:
+            nb = int(lib.gdn_conv_fwd_workspace_bytes(ref, tile_cfg))
+            self._fwd_ws[(B, H, W, tile_cfg)] = nb
+        ws = workspace(nb, x.device, "splitk") if nb else None
         try:
             lib.gdn_conv_fwd(ref, _p(x), _ld(x), _p(x2), 0 if x2 is None else _ld(x2), C1, _p(w_tap), _p(y), _ld(y),
-                             _p(addsrc), 0 if addsrc is None else _ld(addsrc), _p(st), act, tile_cfg, stream())
+                             _p(addsrc), 0 if addsrc is None else _ld(addsrc), _p(st), act, tile_cfg, _p(ws), nb,
+                             stream())
         except GdnError as e:
             raise GdnError("%s [conv %d->%d k%d s%d p%d reflect=%s transposed=%s, x %s ld %d, x2 %s]" % (
                 e, self.cin, self.cout, self.k, self.stride, self.pad, self.reflect, self.transposed,
@@ -107,7 +114,7 @@ class Conv:
         if tuple(dy.shape[1:]) != (Ho, Wo, self.cout):
             raise GdnError("dgrad: dy shape %s does not match layer output (%d,%d,%d)" % (tuple(dy.shape), Ho, Wo, self.cout))
         dx = torch.empty((B, H, W, self.cin), dtype=torch.float32, device=dy.device)
-        nb = int(lib.gdn_conv_dgrad_workspace_bytes(ref))
+        nb = int(lib.gdn_conv_dgrad_workspace_bytes(ref, tile_cfg))
         ws = workspace(nb, dy.device, "dgrad") if nb else None
         lib.gdn_conv_dgrad(ref, _p(dy), _ld(dy), _p(wt_tap), _p(dx), _ld(dx), _p(addsrc),
                            0 if addsrc is None else _ld(addsrc), _p(ws), nb, tile_cfg, stream())

@@ -78,19 +78,25 @@ int64_t gdn_conv_stats_slots(const gdn_conv_geom* g, int32_t tile_cfg);
  *   y[pixel][0..Cout)        = act( conv(x) ) (+ addsrc[pixel][..] if addsrc)
  *   stats[slot][0][c], [1][c] = per-block sum / sum of squares of the raw conv
  *                               output (feeds train-mode BatchNorm, K7).
+ * Launches that cannot fill the chip are split over the filter taps (split-K);
+ * their partial sums live in `workspace` (gdn_conv_fwd_workspace_bytes, 0 when
+ * no split is planned) and are combined -- with the same fusions -- by a second
+ * kernel inside the call.
  * tile_cfg: 0 = automatic; >0 forces a tile configuration (tuning/testing). */
+size_t gdn_conv_fwd_workspace_bytes(const gdn_conv_geom* g, int32_t tile_cfg);
 int gdn_conv_fwd(const gdn_conv_geom* g,
                  const float* x, int32_t ldx, const float* x2, int32_t ldx2, int32_t C1,
                  const float* w, float* y, int32_t ldy,
                  const float* addsrc, int32_t ld_add,
-                 float* stats, int32_t act, int32_t tile_cfg, void* stream);
+                 float* stats, int32_t act, int32_t tile_cfg,
+                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* Data gradient.  Replaces autograd's conv backward-data for the call sites
  * above (loss.backward(), trainer.py:467,767).  wt is the tap-major TRANSPOSED
  * weight [kh*kw][Cin][Cout] (see gdn_transpose_taps).  dx = dgrad(dy) (+ addsrc).
  * Reflection-padded layers need a workspace for the gradient on the padded
  * domain, folded back onto dx inside the call. */
-size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g);
+size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g, int32_t tile_cfg);
 int gdn_conv_dgrad(const gdn_conv_geom* g, const float* dy, int32_t ldy,
                    const float* wt, float* dx, int32_t ldx,
                    const float* addsrc, int32_t ld_add,

@@ -37,18 +37,24 @@ def test_host_queries_without_gpu(built_lib):
     assert lib.gdn_version() >= 100
     assert lib.gdn_strerror(-3) == b"workspace missing or too small"
     g = ConvGeom(20, 16, 52, 512, 512, 3, 1, 1, 0, 0)
+    g4 = ConvGeom(20, 8, 26, 512, 512, 3, 1, 1, 0, 0)
     ho, wo = ctypes.c_int32(), ctypes.c_int32()
     lib.gdn_conv_out_dims(ctypes.byref(g), ctypes.byref(ho), ctypes.byref(wo))
     assert (ho.value, wo.value) == (16, 52)
     gt = ConvGeom(20, 8, 26, 512, 512, 4, 2, 1, 0, 1)          # ConvTranspose2d k4 s2 p1
     lib.gdn_conv_out_dims(ctypes.byref(gt), ctypes.byref(ho), ctypes.byref(wo))
     assert (ho.value, wo.value) == (16, 52)
-    assert lib.gdn_conv_stats_slots(ctypes.byref(g), 1) == (20 * 16 * 52 + 127) // 128
-    assert lib.gdn_conv_stats_slots(ctypes.byref(g), 0) == (20 * 16 * 52 + 63) // 64      # auto: 64x64 tiles
-    assert lib.gdn_conv_stats_slots(ctypes.byref(gt), 3) == 4 * ((20 * 8 * 26 + 63) // 64)
+    assert lib.gdn_conv_stats_slots(ctypes.byref(g), 0x800 | 1) == (20 * 16 * 52 + 127) // 128
+    assert lib.gdn_conv_stats_slots(ctypes.byref(g), 0x800) == (20 * 16 * 52 + 63) // 64  # 64x64 tiles, single stage
+    assert lib.gdn_conv_stats_slots(ctypes.byref(g4), 0) == (20 * 8 * 26 + 63) // 64       # split-K: 64 pixels per combine block
+    assert lib.gdn_conv_stats_slots(ctypes.byref(gt), 0x800 | 3) == 4 * ((20 * 8 * 26 + 63) // 64)
     gr = ConvGeom(2, 16, 24, 64, 128, 7, 2, 3, 1, 0)            # reflect-padded strided conv
-    assert lib.gdn_conv_dgrad_workspace_bytes(ctypes.byref(gr)) == 2 * 22 * 30 * 64 * 4
-    assert lib.gdn_conv_dgrad_workspace_bytes(ctypes.byref(g)) == 0
+    assert lib.gdn_conv_dgrad_workspace_bytes(ctypes.byref(gr), 0x800) == 2 * 22 * 30 * 64 * 4   # 0x800: no split-K
+    assert lib.gdn_conv_dgrad_workspace_bytes(ctypes.byref(g), 0x800) == 0
+    # small launches are split over the filter taps: partial slabs [ksplit][pixels][Cout]
+    assert lib.gdn_conv_fwd_workspace_bytes(ctypes.byref(g4), 0) == 4 * 20 * 8 * 26 * 512 * 4
+    assert lib.gdn_conv_fwd_workspace_bytes(ctypes.byref(g), 0) == 0
+    assert lib.gdn_conv_fwd_workspace_bytes(ctypes.byref(g), 0x800) == 0
     assert lib.gdn_conv_wgrad_workspace_bytes(ctypes.byref(g), 512) > 0
     bad = ConvGeom(1, 4, 4, 8, 8, 11, 1, 5, 0, 0)               # 11x11 > 81 taps
     assert lib.gdn_conv_wgrad_workspace_bytes(ctypes.byref(bad), 8) == 0

@@ -232,6 +232,122 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
     }
 }
 
+// Thin variant for the layers whose shifted tensor has 1-3 channels (the image-input 9x9 conv and the
+// two 64->1 heads): all k*Cx columns of a filter row fit ONE 32-column MFMA tile, so a workgroup keeps
+// the G tile in LDS and sweeps ALL k filter rows over it (tile t of column-wave wc is filter row
+// ky = wc + 2t).  G -- the 272 MB tensor -- is read once instead of once per filter row.
+#define TH_XROW 128       // floats per staged X row (>= (31 + 9) * 3)
+__global__ __launch_bounds__(256) void conv_wgrad_thin_f32(const WgradParams p) {
+    constexpr int TW = 32, NTW = 5;
+    __shared__ __attribute__((aligned(16))) float smem[TW * WG_ROWS + 10 * TH_XROW + 64];
+    float* Gs = smem;
+    float* Xs = smem + TW * WG_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave & 1, wc = wave >> 1, h = lane >> 5;
+    const int cgt = blockIdx.x % p.n_cgt, split = blockIdx.x / p.n_cgt;
+    const int Cx = p.Cx, k = p.k;
+    const int npos = (TW - 1) + k, cg0 = cgt * WG_ROWS;
+
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int R = p.B * p.Hg;
+    const int r0 = split * p.rows_per_split, r1 = min(R, r0 + p.rows_per_split);
+    const int nseg = (p.Wg + TW - 1) / TW;
+    const int total = (r1 - r0) * nseg;
+    const unsigned OOB = 0xFFFFFF00u;
+    __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, (int)p.g_bytes, 0x00020000);
+    unsigned g_lane[2]; int g_px[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int idx = tid + 256 * e, c = (idx & 15) * 4;
+        g_px[e] = idx >> 4;
+        g_lane[e] = (cg0 + c < p.Cg) ? (unsigned)(g_px[e] * p.ldg + cg0 + c) * 4u : OOB;
+    }
+    // X staging slots: idx -> (filter row, position*Cx + channel)
+    int x_ky[5], x_q[5];
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+        const int idx = tid + 256 * e;
+        x_ky[e] = idx / TH_XROW;
+        x_q[e] = idx - x_ky[e] * TH_XROW;
+        if (x_ky[e] >= k || x_q[e] >= npos * Cx) x_ky[e] = -1;
+    }
+    f32x4 rg[2];
+    float rx[5];
+
+    auto gload = [&](int sidx) {
+        const int r = r0 + sidx / nseg, ox0 = (sidx % nseg) * TW;
+        const int b = r / p.Hg, oy = r % p.Hg;
+        const int soff = (int)((unsigned)(((b * p.Hg + oy) * p.Wg + ox0) * p.ldg) * 4u);
+        const int wrem = min(p.Wg - ox0, TW);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            rg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, g_px[e] < wrem ? g_lane[e] : OOB, soff, 0));
+        const int ixb = ox0 - p.pad;
+#pragma unroll
+        for (int e = 0; e < 5; ++e) {
+            float v = 0.f;
+            if (x_ky[e] >= 0) {
+                int iy = oy - p.pad + x_ky[e];
+                const int pos = x_q[e] / Cx, c = x_q[e] - pos * Cx;
+                int ix = ixb + pos;
+                if (p.pad_mode == 1) { iy = reflect_idx(iy, p.Hx); ix = reflect_idx(ix, p.Wx); }
+                if ((unsigned)iy < (unsigned)p.Hx && (unsigned)ix < (unsigned)p.Wx)
+                    v = p.x[((size_t)(b * p.Hx + iy) * p.Wx + ix) * p.ldx + c];
+            }
+            rx[e] = v;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) *reinterpret_cast<f32x4*>(&Gs[(tid + 256 * e) * 4]) = rg[e];
+#pragma unroll
+        for (int e = 0; e < 5; ++e)
+            if (tid + 256 * e < 10 * TH_XROW) Xs[tid + 256 * e] = rx[e];
+    };
+
+    const float* Gp = Gs + (h * 16) * WG_ROWS + wr * 32 + (lane & 31);
+    const float* Xp = Xs + wc * TH_XROW + (h * 16) * Cx + (lane & 31);
+    if (total > 0) {
+        gload(0);
+        lstore();
+        __syncthreads();
+        for (int sidx = 0; sidx < total; ++sidx) {
+            if (sidx + 1 < total) gload(sidx + 1);
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+                const float a = Gp[s * WG_ROWS];
+                const float* xr = Xp + s * Cx;
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xr[t * 2 * TH_XROW], acc[t], 0, 0, 0);
+            }
+            __syncthreads();
+            if (sidx + 1 < total) {
+                lstore();
+                __syncthreads();
+            }
+        }
+    }
+    const int KK = k * k, jj = lane & 31;
+    if (jj >= k * Cx) return;
+    const int kx = jj / Cx, cl = jj - kx * Cx;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int ky = wc + 2 * t;
+        if (ky >= k) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cg = cg0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (cg < p.Cg) p.part[(((size_t)split * KK + ky * k + kx) * p.Cg + cg) * Cx + cl] = acc[t][r];
+        }
+    }
+}
+
 // Sum the split-K slabs in a fixed order and scatter to the destination layout.
 //   part [S][KK][R][C]  ->  dw[tap'][..]: element (tap, r, c) goes to
 //   transpose == 0: dw[(tap' * R + r) * ld + off + c]
@@ -258,6 +374,7 @@ namespace {
 struct WgradPlan {
     WgradParams P;
     int transpose, flip;
+    bool thin;
     size_t ws_bytes;
     int blocks;
 };
@@ -289,6 +406,19 @@ bool make_plan(const gdn_conv_geom* g, int Cx_in, WgradPlan& pl) {
         P.Hg = g->H; P.Wg = g->W; P.Cg = Cx_in;              // G role: x (layer input)
         P.Hx = Ho; P.Wx = Wo; P.Cx = g->Cout;                // X role: dy
         pl.transpose = 1;
+    }
+    pl.thin = P.Cx * P.k <= 32 && P.k <= 9 && P.stride == 1 && (P.Cg % 4 == 0) && ((P.k - 1 + 32) * P.Cx <= TH_XROW);
+    if (pl.thin) {
+        P.cisl = P.Cx; P.tw = 32;
+        P.n_cgt = cdiv(P.Cg, WG_ROWS); P.n_cxt = 1;
+        const int R = P.B * P.Hg;
+        int S = cdiv(768, P.n_cgt);
+        if (S > R) S = R;
+        P.rows_per_split = cdiv(R, S);
+        P.S = cdiv(R, P.rows_per_split);
+        pl.blocks = P.n_cgt * P.S;
+        pl.ws_bytes = (size_t)P.S * P.k * P.k * P.Cg * P.Cx * sizeof(float);
+        return true;
     }
     P.cisl = P.Cx < WG_SLAB ? P.Cx : WG_SLAB;
     if (P.Cx > WG_SLAB && (P.Cx % WG_SLAB)) return false;
@@ -371,6 +501,10 @@ extern "C" int gdn_conv_wgrad(const gdn_conv_geom* g, const float* x, int32_t ld
     hipStream_t st = (hipStream_t)stream;
     const int ntw = ((P.k * P.cisl + 31) / 32 + 1) / 2;   // column tiles per wave
     const dim3 grid(pl.blocks), blk(256);
+    if (pl.thin) {
+        if (P.ldg % 4) return GDN_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(conv_wgrad_thin_f32, grid, blk, 0, st, P);
+    } else
 #define WG_LAUNCH(N)                                                                          \
     do {                                                                                      \
         if (P.tw == 32) hipLaunchKernelGGL((conv_wgrad_f32<N, 32>), grid, blk, 0, st, P);     \

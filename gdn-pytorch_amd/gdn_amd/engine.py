@@ -135,9 +135,11 @@ class Ctx:
         return None if e is None else e[1]
 
     def backward(self):
+        if self.tape is None:
+            raise GdnError("this forward's tape was already consumed (retain_graph is not supported on the HIP path)")
         for fn in reversed(self.tape):
             fn()
-        self.tape = []
+        self.tape = None      # drop the saved activations
 
 
 def _dense(t):
@@ -208,14 +210,15 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
         co = _eval_coeffs(bn)
     a = ops.bn_apply(y, co[0], co[1], relu, residual)
     if ctx.record:
-        if not bn.training:
-            raise GdnError("backward through eval-mode BatchNorm is not implemented on the HIP path")
         in_hw = (x.shape[1], x.shape[2])
+        bn_training = bn.training
 
         def bwd():
             da = ctx.pop_grad(a)
             if da is None:
                 return
+            if not bn_training:       # forward in eval mode is fine; only an actual backward needs this
+                raise GdnError("backward through eval-mode BatchNorm is not implemented on the HIP path")
             if residual is not None:
                 ctx.add_grad(residual, da)
             dy = ops.bn_bwd(da, y, bn.weight.data, co, relu, bn.weight.grad, bn.bias.grad)

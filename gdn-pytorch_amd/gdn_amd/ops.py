@@ -77,7 +77,7 @@ class Conv:
         _, ref, _, _ = self.geom(B, H, W)
         return int(lib.gdn_conv_stats_slots(ref, tile_cfg))
 
-    def fwd(self, x, w_tap, x2=None, stats=False, act=ACT_NONE, addsrc=None, tile_cfg=0, out=None):
+    def fwd(self, x, w_tap, x2=None, stats=False, act=ACT_NONE, addsrc=None, tile_cfg=0, out=None, stats_out=None):
         """y = conv(cat(x, x2)); returns y, or (y, stats_partials) when stats."""
         _chk(x, "x")
         B, H, W, C1 = x.shape
@@ -88,8 +88,10 @@ class Conv:
         y = out if out is not None else torch.empty((B, Ho, Wo, self.cout), dtype=torch.float32, device=x.device)
         st = None
         if stats:
-            slots = int(lib.gdn_conv_stats_slots(ref, tile_cfg))
-            st = torch.empty((slots, 2, self.cout), dtype=torch.float32, device=x.device)
+            st = stats_out
+            if st is None:
+                slots = int(lib.gdn_conv_stats_slots(ref, tile_cfg))
+                st = torch.empty((slots, 2, self.cout), dtype=torch.float32, device=x.device)
         nb = self._fwd_ws.get((B, H, W, tile_cfg))
         if nb is None:
             nb = int(lib.gdn_conv_fwd_workspace_bytes(ref, tile_cfg))

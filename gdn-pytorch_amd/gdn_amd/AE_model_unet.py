@@ -275,6 +275,20 @@ class AutoEncoder_DtoD(_EncDec):
         self.upconv4 = nn.ConvTranspose2d(64, 1, kernel_size=9, stride=1, padding=4, bias=False)
         self._finish(init_weights, height, width)
 
+    def guide_features(self, x):
+        """(x1, x2, x4, x6): the four feature maps the RtoD latent loss uses (trainer.py:700,703).
+
+        Identical to ``self(x, istrain=True)[:4]`` but stops at the bottleneck: the decoder -- 48 % of the
+        forward's FLOPs -- is computed and discarded by the reference."""
+        self._check_hw(x)
+        self._encoder_only = True
+        try:
+            return self._forward_impl(x, (0, 1, 2, 3))
+        finally:
+            self._encoder_only = False
+
+    _encoder_only = False
+
     def _run(self, ctx, x):
         x1 = self.res64_down1.run(ctx, self.downconv0.run(ctx, x, need_dx=False))
         x2 = self.res128_down1.run(ctx, self.downconv1.run(ctx, x1))
@@ -284,6 +298,8 @@ class AutoEncoder_DtoD(_EncDec):
         x6 = self.downconv4.run(ctx, x4)
         for i in range(1, 7):
             x6 = getattr(self, "res512_%d" % i).run(ctx, x6)
+        if self._encoder_only:
+            return x1, x2, x4, x6
         x8 = self.res512_up2.run(ctx, self.res512_up1.run(ctx, self.upconv0.run(ctx, x6)))
         x10 = self.res256_up1.run(ctx, self.upconv1.run(ctx, x8))
         x12 = self.res128_up1.run(ctx, self.upconv2.run(ctx, x10))

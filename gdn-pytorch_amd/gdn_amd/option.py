@@ -41,6 +41,9 @@ def build_parser():
     # --- additions of this build ---
     p.add_argument('--synthetic', action='store_true', help='train on synthetic KITTI-shaped batches (no dataset)')
     p.add_argument('--local_rank', type=int, default=0, help='set by the launcher; RANK/LOCAL_RANK env win')
+    p.add_argument('--faithful_guide', action='store_true',
+                   help='RtoD: run the frozen guide as two full forwards like the reference (default: one '
+                        'batched encoder-only pass, identical features)')
     p.add_argument('--global_berhu', action='store_true',
                    help='all-reduce(MAX) the BerHu threshold like DataParallel\'s gathered batch (SURVEY 8(e))')
     return p

@@ -106,6 +106,28 @@ def train_AE_DtoD(args, model, criterion_L2, criterion_L1, optimizer, dataset_lo
     return loss
 
 
+def guide_latent_loss(G, depths, outputs, faithful=False):
+    """Latent loss of trainer.py:699-733: G's features of the ground truth vs. of the estimate, both under
+    no_grad (value only, F3).
+
+    faithful=True runs the guide exactly like the reference: two full forwards with ``istrain=True``.
+    The default gives bit-identical features with 52 % of that work: the frozen eval-mode guide has no
+    cross-sample coupling, so both inputs go through ONE batched, encoder-only pass."""
+    with torch.no_grad():
+        if faithful or not hasattr(G, "guide_features"):
+            ft_tar = G(depths, istrain=True)[:4]
+            ft = G(outputs, istrain=True)[:4]
+        elif G.training:      # batch statistics would couple the two halves: keep them separate
+            ft_tar = G.guide_features(depths)
+            ft = G.guide_features(outputs.detach())
+        else:
+            B = depths.shape[0]
+            both = G.guide_features(torch.cat((depths, outputs.detach()), 0))
+            ft_tar = [f[:B] for f in both]
+            ft = [f[B:] for f in both]
+    return U.latent_loss(ft, ft_tar)
+
+
 def train_AE_RtoD(args, model, DtoD_model, criterion_L2, criterion_L1, optimizer, dataset_loader, val_loader,
                   batch_size, n_epochs, lr, logger, train_writer):
     """Colour->depth training with the frozen guide G (trainer.py:670-768).
@@ -131,10 +153,7 @@ def train_AE_RtoD(args, model, DtoD_model, criterion_L2, criterion_L1, optimizer
             sparse = _to_dev(gt_data_2, dev) if kitti else None
             outputs = model(inputs, istrain=False)
             if not single:
-                with torch.no_grad():
-                    ft_tar = DtoD_model(depths, istrain=True)[:4]
-                    ft = DtoD_model(outputs, istrain=True)[:4]
-                latent = U.latent_loss(ft, ft_tar)
+                latent = guide_latent_loss(DtoD_model, depths, outputs, faithful=getattr(args, "faithful_guide", False))
             pix, output_loss, smooth = U.rtod_pixel_loss(outputs, depths, inputs, sparse)
             loss = pix + latent
             optimizer.zero_grad()

@@ -280,3 +280,21 @@ def test_overlapped_reducer_engine_integration(gpu, monkeypatch):
     assert sorted((p - base) // 4 for p, _, _ in sent) == sorted(b[0] for b in red.buckets)
     torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-8)
     model._gdn_reducer = None
+
+
+def test_guide_fast_path_identical(gpu):
+    """Encoder-only, batched guide pass == the reference's two full guide forwards (RtoD latent loss)."""
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import trainer as T
+    torch.manual_seed(1)
+    G = M.AutoEncoder_DtoD(input_dim=1, height=32, width=64).to(gpu).eval()
+    depth, rgb, _ = [t.to(gpu) for t in O.synthetic_batch(2, 32, 64, seed=5)]
+    est = (depth + 0.2 * torch.randn_like(depth)).clamp(-1, 1)
+    a = T.guide_latent_loss(G, depth, est, faithful=True)
+    b = T.guide_latent_loss(G, depth, est, faithful=False)
+    assert a.item() == pytest.approx(b.item(), rel=1e-6)
+    with torch.no_grad():
+        full = G(depth, istrain=True)[:4]
+        enc = G.guide_features(depth)
+    for f, e in zip(full, enc):
+        assert torch.equal(f, e)

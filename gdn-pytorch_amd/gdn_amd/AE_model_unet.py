@@ -69,6 +69,8 @@ class _Bridge(torch.autograd.Function):
 
     @staticmethod
     def backward(fctx, *gouts):
+        if fctx.gdn is None:
+            raise GdnError("this forward's tape was already consumed (retain_graph is not supported on the HIP path)")
         ctx, outs, arena = fctx.gdn
         fctx.gdn = None
         pending = arena.bind_grads()

@@ -44,6 +44,36 @@ __device__ __forceinline__ double block_sum_d256(double v, double* sh) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// ---- bf16 storage helpers (configs[2]: bf16 tensors, fp32 arithmetic) ----
+__device__ __forceinline__ unsigned short f32_to_bf16_h(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);      // round to nearest even (NaN inputs do not occur on this path)
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_h_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+// 4 consecutive elements at element index idx of a float (bf16 == 0) or bfloat16 (bf16 != 0) array
+__device__ __forceinline__ f32x4 ld4_any(const void* p, size_t idx, int bf16) {
+    if (!bf16) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + idx);
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + idx);
+    f32x4 v = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+               __uint_as_float(u.y & 0xffff0000u)};
+    return v;
+}
+__device__ __forceinline__ void st4_any(void* p, size_t idx, f32x4 v, int bf16) {
+    if (!bf16) { *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p) + idx) = v; return; }
+    uint2 u;
+    u.x = (unsigned)f32_to_bf16_h(v[0]) | ((unsigned)f32_to_bf16_h(v[1]) << 16);
+    u.y = (unsigned)f32_to_bf16_h(v[2]) | ((unsigned)f32_to_bf16_h(v[3]) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p) + idx) = u;
+}
+__device__ __forceinline__ float ld1_any(const void* p, size_t idx, int bf16) {
+    return bf16 ? bf16_h_to_f32(reinterpret_cast<const unsigned short*>(p)[idx]) : reinterpret_cast<const float*>(p)[idx];
+}
+__device__ __forceinline__ void st1_any(void* p, size_t idx, float v, int bf16) {
+    if (bf16) reinterpret_cast<unsigned short*>(p)[idx] = f32_to_bf16_h(v);
+    else reinterpret_cast<float*>(p)[idx] = v;
+}
+
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     i = i < 0 ? -i : i;
     return i >= n ? 2 * (n - 1) - i : i;

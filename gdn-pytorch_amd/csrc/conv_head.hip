@@ -9,6 +9,7 @@
 // horizontally adjacent pixels: per filter row it reads 12 float4 from LDS and
 // issues 9 taps x 4 pixels x 4 channels = 144 FMAs.  Weights are wave-uniform
 // (scalar loads).  HBM traffic: the input once (272 MB at B=20) + 4 B per pixel out.
+// Mixed-precision path: x may hold bf16 (weights and the depth map stay fp32).
 #include "common.h"
 
 namespace {
@@ -18,9 +19,9 @@ namespace {
 #define HD_PX 4
 
 template <int K>
-__global__ __launch_bounds__(256) void conv_head_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void conv_head_kernel(const void* __restrict__ x, int ldx, const float* __restrict__ w,
                                                         float* __restrict__ y, int B, int H, int W, int C, int pad,
-                                                        int flip, int act, int tiles_x, int tiles_y) {
+                                                        int flip, int act, int tiles_x, int tiles_y, int x_bf16) {
     constexpr int PH = HD_TH + K - 1, PW = HD_TW + K - 1;
     constexpr int PWQ = (PW + 3) / 4;                 // swizzled row: [r = col%4][q = col/4]
     __shared__ f32x4 patch[PH * PWQ * 4];
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void conv_head_kernel(const float* __restrict_
     const int tiy = bid % tiles_y;
     const int b = bid / tiles_y;
     const int y0 = tiy * HD_TH, x0 = tix * HD_TW;
-    const float* xb = x + (size_t)b * H * W * ldx;
+    const size_t xb = (size_t)b * H * W * ldx;
 
     float acc[HD_PX] = {0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < C; c0 += 4) {
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void conv_head_kernel(const float* __restrict_
             const int iy = y0 - pad + py, ix = x0 - pad + px;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = *reinterpret_cast<const f32x4*>(xb + ((size_t)iy * W + ix) * ldx + c0);
+                v = ld4_any(x, xb + ((size_t)iy * W + ix) * ldx + c0, x_bf16);
             patch[(py * 4 + (px & 3)) * PWQ + (px >> 2)] = v;
         }
         __syncthreads();
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(256) void conv_head_kernel(const float* __restrict_
 }  // namespace
 
 // Returns GDN_ERR_UNSUPPORTED when the geometry is not a 1-channel stride-1 head this kernel covers.
-int gdn_conv_head_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w, float* y, int32_t ldy,
-                      int32_t act, void* stream) {
+int gdn_conv_head_fwd(const gdn_conv_geom* g, const void* x, int32_t ldx, const float* w, float* y, int32_t ldy,
+                      int32_t act, int32_t x_bf16, void* stream) {
     if (g->Cout != 1 || g->stride != 1 || g->k != 9 || g->pad_mode != 0 || (g->Cin % 4) || (ldx % 4) || ldy != 1)
         return GDN_ERR_UNSUPPORTED;
     // Conv2d: out[o] = sum x[o - p + k] w[k];  ConvTranspose2d (s=1): out[o] = sum x[o + p - k] w[k]
@@ -93,6 +94,6 @@ int gdn_conv_head_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const
     if (Ho != g->H || Wo != g->W) return GDN_ERR_UNSUPPORTED;      // "same" heads only
     const int tiles_x = cdiv(g->W, HD_TW), tiles_y = cdiv(g->H, HD_TH);
     hipLaunchKernelGGL((conv_head_kernel<9>), dim3(tiles_x * tiles_y * g->B), dim3(256), 0, (hipStream_t)stream, x,
-                       ldx, w, y, g->B, g->H, g->W, g->Cin, pad, g->transposed ? 1 : 0, act, tiles_x, tiles_y);
+                       ldx, w, y, g->B, g->H, g->W, g->Cin, pad, g->transposed ? 1 : 0, act, tiles_x, tiles_y, x_bf16);
     return gdn_launch_status();
 }

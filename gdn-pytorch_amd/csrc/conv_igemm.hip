@@ -39,6 +39,7 @@ struct IgemmParams {
     unsigned long long x_bytes, x2_bytes;  // tensor extents; descriptors are re-based per workgroup (32-bit offsets)
     unsigned w_bytes;
     int kc;                                // reduction slab per k-step (32 or 64)
+    int bf16;                              // 1: x/x2/w/y/addsrc hold bf16 (fp32 accumulate, fp32 stats/partials)
     int ksplit;                            // split-K over taps (grid.z); >1: raw partials go to `part`
     float* part;                           // [ksplit][npix_out][N]
     long long npix_out;
@@ -362,15 +363,250 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// bf16 variant (BASELINE configs[2]): bf16 activations/weights, v_mfma_f32_32x32x16_bf16, fp32
+// accumulate, fp32 BatchNorm statistics.  Same byte geometry as the fp32 kernel -- a k-step row is
+// 128 bytes (64 channels), 8 lanes x 16 B per row, 144-byte LDS pitch, lane-half h owns bytes
+// [64h, 64h+64) of the row -- so loader, LDS image and tile/phase logic are shared; one 16-byte
+// fragment read now feeds ONE MFMA (8 bf16 k-values) instead of four.  The MFMA is 16x faster than
+// the fp32 one, so the tile is 128x128 (64 MFMAs per wave per k-step) to keep it fed.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) { return f32_to_bf16_h(f); }
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_bf16(const IgemmParams p) {
+    constexpr int KC = 64, LDS_LD = 36, RPP = 32;        // 64 bf16 = 128 B per row, 144-B pitch
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int A_FLOATS = BM * LDS_LD, B_FLOATS = BN * LDS_LD;
+    __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS + 3 * BM];
+    float* As = smem;
+    float* Bs = smem + A_FLOATS;
+    int* row_pix = reinterpret_cast<int*>(smem + A_FLOATS + B_FLOATS);
+    int* row_out = row_pix + BM;
+    int* row_yx = row_out + BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ph_i = blockIdx.y;
+    IgemmPhase ph = p.ph[ph_i];
+    const int kz = blockIdx.z;
+    if (p.ksplit > 1) {
+        const int tb = ph.tap_begin, nt_all = ph.tap_end - ph.tap_begin;
+        ph.tap_begin = tb + (nt_all * kz) / p.ksplit;
+        ph.tap_end = tb + (nt_all * (kz + 1)) / p.ksplit;
+    }
+    const int bid = blockIdx.x, xcd = bid & 7, q = bid >> 3;
+    const int per_xcd = (p.grid_m + 7) >> 3;
+    const int nt = q % p.grid_n, mt = xcd * per_xcd + q / p.grid_n;
+    if (q / p.grid_n >= per_xcd || mt >= p.grid_m) return;
+    const int M = p.B * ph.Ho * ph.Wo;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int slot = ph_i * p.grid_m + mt;
+    if (m0 >= M) {
+        if (p.ksplit == 1 && p.stats && tid < BN && n0 + tid < p.N) {
+            p.stats[((size_t)slot * 2 + 0) * p.N + n0 + tid] = 0.f;
+            p.stats[((size_t)slot * 2 + 1) * p.N + n0 + tid] = 0.f;
+        }
+        return;
+    }
+    const int b_first = m0 / (ph.Ho * ph.Wo);
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        if (m < M) {
+            const int ox = m % ph.Wo, t = m / ph.Wo, oy = t % ph.Ho, b = t / ph.Ho;
+            row_pix[r] = (b - b_first) * p.Hi * p.Wi;
+            row_yx[r] = (oy * p.stride) | ((ox * p.stride) << 16);
+            row_out[r] = (b * p.Hy + oy * p.osy + ph.oy0) * p.Wy + ox * p.osx + ph.ox0;
+        } else {
+            row_pix[r] = -1; row_yx[r] = 0; row_out[r] = -1;
+        }
+    }
+    __syncthreads();
+
+    const int ntap = ph.tap_end - ph.tap_begin;
+    const int nchunks = p.Cred / KC;
+    const int nk = ntap * nchunks;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
+    f32x4 ra[A_PASSES], rb[B_PASSES];
+    int aoff[A_PASSES];
+    unsigned boff[B_PASSES];
+    int tl_n = 0, cc_n = 0, wi_n = 0;
+    const unsigned lane_b = (unsigned)(tid & 7) * 16u;
+    const int row_in_pass = tid >> 3;
+    const unsigned long long img1 = (unsigned long long)p.Hi * p.Wi * p.ldx1 * 2ull * b_first;
+    const unsigned long long img2 = (unsigned long long)p.Hi * p.Wi * p.ldx2 * 2ull * b_first;
+    const unsigned long long rem1 = p.x_bytes - img1, rem2 = p.x2 ? p.x2_bytes - img2 : rem1;
+    const unsigned long long cap = 0xFF000000ull;
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x) + img1), 0, (int)(unsigned)(rem1 < cap ? rem1 : cap), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(p.x2 ? reinterpret_cast<const char*>(p.x2) + img2 : reinterpret_cast<const char*>(p.x) + img1), 0,
+        (int)(unsigned)(rem2 < cap ? rem2 : cap), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) {
+        const int n = n0 + ps * RPP + row_in_pass;
+        boff[ps] = n < p.N ? (unsigned)(n * p.Cred) * 2u + lane_b : 0xFFFFFF00u;
+    }
+    auto set_tap = [&](int tl) {
+        const int t = ph.tap_begin + tl;
+        const int dy = p.tdy[t], dx = p.tdx[t];
+        wi_n = p.twi[t];
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps) {
+            const int r = ps * RPP + row_in_pass;
+            const int base = row_pix[r], yx = row_yx[r];
+            int iy = (yx & 0xffff) + dy, ix = (yx >> 16) + dx;
+            if (p.pad_mode == 1) { iy = reflect_idx(iy, p.Hi); ix = reflect_idx(ix, p.Wi); }
+            const bool ok = base >= 0 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            aoff[ps] = ok ? base + iy * p.Wi + ix : -1;
+        }
+    };
+    auto gload = [&]() {
+        if (cc_n == 0) set_tap(tl_n);
+        const int ci0 = cc_n * KC;
+        const bool first = ci0 < p.C1;
+        const unsigned ld2 = (unsigned)(first ? p.ldx1 : p.ldx2) * 2u;
+        const int soff = (first ? ci0 : ci0 - p.C1) * 2;
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps) {
+            const unsigned vo = (unsigned)aoff[ps] * ld2 + lane_b;
+            ra[ps] = __builtin_bit_cast(f32x4, first ? __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, soff, 0)
+                                                     : __builtin_amdgcn_raw_buffer_load_b128(rs_x2, vo, soff, 0));
+        }
+        const int soff_w = (wi_n * p.w_tap_stride + ci0) * 2;
+#pragma unroll
+        for (int ps = 0; ps < B_PASSES; ++ps)
+            rb[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, boff[ps], soff_w, 0));
+        if (++cc_n == nchunks) { cc_n = 0; ++tl_n; }
+    };
+    auto lds_store = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps)
+            *reinterpret_cast<f32x4*>(&As[(ps * RPP + row_in_pass) * LDS_LD + (tid & 7) * 4]) = ra[ps];
+#pragma unroll
+        for (int ps = 0; ps < B_PASSES; ++ps)
+            *reinterpret_cast<f32x4*>(&Bs[(ps * RPP + row_in_pass) * LDS_LD + (tid & 7) * 4]) = rb[ps];
+    };
+    const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 16;
+    const int b_off = (wn * TN * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 16;
+
+    gload();
+    lds_store();
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + 1 < nk) gload();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&As[a_off + i * 32 * LDS_LD + g * 4]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&Bs[b_off + j * 32 * LDS_LD + g * 4]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (ks + 1 < nk) {
+            lds_store();
+            __syncthreads();
+        }
+    }
+
+    const int col_l = lane & 31, rsh = 4 * (lane >> 5);
+    if (p.ksplit > 1) {
+        float* pp = p.part + (size_t)kz * p.npix_out * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + rsh;
+                const int op = row_out[row];
+                if (op < 0) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+                    if (n < p.N) pp[(size_t)op * p.N + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    if (p.stats) {
+        float* red = As;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s1 += v; s2 += v * v; }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) {
+                const int c = wn * TN * 32 + j * 32 + lane;
+                red[(wm * BN + c) * 2 + 0] = s1;
+                red[(wm * BN + c) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int wmi = 0; wmi < WAVES_M; ++wmi) { s1 += red[(wmi * BN + tid) * 2]; s2 += red[(wmi * BN + tid) * 2 + 1]; }
+            p.stats[((size_t)slot * 2 + 0) * p.N + n0 + tid] = s1;
+            p.stats[((size_t)slot * 2 + 1) * p.N + n0 + tid] = s2;
+        }
+    }
+    unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
+    const unsigned short* ad = reinterpret_cast<const unsigned short*>(p.addsrc);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + rsh;
+            const int op = row_out[row];
+            if (op < 0) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+                if (n < p.N) {
+                    float v = acc[i][j][r];
+                    if (ad) v += bf16_to_f32(ad[(size_t)op * p.ld_add + n]);
+                    if (p.act == GDN_ACT_TANH) v = tanhf(v);
+                    yo[(size_t)op * p.ldy + n] = f32_to_bf16(v);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Host side: geometry -> phases / tap lists, tile selection, launch.
 // ---------------------------------------------------------------------------
 // Second stage of a split-K launch: y = act(sum_z part[z] + addsrc), plus the per-block BatchNorm
 // partial statistics the single-stage epilogue would have produced.  64 pixels per workgroup.
 #define SK_ROWS 64
 __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ part, int ksplit, long long npix,
-                                                             int N, float* __restrict__ y, int ldy,
-                                                             const float* __restrict__ addsrc, int ld_add, int act,
-                                                             float* __restrict__ stats) {
+                                                             int N, void* __restrict__ y, int ldy,
+                                                             const void* __restrict__ addsrc, int ld_add, int act,
+                                                             float* __restrict__ stats, int bf16) {
     __shared__ float sh[256 * 8];
     const int cq = N >> 2;
     const int CQ = cq < 256 ? cq : 256, PY = 256 / CQ;
@@ -387,12 +623,12 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
                 for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + z * zs + (size_t)pix * N + c);
                 s1 += v;
                 s2 += v * v;
-                if (addsrc) v += *reinterpret_cast<const f32x4*>(addsrc + (size_t)pix * ld_add + c);
+                if (addsrc) v += ld4_any(addsrc, (size_t)pix * ld_add + c, bf16);
                 if (act == GDN_ACT_TANH) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
                 }
-                *reinterpret_cast<f32x4*>(y + (size_t)pix * ldy + c) = v;
+                st4_any(y, (size_t)pix * ldy + c, v, bf16);
             }
         }
         if (stats) {
@@ -423,7 +659,14 @@ struct TileCfg { int bm, bn; };
 #define NUM_CFG 8
 const TileCfg kCfg[NUM_CFG] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 64}, {32, 128}, {64, 128}};
 
-int pick_cfg(int64_t M, int N, bool scalar, int forced) {
+// bf16: the MFMA is 16x faster, so tiles must be large enough to amortise the staging of a k-step.
+int pick_cfg_bf16(int64_t M, int N, int forced) {
+    if (forced >= 1 && forced <= 3) return forced;
+    if (N <= 64) return 2;
+    return cdiv64(M, 128) * cdiv(N, 128) >= 384 ? 1 : 3;
+}
+
+int pick_cfg_f32(int64_t M, int N, bool scalar, int forced) {
     // Measured on MI355X at B=20 (tools/tune_conv.py, profiles/r01_tune_conv_*): 64x64 tiles at
     // 6 waves/SIMD beat every larger tile on every layer (CU balance + latency hiding).
     (void)M;
@@ -431,6 +674,11 @@ int pick_cfg(int64_t M, int N, bool scalar, int forced) {
     if ((forced >= 1 && forced <= 4) || forced == 6 || forced == 7) return forced;
     if (N <= 32) return 4;
     return 3;
+}
+
+#define CFG_BF16 0x10000     // GDN_CFG_BF16 in tile_cfg: tensors hold bf16
+int pick_cfg(int64_t M, int N, bool scalar, int tile_cfg) {
+    return (tile_cfg & CFG_BF16) ? pick_cfg_bf16(M, N, tile_cfg & 0xff) : pick_cfg_f32(M, N, scalar, tile_cfg & 0xff);
 }
 
 // Builds the phase decomposition of a "transposed-type" gather:
@@ -537,6 +785,16 @@ int launch_igemm(IgemmParams& P, int cfg, hipStream_t st, int ksplit = 1, void* 
     P.part = (float*)split_ws;
     P.npix_out = (long long)P.B * P.Hy * P.Wy;
     if (ksplit > 1 && !split_ws) return GDN_ERR_WORKSPACE;
+    if (P.bf16) {
+        const int gm_pad = cdiv(P.grid_m, 8) * 8;
+        dim3 grid((unsigned)(gm_pad * P.grid_n), (unsigned)P.nphase, (unsigned)P.ksplit);
+        switch (cfg) {
+            case 1: hipLaunchKernelGGL((conv_igemm_bf16<128, 128, 2, 2>), grid, dim3(256), 0, st, P); break;
+            case 2: hipLaunchKernelGGL((conv_igemm_bf16<128, 64, 2, 2>), grid, dim3(256), 0, st, P); break;
+            case 3: hipLaunchKernelGGL((conv_igemm_bf16<64, 64, 2, 2>), grid, dim3(256), 0, st, P); break;
+            default: return GDN_ERR_BAD_ARG;
+        }
+    } else
     switch (cfg) {
         case 1: launch_one<128, 128, 2, 2, false>(P, st); break;
         case 2: launch_one<128, 64, 2, 2, false>(P, st); break;
@@ -550,7 +808,7 @@ int launch_igemm(IgemmParams& P, int cfg, hipStream_t st, int ksplit = 1, void* 
     if (ksplit > 1) {
         const int blocks = (int)cdiv64(P.npix_out, SK_ROWS);
         hipLaunchKernelGGL(splitk_combine_kernel, dim3(blocks), dim3(256), 0, st, (const float*)P.part, ksplit,
-                           P.npix_out, P.N, P.y, P.ldy, P.addsrc, P.ld_add, P.act, P.stats);
+                           P.npix_out, P.N, (void*)P.y, P.ldy, (const void*)P.addsrc, P.ld_add, P.act, P.stats, P.bf16);
     }
     return gdn_launch_status();
 }
@@ -563,9 +821,9 @@ bool geom_ok(const gdn_conv_geom* g) {
     return true;
 }
 
-__global__ void reflect_fold_kernel(const float* __restrict__ dxp, float* __restrict__ dx,
-                                    const float* __restrict__ addsrc, int ld_add, int ldx,
-                                    int B, int H, int W, int C, int p) {
+__global__ void reflect_fold_kernel(const void* __restrict__ dxp, void* __restrict__ dx,
+                                    const void* __restrict__ addsrc, int ld_add, int ldx,
+                                    int B, int H, int W, int C, int p, int bf16) {
     // dx[y][x] = sum of dxp over the padded coordinates that reflect onto (y, x).
     const int Hp = H + 2 * p, Wp = W + 2 * p;
     const int c4n = C / 4;
@@ -586,10 +844,10 @@ __global__ void reflect_fold_kernel(const float* __restrict__ dxp, float* __rest
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int a = 0; a < ny; ++a)
             for (int e = 0; e < nx; ++e)
-                s += *reinterpret_cast<const f32x4*>(dxp + ((size_t)(b * Hp + qy[a]) * Wp + qx[e]) * C + c4 * 4);
+                s += ld4_any(dxp, ((size_t)(b * Hp + qy[a]) * Wp + qx[e]) * C + c4 * 4, bf16);
         const size_t op = (size_t)(b * H + y) * W + x;
-        if (addsrc) s += *reinterpret_cast<const f32x4*>(addsrc + op * ld_add + c4 * 4);
-        *reinterpret_cast<f32x4*>(dx + op * ldx + c4 * 4) = s;
+        if (addsrc) s += ld4_any(addsrc, op * ld_add + c4 * 4, bf16);
+        st4_any(dx, op * ldx + c4 * 4, s, bf16);
     }
 }
 
@@ -609,8 +867,8 @@ extern "C" int gdn_conv_out_dims(const gdn_conv_geom* g, int32_t* Ho, int32_t* W
 }
 
 // conv_head.hip: register-blocked VALU kernel for the 1-channel 9x9 heads
-int gdn_conv_head_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w, float* y, int32_t ldy,
-                      int32_t act, void* stream);
+int gdn_conv_head_fwd(const gdn_conv_geom* g, const void* x, int32_t ldx, const float* w, float* y, int32_t ldy,
+                      int32_t act, int32_t x_bf16, void* stream);
 
 static int fill_fwd(const gdn_conv_geom* g, IgemmParams& P) {
     int Ho, Wo;
@@ -629,7 +887,7 @@ extern "C" int64_t gdn_conv_stats_slots(const gdn_conv_geom* g, int32_t tile_cfg
     IgemmParams P{};
     if (fill_fwd(g, P) != GDN_OK) return GDN_ERR_BAD_ARG;
     const bool scalar = (g->Cin % KC_MIN) != 0;
-    const int cfg = pick_cfg(max_phase_m(P), g->Cout, scalar, tile_cfg & 0xff);
+    const int cfg = pick_cfg(max_phase_m(P), g->Cout, scalar, tile_cfg);
     if (pick_ksplit(P, cfg, scalar, tile_cfg) > 1) return cdiv64((int64_t)P.B * P.Hy * P.Wy, SK_ROWS);
     return (int64_t)P.nphase * cdiv64(max_phase_m(P), kCfg[cfg].bm);
 }
@@ -638,19 +896,24 @@ extern "C" size_t gdn_conv_fwd_workspace_bytes(const gdn_conv_geom* g, int32_t t
     IgemmParams P{};
     if (fill_fwd(g, P) != GDN_OK) return 0;
     const bool scalar = (g->Cin % KC_MIN) != 0;
-    const int cfg = pick_cfg(max_phase_m(P), g->Cout, scalar, tile_cfg & 0xff);
+    const int cfg = pick_cfg(max_phase_m(P), g->Cout, scalar, tile_cfg);
     return ksplit_bytes(P, pick_ksplit(P, cfg, scalar, tile_cfg));
 }
 
-extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* x2, int32_t ldx2,
-                            int32_t C1, const float* w, float* y, int32_t ldy, const float* addsrc, int32_t ld_add,
+extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const void* xv, int32_t ldx, const void* x2v, int32_t ldx2,
+                            int32_t C1, const void* wv, void* yv, int32_t ldy, const void* addsrcv, int32_t ld_add,
                             float* stats, int32_t act, int32_t tile_cfg, void* workspace, size_t workspace_bytes,
                             void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    const float *x = (const float*)xv, *x2 = (const float*)x2v, *w = (const float*)wv, *addsrc = (const float*)addsrcv;
+    float* y = (float*)yv;
+    const bool bf = (tile_cfg & CFG_BF16) != 0;
+    const uint64_t es = bf ? 2 : 4;
     if (!geom_ok(g) || !x || !w || !y) return GDN_ERR_BAD_ARG;
-    if (g->Cout == 1 && !x2 && !stats && !addsrc && tile_cfg == 0) {
-        const int rc = gdn_conv_head_fwd(g, x, ldx, w, y, ldy, act, stream);
-        if (rc != GDN_ERR_UNSUPPORTED) return rc;
+    if (g->Cout == 1 && !x2 && !stats && !addsrc && (tile_cfg & ~CFG_BF16) == 0) {
+        // 1-channel heads: with GDN_CFG_BF16 only x is bf16 -- weights and the depth map stay fp32
+        const int rc = gdn_conv_head_fwd(g, x, ldx, w, y, ldy, act, bf ? 1 : 0, stream);
+        if (rc != GDN_ERR_UNSUPPORTED || bf) return rc;
     }
     IgemmParams P{};
     if (fill_fwd(g, P) != GDN_OK) return GDN_ERR_BAD_ARG;
@@ -659,20 +922,23 @@ extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx,
     if (C1 <= 0 || C1 > g->Cin) return GDN_ERR_BAD_ARG;
     if (scalar && C1 != g->Cin) return GDN_ERR_UNSUPPORTED;
     if (!scalar && ((C1 % KC_MIN) || (ldx % 4) || (x2 && (ldx2 % 4)))) return GDN_ERR_UNSUPPORTED;
+    // bf16: 64-channel (128-byte) slabs, 16-byte aligned rows
+    if (bf && ((g->Cin % 64) || (C1 % 64) || (ldx % 8) || (x2 && (ldx2 % 8)))) return GDN_ERR_UNSUPPORTED;
+    P.bf16 = bf ? 1 : 0;
     P.x = x; P.x2 = x2; P.w = w; P.y = y; P.addsrc = addsrc; P.stats = stats;
     P.C1 = C1; P.C2 = g->Cin - C1; P.ldx1 = ldx; P.ldx2 = ldx2; P.ldy = ldy; P.ld_add = ld_add; P.act = act;
     {
         const uint64_t npix = (uint64_t)g->B * g->H * g->W;
-        const uint64_t xb = ((npix - 1) * (uint64_t)ldx + C1) * 4, x2b = x2 ? ((npix - 1) * (uint64_t)ldx2 + P.C2) * 4 : 0;
-        const uint64_t wb = (uint64_t)g->k * g->k * g->Cout * g->Cin * 4;
+        const uint64_t xb = ((npix - 1) * (uint64_t)ldx + C1) * es, x2b = x2 ? ((npix - 1) * (uint64_t)ldx2 + P.C2) * es : 0;
+        const uint64_t wb = (uint64_t)g->k * g->k * g->Cout * g->Cin * es;
         // per-workgroup descriptors span at most two images
-        const uint64_t two1 = 2ull * g->H * g->W * (uint64_t)ldx * 4, two2 = x2 ? 2ull * g->H * g->W * (uint64_t)ldx2 * 4 : 0;
+        const uint64_t two1 = 2ull * g->H * g->W * (uint64_t)ldx * es, two2 = x2 ? 2ull * g->H * g->W * (uint64_t)ldx2 * es : 0;
         if (two1 >= kMaxBufBytes || two2 >= kMaxBufBytes || wb >= kMaxBufBytes) return GDN_ERR_UNSUPPORTED;
         P.x_bytes = xb; P.x2_bytes = x2b; P.w_bytes = (unsigned)wb;
     }
     // 32-channel slabs measured faster than 64 everywhere (6 waves/SIMD vs 4); 0x200 selects 64 for tuning runs
     P.kc = (!scalar && g->Cin % 64 == 0 && C1 % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
-    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg & 0xff);
+    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg);
     const int ksplit = pick_ksplit(P, cfg, scalar, tile_cfg);
     if (ksplit > 1 && (!workspace || workspace_bytes < ksplit_bytes(P, ksplit))) return GDN_ERR_WORKSPACE;
     if (ksplit > 1 && ((ldy % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
@@ -712,14 +978,18 @@ extern "C" size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g, int32_t
     IgemmParams P{};
     bool fold, scalar;
     if (!fill_dgrad(g, P, fold, scalar)) return 0;
-    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg & 0xff);
+    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg);
     return (fold ? fold_bytes(g) : 0) + ksplit_bytes(P, pick_ksplit(P, cfg, scalar, tile_cfg));
 }
 
-extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* wt, float* dx,
-                              int32_t ldx, const float* addsrc, int32_t ld_add, void* workspace,
+extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t ldy, const void* wtv, void* dxv,
+                              int32_t ldx, const void* addsrcv, int32_t ld_add, void* workspace,
                               size_t workspace_bytes, int32_t tile_cfg, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    const float *dy = (const float*)dyv, *wt = (const float*)wtv, *addsrc = (const float*)addsrcv;
+    float* dx = (float*)dxv;
+    const bool bf = (tile_cfg & CFG_BF16) != 0;
+    const uint64_t es = bf ? 2 : 4;
     if (!dy || !wt || !dx) return GDN_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     IgemmParams P{};
@@ -727,14 +997,16 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const float* dy, int32_t l
     if (!fill_dgrad(g, P, fold, scalar)) return GDN_ERR_BAD_ARG;
     P.x = dy; P.ldx1 = ldy; P.w = wt;
     {
-        const uint64_t xb = (((uint64_t)g->B * P.Hi * P.Wi - 1) * (uint64_t)ldy + g->Cout) * 4;
-        const uint64_t wb = (uint64_t)g->k * g->k * g->Cout * g->Cin * 4;
-        if (2ull * P.Hi * P.Wi * (uint64_t)ldy * 4 >= kMaxBufBytes || wb >= kMaxBufBytes) return GDN_ERR_UNSUPPORTED;
+        const uint64_t xb = (((uint64_t)g->B * P.Hi * P.Wi - 1) * (uint64_t)ldy + g->Cout) * es;
+        const uint64_t wb = (uint64_t)g->k * g->k * g->Cout * g->Cin * es;
+        if (2ull * P.Hi * P.Wi * (uint64_t)ldy * es >= kMaxBufBytes || wb >= kMaxBufBytes) return GDN_ERR_UNSUPPORTED;
         P.x_bytes = xb; P.x2_bytes = 0; P.w_bytes = (unsigned)wb;
     }
     if (!scalar && (ldy % 4)) return GDN_ERR_UNSUPPORTED;
+    if (bf && (scalar || (g->Cout % 64) || (ldy % 8) || (g->Cin % 4))) return GDN_ERR_UNSUPPORTED;
+    P.bf16 = bf ? 1 : 0;
     if (fold && (g->Cin % 4)) return GDN_ERR_UNSUPPORTED;
-    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg & 0xff);
+    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg);
     const int ksplit = pick_ksplit(P, cfg, scalar, tile_cfg);
     const size_t fb = fold ? fold_bytes(g) : 0, need = fb + ksplit_bytes(P, ksplit);
     if (need && (!workspace || workspace_bytes < need)) return GDN_ERR_WORKSPACE;
@@ -747,8 +1019,8 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const float* dy, int32_t l
     if (fold) {
         const int64_t total = (int64_t)g->B * g->H * g->W * (g->Cin / 4);
         const int blocks = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
-        hipLaunchKernelGGL(reflect_fold_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dx, addsrc,
-                           ld_add, ldx, g->B, g->H, g->W, g->Cin, g->pad);
+        hipLaunchKernelGGL(reflect_fold_kernel, dim3(blocks), dim3(256), 0, st, (const void*)workspace, (void*)dx,
+                           (const void*)addsrc, ld_add, ldx, g->B, g->H, g->W, g->Cin, g->pad, P.bf16);
         rc = gdn_launch_status();
     }
     return rc;

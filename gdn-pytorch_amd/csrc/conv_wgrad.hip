@@ -31,6 +31,7 @@ struct WgradParams {
     int k, stride, pad, pad_mode;
     int cisl, n_cgt, n_cxt, S, rows_per_split;
     int tw;                         // pixels per row segment
+    int g_bf16;                     // thin variant only: the G tensor holds bf16 (mixed-precision path)
     unsigned g_bytes, x_bytes;      // extents for the buffer descriptors (< 4 GiB each)
 };
 
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_f32(const WgradParams p) 
     for (int e = 0; e < 2; ++e) {
         const int idx = tid + 256 * e, c = (idx & 15) * 4;
         g_px[e] = idx >> 4;
-        g_lane[e] = (cg0 + c < p.Cg) ? (unsigned)(g_px[e] * p.ldg + cg0 + c) * 4u : OOB;
+        g_lane[e] = (cg0 + c < p.Cg) ? (unsigned)(g_px[e] * p.ldg + cg0 + c) * (p.g_bf16 ? 2u : 4u) : OOB;
     }
     // X staging slots: idx -> (filter row, position*Cx + channel)
     int x_ky[5], x_q[5];
@@ -282,8 +283,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_f32(const WgradParams p) 
     auto gload = [&](int sidx) {
         const int r = r0 + sidx / nseg, ox0 = (sidx % nseg) * TW;
         const int b = r / p.Hg, oy = r % p.Hg;
-        const int soff = (int)((unsigned)(((b * p.Hg + oy) * p.Wg + ox0) * p.ldg) * 4u);
+        const int soff = (int)((unsigned)(((b * p.Hg + oy) * p.Wg + ox0) * p.ldg) * (p.g_bf16 ? 2u : 4u));
         const int wrem = min(p.Wg - ox0, TW);
+        if (p.g_bf16) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 u = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_g, g_px[e] < wrem ? g_lane[e] : OOB, soff, 0));
+                rg[e][0] = __uint_as_float(u[0] << 16); rg[e][1] = __uint_as_float(u[0] & 0xffff0000u);
+                rg[e][2] = __uint_as_float(u[1] << 16); rg[e][3] = __uint_as_float(u[1] & 0xffff0000u);
+            }
+        } else
 #pragma unroll
         for (int e = 0; e < 2; ++e)
             rg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, g_px[e] < wrem ? g_lane[e] : OOB, soff, 0));
@@ -479,10 +489,11 @@ extern "C" size_t gdn_conv_wgrad_workspace_bytes(const gdn_conv_geom* g, int32_t
     return pl.ws_bytes;
 }
 
-extern "C" int gdn_conv_wgrad(const gdn_conv_geom* g, const float* x, int32_t ldx, int32_t Cx, const float* dy,
+extern "C" int gdn_conv_wgrad(const gdn_conv_geom* g, const void* xv, int32_t ldx, int32_t Cx, const void* dyv,
                               int32_t ldy, float* dw, int32_t ld_dw, int32_t ci_off, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+                              size_t workspace_bytes, int32_t dtypes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    const float *x = (const float*)xv, *dy = (const float*)dyv;
     if (!x || !dy || !dw) return GDN_ERR_BAD_ARG;
     WgradPlan pl;
     if (!make_plan(g, Cx, pl)) return GDN_ERR_UNSUPPORTED;
@@ -491,9 +502,15 @@ extern "C" int gdn_conv_wgrad(const gdn_conv_geom* g, const float* x, int32_t ld
     const bool x_is_g = pl.transpose != 0;   // roles swapped: layer input is the G tensor
     if (x_is_g) { P.g = x; P.ldg = ldx; P.x = dy; P.ldx = ldy; }
     else { P.g = dy; P.ldg = ldy; P.x = x; P.ldx = ldx; }
+    // mixed precision: only the wide (>= 4 channel) tensor of a thin layer may hold bf16
+    if (dtypes) {
+        const int g_bit = x_is_g ? 1 : 2;
+        if (!pl.thin || dtypes != g_bit || (P.ldg % 4)) return GDN_ERR_UNSUPPORTED;
+        P.g_bf16 = 1;
+    }
     P.part = (float*)workspace;
     {
-        const uint64_t gb = (((uint64_t)P.B * P.Hg * P.Wg - 1) * (uint64_t)P.ldg + P.Cg) * 4;
+        const uint64_t gb = (((uint64_t)P.B * P.Hg * P.Wg - 1) * (uint64_t)P.ldg + P.Cg) * (P.g_bf16 ? 2 : 4);
         const uint64_t xb = (((uint64_t)P.B * P.Hx * P.Wx - 1) * (uint64_t)P.ldx + P.Cx) * 4;
         if (gb >= 0xFF000000ull || xb >= 0xFF000000ull) return GDN_ERR_UNSUPPORTED;
         P.g_bytes = (unsigned)gb; P.x_bytes = (unsigned)xb;

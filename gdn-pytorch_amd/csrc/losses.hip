@@ -196,17 +196,17 @@ __global__ __launch_bounds__(256) void smooth_kernel(const float* __restrict__ D
 }
 
 // ------------------------------------------------------------------ MSE
-__global__ __launch_bounds__(256) void sqdiff_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                     int64_t n, double* part) {
+__global__ __launch_bounds__(256) void sqdiff_kernel(const void* __restrict__ a, const void* __restrict__ b,
+                                                     int64_t n, double* part, int dt) {
     __shared__ double sh[4];
     double acc = 0.0;
     const int64_t n4 = n >> 2;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const f32x4 d = reinterpret_cast<const f32x4*>(a)[i] - reinterpret_cast<const f32x4*>(b)[i];
+        const f32x4 d = ld4_any(a, i * 4, dt & 1) - ld4_any(b, i * 4, dt & 2);
         acc += (double)(d[0] * d[0] + d[1] * d[1]) + (double)(d[2] * d[2] + d[3] * d[3]);
     }
     for (int64_t i = (n4 << 2) + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float d = a[i] - b[i];
+        const float d = ld1_any(a, i, dt & 1) - ld1_any(b, i, dt & 2);
         acc += (double)(d * d);
     }
     acc = block_sum_d256(acc, sh);
@@ -272,14 +272,14 @@ extern "C" int gdn_smoothness(const float* depth, const float* img, int32_t Ci, 
     return gdn_launch_status();
 }
 
-extern "C" int gdn_mse(const float* a, const float* b, int64_t n, float weight, int32_t accumulate, float* loss,
-                       void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int gdn_mse(const void* a, const void* b, int64_t n, float weight, int32_t accumulate, float* loss,
+                       void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!a || !b || !loss || n <= 0) return GDN_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gdn_loss_workspace_bytes(0)) return GDN_ERR_WORKSPACE;
     LossWs w = carve(workspace, 0);
     const int nb = loss_blocks(n / 4 + 1);
-    hipLaunchKernelGGL(sqdiff_kernel, dim3(nb), dim3(256), 0, ST(stream), a, b, n, w.part);
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(nb), dim3(256), 0, ST(stream), a, b, n, w.part, dtypes);
     hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)w.part, nb,
                        (double)weight / (double)n, accumulate, loss);
     return gdn_launch_status();

@@ -54,18 +54,18 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     shift[c] = b - rm[c] * g * inv;
 }
 
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int ldy,
+__global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ y, int ldy,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
-                                                       const float* __restrict__ res, int ld_res,
-                                                       float* __restrict__ out, int ld_out, int64_t npix, int C,
-                                                       int relu) {
+                                                       const void* __restrict__ res, int ld_res,
+                                                       void* __restrict__ out, int ld_out, int64_t npix, int C,
+                                                       int relu, int dt) {
     const int cq = C >> 2;
     const int64_t total = npix * cq;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t pix = i / cq;
         const int c = (int)(i - pix * cq) * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(y + pix * ldy + c);
+        const f32x4 v = ld4_any(y, pix * ldy + c, dt & 1);
         const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c);
         const f32x4 t = *reinterpret_cast<const f32x4*>(shift + c);
         f32x4 o = v * s + t;
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
         }
-        if (res) o += *reinterpret_cast<const f32x4*>(res + pix * ld_res + c);
-        *reinterpret_cast<f32x4*>(out + pix * ld_out + c) = o;
+        if (res) o += ld4_any(res, pix * ld_res + c, dt & 2);
+        st4_any(out, pix * ld_out + c, o, dt & 4);
     }
 }
 
@@ -82,9 +82,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 #define BNB_MAXBLK 1024
 // pass 1: partial[blk][2][C] = sum over the block's pixels of dz, dz*xhat
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const float* __restrict__ dout, int ld_dout, const float* __restrict__ y, int ldy,
+    const void* __restrict__ dout, int ld_dout, const void* __restrict__ y, int ldy,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, float* __restrict__ partial, int64_t npix, int C, int relu) {
+    const float* __restrict__ invstd, float* __restrict__ partial, int64_t npix, int C, int relu, int dt) {
     __shared__ float sh[256 * 8];
     const int cq = C >> 2;
     const int CQ = cq < 256 ? cq : 256;      // channel-quad lanes
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
             const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
             for (int64_t pix = p0 + ty; pix < p1; pix += PY) {
-                const f32x4 d = *reinterpret_cast<const f32x4*>(dout + pix * ld_dout + c);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(y + pix * ldy + c);
+                const f32x4 d = ld4_any(dout, pix * ld_dout + c, dt & 1);
+                const f32x4 v = ld4_any(y, pix * ldy + c, dt & 2);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float dz = d[e];
@@ -151,17 +151,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 
 // pass 3: dy = gamma*invstd * (dz - mean(dz) - xhat*mean(dz*xhat))
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const float* __restrict__ dout, int ld_dout, const float* __restrict__ y, int ldy,
+    const void* __restrict__ dout, int ld_dout, const void* __restrict__ y, int ldy,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ k1, const float* __restrict__ k2,
-    float* __restrict__ dy, int ld_dy, int64_t npix, int C, int relu) {
+    void* __restrict__ dy, int ld_dy, int64_t npix, int C, int relu, int dt) {
     const int cq = C >> 2;
     const int64_t total = npix * cq;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t pix = i / cq;
         const int c = (int)(i - pix * cq) * 4;
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dout + pix * ld_dout + c);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(y + pix * ldy + c);
+        const f32x4 d = ld4_any(dout, pix * ld_dout + c, dt & 1);
+        const f32x4 v = ld4_any(y, pix * ldy + c, dt & 2);
         const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c);   // gamma*invstd
         const f32x4 t = *reinterpret_cast<const f32x4*>(shift + c);
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             const float xh = (v[e] - mu[e]) * is[e];
             o[e] = s[e] * (dz - a[e] - xh * b[e]);
         }
-        *reinterpret_cast<f32x4*>(dy + pix * ld_dy + c) = o;
+        st4_any(dy, pix * ld_dy + c, o, dt & 4);
     }
 }
 
@@ -196,8 +196,8 @@ __device__ __forceinline__ void up_src(int o, int in, int align, float& l1, int&
     l1 = src - i0;
 }
 
-__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                             int B, int H, int W, int C, int align) {
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                             int B, int H, int W, int C, int align, int dt) {
     const int cq = C >> 2, Ho = 2 * H, Wo = 2 * W;
     const int64_t total = (int64_t)B * Ho * Wo * cq;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -209,20 +209,20 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
         float ly, lx; int y0, y1, x0, x1;
         up_src(oy, H, align, ly, y0, y1);
         up_src(ox, W, align, lx, x0, x1);
-        const float* xb = x + (size_t)b * H * W * C + c;
-        const f32x4 v00 = *reinterpret_cast<const f32x4*>(xb + ((size_t)y0 * W + x0) * C);
-        const f32x4 v01 = *reinterpret_cast<const f32x4*>(xb + ((size_t)y0 * W + x1) * C);
-        const f32x4 v10 = *reinterpret_cast<const f32x4*>(xb + ((size_t)y1 * W + x0) * C);
-        const f32x4 v11 = *reinterpret_cast<const f32x4*>(xb + ((size_t)y1 * W + x1) * C);
+        const size_t xb = (size_t)b * H * W * C + c;
+        const f32x4 v00 = ld4_any(x, xb + ((size_t)y0 * W + x0) * C, dt & 1);
+        const f32x4 v01 = ld4_any(x, xb + ((size_t)y0 * W + x1) * C, dt & 1);
+        const f32x4 v10 = ld4_any(x, xb + ((size_t)y1 * W + x0) * C, dt & 1);
+        const f32x4 v11 = ld4_any(x, xb + ((size_t)y1 * W + x1) * C, dt & 1);
         const f32x4 o = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-        *reinterpret_cast<f32x4*>(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c) = o;
+        st4_any(y, (((size_t)b * Ho + oy) * Wo + ox) * C + c, o, dt & 2);
     }
 }
 
 // Gather form of the adjoint (deterministic, no atomics): each input pixel sums
 // the <= 6x6 output pixels whose stencil touches it.
-__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
-                                                             int B, int H, int W, int C, int align) {
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const void* __restrict__ dy, void* __restrict__ dx,
+                                                             int B, int H, int W, int C, int align, int dt) {
     const int cq = C >> 2, Ho = 2 * H, Wo = 2 * W;
     const int64_t total = (int64_t)B * H * W * cq;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -249,47 +249,47 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
             for (int jx = 0; jx < 6; ++jx) {
                 if (wx[jx] == 0.f) continue;
                 const int ox = 2 * ix - 2 + jx;
-                s += (wy[jy] * wx[jx]) * *reinterpret_cast<const f32x4*>(dy + (((size_t)b * Ho + oy) * Wo + ox) * C + c);
+                s += (wy[jy] * wx[jx]) * ld4_any(dy, (((size_t)b * Ho + oy) * Wo + ox) * C + c, dt & 1);
             }
         }
-        *reinterpret_cast<f32x4*>(dx + (((size_t)b * H + iy) * W + ix) * C + c) = s;
+        st4_any(dx, (((size_t)b * H + iy) * W + ix) * C + c, s, dt & 2);
     }
 }
 
 // --------------------------------------------------------------------- layouts
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
+__global__ void nchw_to_nhwc_kernel(const void* __restrict__ x, void* __restrict__ y, int B, int C, int HW, int dt) {
     const int64_t total = (int64_t)B * HW * C;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const int64_t t = i / C;
         const int hw = (int)(t % HW);
         const int b = (int)(t / HW);
-        y[i] = x[((size_t)b * C + c) * HW + hw];
+        st1_any(y, i, ld1_any(x, ((size_t)b * C + c) * HW + hw, dt & 1), dt & 2);
     }
 }
-__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
+__global__ void nhwc_to_nchw_kernel(const void* __restrict__ x, void* __restrict__ y, int B, int C, int HW, int dt) {
     const int64_t total = (int64_t)B * HW * C;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int hw = (int)(i % HW);
         const int64_t t = i / HW;
         const int c = (int)(t % C);
         const int b = (int)(t / C);
-        y[i] = x[((size_t)b * HW + hw) * C + c];
+        st1_any(y, i, ld1_any(x, ((size_t)b * HW + hw) * C + c, dt & 1), dt & 2);
     }
 }
 
 // [ntaps][R][C] -> [ntaps][C][R], 32x32 LDS tiles
-__global__ __launch_bounds__(256) void transpose_taps_kernel(const float* __restrict__ w, float* __restrict__ wt,
-                                                             int R, int C) {
+__global__ __launch_bounds__(256) void transpose_taps_kernel(const void* __restrict__ w, void* __restrict__ wt,
+                                                             int R, int C, int dt) {
     __shared__ float tile[32][33];
     const size_t tb = (size_t)blockIdx.z * R * C;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int j = ty; j < 32; j += 8)
-        if (r0 + j < R && c0 + tx < C) tile[j][tx] = w[tb + (size_t)(r0 + j) * C + c0 + tx];
+        if (r0 + j < R && c0 + tx < C) tile[j][tx] = ld1_any(w, tb + (size_t)(r0 + j) * C + c0 + tx, dt & 1);
     __syncthreads();
     for (int j = ty; j < 32; j += 8)
-        if (c0 + j < C && r0 + tx < R) wt[tb + (size_t)(c0 + j) * R + r0 + tx] = tile[tx][j];
+        if (c0 + j < C && r0 + tx < R) st1_any(wt, tb + (size_t)(c0 + j) * R + r0 + tx, tile[tx][j], dt & 2);
 }
 
 // torch [A][Bc][T] <-> tap-major [T][Cout][Cin]
@@ -308,12 +308,19 @@ __global__ void weight_tapmajor_kernel(const float* __restrict__ src, float* __r
 }
 
 // ------------------------------------------------------------------ elementwise
-__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int64_t n) {
+__global__ void add_kernel(const void* __restrict__ a, const void* __restrict__ b, void* __restrict__ o, int64_t n, int dt) {
     const int64_t n4 = n >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
-        reinterpret_cast<f32x4*>(o)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+        st4_any(o, i * 4, ld4_any(a, i * 4, dt & 1) + ld4_any(b, i * 4, dt & 2), dt & 4);
     for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        o[i] = a[i] + b[i];
+        st1_any(o, i, ld1_any(a, i, dt & 1) + ld1_any(b, i, dt & 2), dt & 4);
+}
+__global__ void cast_kernel(const void* __restrict__ a, void* __restrict__ o, int64_t n, int dt) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        st4_any(o, i * 4, ld4_any(a, i * 4, dt & 1), dt & 2);
+    for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        st1_any(o, i, ld1_any(a, i, dt & 1), dt & 2);
 }
 __global__ void tanh_bwd_kernel(const float* __restrict__ d, const float* __restrict__ o, float* __restrict__ r, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -365,14 +372,14 @@ extern "C" int gdn_bn_eval_coeffs(const float* gamma, const float* beta, const f
     return gdn_launch_status();
 }
 
-extern "C" int gdn_bn_apply(const float* y, int32_t ldy, const float* scale, const float* shift, const float* residual,
-                            int32_t ld_res, float* out, int32_t ld_out, int64_t npix, int32_t C, int32_t relu,
-                            void* stream) {
+extern "C" int gdn_bn_apply(const void* y, int32_t ldy, const float* scale, const float* shift, const void* residual,
+                            int32_t ld_res, void* out, int32_t ld_out, int64_t npix, int32_t C, int32_t relu,
+                            int32_t dtypes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!y || !scale || !shift || !out || npix <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     if ((C % 4) || (ldy % 4) || (ld_out % 4) || (residual && (ld_res % 4))) return GDN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, ST(stream), y, ldy, scale,
-                       shift, residual, ld_res, out, ld_out, npix, C, relu);
+                       shift, residual, ld_res, out, ld_out, npix, C, relu, dtypes);
     return gdn_launch_status();
 }
 
@@ -386,10 +393,10 @@ extern "C" size_t gdn_bn_bwd_workspace_bytes(int64_t npix, int32_t C) {
     return ((size_t)bnb_blocks(npix) * 2 * C + 2 * (size_t)C) * sizeof(float);
 }
 
-extern "C" int gdn_bn_bwd(const float* dout, int32_t ld_dout, const float* y, int32_t ldy, const float* gamma,
-                          const float* scale, const float* shift, const float* mean, const float* invstd, float* dy,
+extern "C" int gdn_bn_bwd(const void* dout, int32_t ld_dout, const void* y, int32_t ldy, const float* gamma,
+                          const float* scale, const float* shift, const float* mean, const float* invstd, void* dy,
                           int32_t ld_dy, float* dgamma, float* dbeta, int64_t npix, int32_t C, int32_t relu,
-                          void* workspace, size_t workspace_bytes, void* stream) {
+                          void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     (void)gamma;
     if (!dout || !y || !scale || !shift || !mean || !invstd || !dy || npix <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
@@ -400,55 +407,58 @@ extern "C" int gdn_bn_bwd(const float* dout, int32_t ld_dout, const float* y, in
     float* k1 = partial + (size_t)nblk * 2 * C;
     float* k2 = k1 + C;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, ST(stream), dout, ld_dout, y, ldy, scale, shift,
-                       mean, invstd, partial, npix, C, relu);
+                       mean, invstd, partial, npix, C, relu, dtypes);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, ST(stream), (const float*)partial, nblk, C,
                        (double)npix, dgamma, dbeta, k1, k2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, ST(stream), dout,
                        ld_dout, y, ldy, scale, shift, mean, invstd, (const float*)k1, (const float*)k2, dy, ld_dy, npix,
-                       C, relu);
+                       C, relu, dtypes);
     return gdn_launch_status();
 }
 
-extern "C" int gdn_upsample2x_fwd(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C,
-                                  int32_t align_corners, void* stream) {
+extern "C" int gdn_upsample2x_fwd(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                                  int32_t align_corners, int32_t dtypes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     if (C % 4) return GDN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(stream_blocks((int64_t)B * 4 * H * W * (C / 4))), dim3(256), 0,
-                       ST(stream), x, y, B, H, W, C, align_corners);
+                       ST(stream), x, y, B, H, W, C, align_corners, dtypes);
     return gdn_launch_status();
 }
 
-extern "C" int gdn_upsample2x_bwd(const float* dy, float* dx, int32_t B, int32_t H, int32_t W, int32_t C,
-                                  int32_t align_corners, void* stream) {
+extern "C" int gdn_upsample2x_bwd(const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C,
+                                  int32_t align_corners, int32_t dtypes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     if (C % 4) return GDN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(stream_blocks((int64_t)B * H * W * (C / 4))), dim3(256), 0,
-                       ST(stream), dy, dx, B, H, W, C, align_corners);
+                       ST(stream), dy, dx, B, H, W, C, align_corners, dtypes);
     return gdn_launch_status();
 }
 
-extern "C" int gdn_nchw_to_nhwc(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+extern "C" int gdn_nchw_to_nhwc(const void* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtypes,
+                                void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_blocks((int64_t)B * C * H * W)), dim3(256), 0, ST(stream), x, y,
-                       B, C, H * W);
+                       B, C, H * W, dtypes);
     return gdn_launch_status();
 }
-extern "C" int gdn_nhwc_to_nchw(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+extern "C" int gdn_nhwc_to_nchw(const void* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtypes,
+                                void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(stream_blocks((int64_t)B * C * H * W)), dim3(256), 0, ST(stream), x, y,
-                       B, C, H * W);
+                       B, C, H * W, dtypes);
     return gdn_launch_status();
 }
 
-extern "C" int gdn_transpose_taps(const float* w, float* wt, int32_t ntaps, int32_t R, int32_t C, void* stream) {
+extern "C" int gdn_transpose_taps(const void* w, void* wt, int32_t ntaps, int32_t R, int32_t C, int32_t dtypes,
+                                  void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!w || !wt || ntaps <= 0 || R <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(transpose_taps_kernel, dim3(cdiv(C, 32), cdiv(R, 32), ntaps), dim3(256), 0, ST(stream), w, wt, R,
-                       C);
+                       C, dtypes);
     return gdn_launch_status();
 }
 
@@ -469,10 +479,16 @@ extern "C" int gdn_weight_from_tapmajor(const float* w_tap, float* w_torch, int3
     return gdn_launch_status();
 }
 
-extern "C" int gdn_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+extern "C" int gdn_add(const void* a, const void* b, void* out, int64_t n, int32_t dtypes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!a || !b || !out || n <= 0) return GDN_ERR_BAD_ARG;
-    hipLaunchKernelGGL(add_kernel, dim3(stream_blocks(n / 4 + 1)), dim3(256), 0, ST(stream), a, b, out, n);
+    hipLaunchKernelGGL(add_kernel, dim3(stream_blocks(n / 4 + 1)), dim3(256), 0, ST(stream), a, b, out, n, dtypes);
+    return gdn_launch_status();
+}
+extern "C" int gdn_cast(const void* src, void* dst, int64_t n, int32_t dtypes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    if (!src || !dst || n <= 0) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cast_kernel, dim3(stream_blocks(n / 4 + 1, 256, 4096)), dim3(256), 0, ST(stream), src, dst, n, dtypes);
     return gdn_launch_status();
 }
 extern "C" int gdn_tanh_bwd(const float* dout, const float* out, float* dpre, int64_t n, void* stream) {

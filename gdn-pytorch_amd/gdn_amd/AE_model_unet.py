@@ -27,6 +27,19 @@ def _check_norm(norm):
 class _HipModule(nn.Module):
     """Common boundary: NCHW in, tape-recording autograd bridge, NCHW views out."""
 
+    _gdn_dtype = torch.float32
+
+    def compute_dtype(self, dtype):
+        """Storage dtype of activations / activation gradients: 'fp32' (default, the reference's) or
+        'bf16' (BASELINE configs[2]: bf16 tensors and MFMA operands, fp32 accumulation, fp32 master
+        weights, BatchNorm statistics, losses and optimizer).  Returns self."""
+        table = {"fp32": torch.float32, "float32": torch.float32, torch.float32: torch.float32,
+                 "bf16": torch.bfloat16, "bfloat16": torch.bfloat16, torch.bfloat16: torch.bfloat16}
+        if dtype not in table:
+            raise GdnError("compute_dtype: %r is not one of fp32 / bf16" % (dtype,))
+        self._gdn_dtype = table[dtype]
+        return self
+
     def _run(self, ctx, x):     # x: NHWC buffer -> tuple of NHWC buffers
         raise NotImplementedError
 
@@ -57,8 +70,11 @@ class _Bridge(torch.autograd.Function):
 
     @staticmethod
     def forward(fctx, module, arena, need_grad, select, x, anchor):
-        ctx = E.Ctx(record=need_grad, arena=arena, input_needs_grad=need_grad and x.requires_grad)
+        ctx = E.Ctx(record=need_grad, arena=arena, input_needs_grad=need_grad and x.requires_grad,
+                    dtype=module._gdn_dtype)
         xin = E.to_nhwc(x)
+        if ctx.dtype != xin.dtype and xin.shape[3] % 64 == 0:      # a 64k-channel feature map fed to a bf16 block
+            xin = E.ops.cast(xin.contiguous(), ctx.dtype)
         ctx.input = xin
         outs = module._run(ctx, xin)
         outs = tuple(outs[i] for i in select)
@@ -88,7 +104,7 @@ class _Bridge(torch.autograd.Function):
         dx = None
         if ctx.input_needs_grad:
             g = ctx.pop_grad(ctx.input)
-            dx = None if g is None else E.to_nchw_view(g)
+            dx = None if g is None else E.to_nchw_view(g if g.dtype == torch.float32 else E.ops.cast(g.contiguous(), torch.float32))
         return None, None, None, None, dx, None
 
 

@@ -162,6 +162,7 @@ def broadcast_parameters(model, src=0):
     ar = getattr(model, "_gdn_param_arena", None)
     if ar is not None:
         dist.broadcast(ar.data, src)
+        ar.touch()
     else:
         for p in model.parameters():
             dist.broadcast(p.data, src)

@@ -55,6 +55,8 @@ class ParamArena:
             p.data.copy_(src)
             p._gdn_arena = self
         self.ptr0 = self.items[0][0].data_ptr() if self.items else 0
+        self.generation = 0
+        self.data16, self._key16, self._v16 = None, None, {}
 
     @staticmethod
     def _view(flat, off, shape, tr):
@@ -67,6 +69,33 @@ class ParamArena:
         fwd, inv = _perm(tr)
         phys = [shape[i] for i in fwd]
         return sl.view(phys).permute(*inv)
+
+    def touch(self):
+        """Called by writers that bypass torch (the fused Adam kernel): parameters changed."""
+        self.generation += 1
+
+    def bf16_data(self):
+        """bf16 shadow of the parameter arena (same offsets/layout), re-cast when the master changed."""
+        key = (self.generation, self.data._version)
+        if self.data16 is None:
+            self.data16 = torch.empty(self.numel, dtype=torch.bfloat16, device=self.device)
+            self._key16 = None
+        if self._key16 != key or torch.cuda.is_current_stream_capturing():
+            ops.cast(self.data, out=self.data16)
+            self._key16 = key
+        return self.data16
+
+    def bf16_view(self, p):
+        v = self._v16.get(id(p))
+        if v is None:
+            for q, o, n, tr in self.items:
+                if q is p:
+                    v = self._view(self.bf16_data(), o, p.shape, tr)
+                    self._v16[id(p)] = v
+                    break
+            else:
+                raise KeyError("parameter not in arena")
+        return v
 
     def intact(self):
         return all(p.data_ptr() == self.data.data_ptr() + 4 * o and p.device == self.data.device
@@ -103,8 +132,9 @@ def ensure_arena(module, device):
 # Tape
 # ----------------------------------------------------------------------------
 class Ctx:
-    def __init__(self, record, arena=None, input_needs_grad=False):
+    def __init__(self, record, arena=None, input_needs_grad=False, dtype=torch.float32):
         self.record = record
+        self.dtype = dtype                     # storage dtype of activations / activation gradients
         self.tape = []
         self.arena = arena
         self.grads = {}
@@ -128,7 +158,14 @@ class Ctx:
         if old is None:
             self.grads[k] = (t, g)
         else:
-            self.grads[k] = (t, ops.add(_dense(old[1]), _dense(g)))
+            self.grads[k] = (t, ops.add(_dense(old[1]), _dense(g), out_dtype=t.dtype))
+
+    def pop_grad_as(self, t, dtype):
+        """pop_grad, converted to `dtype` (the head's fp32 input gradient meeting a bf16 consumer)."""
+        g = self.pop_grad(t)
+        if g is not None and g.dtype != dtype:
+            g = ops.cast(_dense(g), dtype)
+        return g
 
     def pop_grad(self, t):
         e = self.grads.pop(id(t), None)
@@ -169,6 +206,25 @@ def _w_tap(mod):
     return v, tr
 
 
+def _w_for(ctx, mod, dtype):
+    """Tap-major weight in the layer's compute dtype (bf16: view into the arena's bf16 shadow)."""
+    w, tr = _w_tap(mod)
+    if dtype == torch.float32:
+        return w, tr
+    if ctx.arena is None:
+        raise GdnError("bf16 compute needs the parameter arena")
+    ctx.arena.bf16_data()                       # refresh the shadow if the master changed
+    v = tap_view(ctx.arena.bf16_view(mod.weight), tr)
+    return v, tr
+
+
+def _layer_dtype(ctx, conv):
+    """bf16 layers need 64-channel reduction slabs; the image-input conv stays fp32."""
+    if ctx.dtype == torch.bfloat16 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0:
+        return torch.bfloat16
+    return torch.float32
+
+
 def _wgrad_into(ctx, mod, x, dy, x2=None):
     """Weight gradient of a conv module straight into its arena slice."""
     op = mod._gdn_op
@@ -196,7 +252,10 @@ def _eval_coeffs(bn):
 def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_dx=True):
     """[relu](BN(conv(cat(x, x2)))) (+ residual): ConvBlock / ResidualBlock halves / ConvTBlock."""
     op = _conv_op(conv, reflect)
-    w, tr = _w_tap(conv)
+    ldt = _layer_dtype(ctx, conv)
+    if x.dtype != ldt:
+        raise GdnError("layer %d->%d computes in %s but its input is %s" % (conv.in_channels, conv.out_channels, ldt, x.dtype))
+    w, tr = _w_for(ctx, conv, ldt)
     if bn.training:
         y, st = op.fwd(x, w, x2=x2, stats=True)
         count = y.shape[0] * y.shape[1] * y.shape[2]
@@ -208,7 +267,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     else:
         y = op.fwd(x, w, x2=x2)
         co = _eval_coeffs(bn)
-    a = ops.bn_apply(y, co[0], co[1], relu, residual)
+    a = ops.bn_apply(y, co[0], co[1], relu, residual, out_dtype=ctx.dtype)
     if ctx.record:
         in_hw = (x.shape[1], x.shape[2])
         bn_training = bn.training
@@ -221,13 +280,13 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                 raise GdnError("backward through eval-mode BatchNorm is not implemented on the HIP path")
             if residual is not None:
                 ctx.add_grad(residual, da)
-            dy = ops.bn_bwd(da, y, bn.weight.data, co, relu, bn.weight.grad, bn.bias.grad)
+            dy = ops.bn_bwd(da, y, bn.weight.data, co, relu, bn.weight.grad, bn.bias.grad, out_dtype=ldt)
             _wgrad_into(ctx, conv, x, dy, x2)
             ctx.grads_done(bn.weight, bn.bias, conv.weight)
             if need_dx and ctx.wants_dx(x):
-                wt = ops.transpose_taps(w)
+                wt = ops.transpose_taps(_w_tap(conv)[0], dtype=ldt)
                 if x2 is None:
-                    dx = op.dgrad(dy, wt, in_hw, addsrc=ctx.pop_grad(x))
+                    dx = op.dgrad(dy, wt, in_hw, addsrc=ctx.pop_grad_as(x, ldt))
                     ctx.grads[id(x)] = (x, dx)
                 else:
                     dcat = op.dgrad(dy, wt, in_hw)
@@ -239,7 +298,8 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
 
 
 def conv_head_tanh(ctx, x, conv):
-    """Final 9x9 (transposed) conv to one channel + tanh (AE_model_unet.py:362-363, :570-571)."""
+    """Final 9x9 (transposed) conv to one channel + tanh (AE_model_unet.py:362-363, :570-571).
+    On the bf16 path only x is bf16: weights, the depth map and this layer's backward are fp32."""
     op = _conv_op(conv, 0)
     w, tr = _w_tap(conv)
     out = op.fwd(x, w, act=ops.ACT_TANH)
@@ -254,7 +314,7 @@ def conv_head_tanh(ctx, x, conv):
             _wgrad_into(ctx, conv, x, dpre)
             ctx.grads_done(conv.weight)
             wt = ops.transpose_taps(w)
-            dx = op.dgrad(dpre, wt, in_hw, addsrc=ctx.pop_grad(x))
+            dx = op.dgrad(dpre, wt, in_hw, addsrc=ctx.pop_grad_as(x, torch.float32))
             ctx.grads[id(x)] = (x, dx)
         ctx.tape.append(bwd)
     return out
@@ -263,7 +323,7 @@ def conv_head_tanh(ctx, x, conv):
 def conv_plain(ctx, x, conv, x2=None):
     """Bare convolution without norm/activation (legacy AutoEncoder 1x1 after cat, :210)."""
     op = _conv_op(conv, 0)
-    w, tr = _w_tap(conv)
+    w, tr = _w_for(ctx, conv, _layer_dtype(ctx, conv))
     y = op.fwd(x, w, x2=x2)
     if ctx.record:
         raise GdnError("legacy AutoEncoder is inference-only on the HIP path")
@@ -310,7 +370,7 @@ def to_nchw_view(t):
 def grad_to_nhwc(g):
     """Incoming NCHW-shaped gradient -> dense NHWC buffer (copy only if the memory order differs)."""
     g = g.detach()
-    if g.dtype != torch.float32:
+    if g.dtype not in (torch.float32, torch.bfloat16):
         g = g.float()
     B, C, H, W = g.shape
     if C == 1:

@@ -30,11 +30,37 @@ def _ld(t):
     return t.stride(-2)
 
 
-def _chk(t, name="tensor"):
-    if t.dtype != torch.float32 or not t.is_cuda:
+def _chk(t, name="tensor", bf16_ok=False):
+    ok = t.dtype == torch.float32 or (bf16_ok and t.dtype == torch.bfloat16)
+    if not ok or not t.is_cuda:
         raise GdnError("%s must be a CUDA/HIP float32 tensor (got %s on %s); the HIP path has no CPU fallback"
                        % (name, t.dtype, t.device))
     return t
+
+
+CFG_BF16 = 0x10000      # GDN_CFG_BF16
+
+
+def _bf(t):
+    """dtype-mask bit of a tensor argument: 1 for bfloat16, 0 for float32 / None."""
+    if t is None or t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise GdnError("unsupported dtype %s (float32 or bfloat16)" % t.dtype)
+
+
+def _mask(*ts):
+    m = 0
+    for i, t in enumerate(ts):
+        m |= _bf(t) << i
+    return m
+
+
+def _same_dtype(ref, *others):
+    for o in others:
+        if o is not None and o.dtype != ref.dtype:
+            raise GdnError("mixed dtypes in one conv call: %s vs %s" % (ref.dtype, o.dtype))
 
 
 _ws_cache = {}
@@ -79,13 +105,24 @@ class Conv:
 
     def fwd(self, x, w_tap, x2=None, stats=False, act=ACT_NONE, addsrc=None, tile_cfg=0, out=None, stats_out=None):
         """y = conv(cat(x, x2)); returns y, or (y, stats_partials) when stats."""
-        _chk(x, "x")
+        _chk(x, "x", bf16_ok=True)
+        bf = x.dtype == torch.bfloat16
+        head_mixed = bf and self.cout == 1       # 1-channel heads: bf16 x, fp32 weights and depth map
+        if head_mixed:
+            _chk(w_tap, "head weight")
+            if x2 is not None or addsrc is not None or stats:
+                raise GdnError("the bf16 head takes no concat / addsrc / stats")
+        else:
+            _same_dtype(x, x2, w_tap, addsrc, out)
+        if bf:
+            tile_cfg |= CFG_BF16
         B, H, W, C1 = x.shape
         _, ref, Ho, Wo = self.geom(B, H, W)
         c2 = 0 if x2 is None else x2.shape[3]
         if C1 + c2 != self.cin:
             raise GdnError("conv expects %d input channels, got %d" % (self.cin, C1 + c2))
-        y = out if out is not None else torch.empty((B, Ho, Wo, self.cout), dtype=torch.float32, device=x.device)
+        y = out if out is not None else torch.empty((B, Ho, Wo, self.cout),
+                                                    dtype=torch.float32 if head_mixed else x.dtype, device=x.device)
         st = None
         if stats:
             st = stats_out
@@ -109,37 +146,61 @@ class Conv:
 
     def dgrad(self, dy, wt_tap, in_hw, addsrc=None, tile_cfg=0):
         """dx = dgrad(dy) (+ addsrc).  wt_tap: [k*k, Cin, Cout]; in_hw: layer input (H, W)."""
-        _chk(dy, "dy")
+        _chk(dy, "dy", bf16_ok=True)
+        _same_dtype(dy, wt_tap, addsrc)
+        if dy.dtype == torch.bfloat16:
+            tile_cfg |= CFG_BF16
         B = dy.shape[0]
         H, W = in_hw
         _, ref, Ho, Wo = self.geom(B, H, W)
         if tuple(dy.shape[1:]) != (Ho, Wo, self.cout):
             raise GdnError("dgrad: dy shape %s does not match layer output (%d,%d,%d)" % (tuple(dy.shape), Ho, Wo, self.cout))
-        dx = torch.empty((B, H, W, self.cin), dtype=torch.float32, device=dy.device)
+        dx = torch.empty((B, H, W, self.cin), dtype=dy.dtype, device=dy.device)
         nb = int(lib.gdn_conv_dgrad_workspace_bytes(ref, tile_cfg))
         ws = workspace(nb, dy.device, "dgrad") if nb else None
         lib.gdn_conv_dgrad(ref, _p(dy), _ld(dy), _p(wt_tap), _p(dx), _ld(dx), _p(addsrc),
                            0 if addsrc is None else _ld(addsrc), _p(ws), nb, tile_cfg, stream())
         return dx
 
-    def wgrad(self, x, dy, dw_tap, ci_off=0):
-        """dw_tap[tap][co][ci_off + ci] = wgrad over the channel slice x (Cx = x.shape[3])."""
-        _chk(x, "x")
+    def wgrad(self, x, dy, dw_tap, ci_off=0, cfg=0):
+        """dw_tap[tap][co][ci_off + ci] = wgrad over the channel slice x (Cx = x.shape[3]).
+        bf16 x/dy take the bf16 MFMA kernel; dw_tap is fp32 either way."""
+        _chk(x, "x", bf16_ok=True)
+        _chk(dy, "dy", bf16_ok=True)
+        _chk(dw_tap, "dw")
         B, H, W, Cx = x.shape
         _, ref, _, _ = self.geom(B, H, W)
+        if x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16:
+            nb = int(lib.gdn_conv_wgrad_bf16_workspace_bytes(ref, Cx, cfg))
+            if nb == 0:
+                raise GdnError("bf16 wgrad: unsupported geometry k=%d stride=%d Cx=%d Cout=%d" % (self.k, self.stride, Cx, self.cout))
+            ws = workspace(nb, x.device, "wgrad")
+            lib.gdn_conv_wgrad_bf16(ref, _p(x), _ld(x), Cx, _p(dy), _ld(dy), _p(dw_tap), self.cin, ci_off, _p(ws), nb, cfg,
+                                    stream())
+            return
         nb = int(lib.gdn_conv_wgrad_workspace_bytes(ref, Cx))
         if nb == 0:
             raise GdnError("wgrad: unsupported geometry k=%d stride=%d Cx=%d" % (self.k, self.stride, Cx))
         ws = workspace(nb, x.device, "wgrad")
-        lib.gdn_conv_wgrad(ref, _p(x), _ld(x), Cx, _p(dy), _ld(dy), _p(dw_tap), self.cin, ci_off, _p(ws), nb, stream())
+        lib.gdn_conv_wgrad(ref, _p(x), _ld(x), Cx, _p(dy), _ld(dy), _p(dw_tap), self.cin, ci_off, _p(ws), nb,
+                           _mask(x, dy), stream())
 
 
-def transpose_taps(w_tap, out=None):
-    """[T, R, C] -> [T, C, R]"""
+def transpose_taps(w_tap, out=None, dtype=None):
+    """[T, R, C] -> [T, C, R]; dtype (or out.dtype) may differ from w_tap's: fp32 master -> bf16 copy."""
     T, R, C = w_tap.shape
-    wt = out if out is not None else torch.empty((T, C, R), dtype=torch.float32, device=w_tap.device)
-    lib.gdn_transpose_taps(_p(w_tap), _p(wt), T, R, C, stream())
+    wt = out if out is not None else torch.empty((T, C, R), dtype=dtype or w_tap.dtype, device=w_tap.device)
+    lib.gdn_transpose_taps(_p(w_tap), _p(wt), T, R, C, _mask(w_tap, wt), stream())
     return wt
+
+
+def cast(src, dtype=None, out=None):
+    """Dense dtype conversion fp32 <-> bf16 (one streaming kernel)."""
+    if not src.is_contiguous():
+        raise GdnError("cast needs a dense tensor")
+    dst = out if out is not None else torch.empty(src.shape, dtype=dtype, device=src.device)
+    lib.gdn_cast(_p(src), _p(dst), src.numel(), _mask(src, dst), stream())
+    return dst
 
 
 def weight_to_tapmajor(w, transposed):
@@ -174,23 +235,24 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=BN_EPS):
     return co
 
 
-def bn_apply(y, scale, shift, relu, residual=None, out=None):
+def bn_apply(y, scale, shift, relu, residual=None, out=None, out_dtype=None):
     B, H, W, C = y.shape
-    o = out if out is not None else torch.empty((B, H, W, C), dtype=torch.float32, device=y.device)
+    o = out if out is not None else torch.empty((B, H, W, C), dtype=out_dtype or y.dtype, device=y.device)
     lib.gdn_bn_apply(_p(y), _ld(y), _p(scale), _p(shift), _p(residual), 0 if residual is None else _ld(residual),
-                     _p(o), _ld(o), B * H * W, C, 1 if relu else 0, stream())
+                     _p(o), _ld(o), B * H * W, C, 1 if relu else 0, _mask(y, residual, o), stream())
     return o
 
 
-def bn_bwd(dout, y, gamma, coeffs, relu, dgamma, dbeta):
+def bn_bwd(dout, y, gamma, coeffs, relu, dgamma, dbeta, out_dtype=None):
     """coeffs = [scale, shift, mean, invstd] from bn_finalize_train. Returns dy."""
     B, H, W, C = y.shape
     npix = B * H * W
-    dy = torch.empty((B, H, W, C), dtype=torch.float32, device=y.device)
+    dy = torch.empty((B, H, W, C), dtype=out_dtype or y.dtype, device=y.device)
     nb = int(lib.gdn_bn_bwd_workspace_bytes(npix, C))
     ws = workspace(nb, y.device, "bnbwd")
     lib.gdn_bn_bwd(_p(dout), _ld(dout), _p(y), _ld(y), _p(gamma), _p(coeffs[0]), _p(coeffs[1]), _p(coeffs[2]),
-                   _p(coeffs[3]), _p(dy), _ld(dy), _p(dgamma), _p(dbeta), npix, C, 1 if relu else 0, _p(ws), nb, stream())
+                   _p(coeffs[3]), _p(dy), _ld(dy), _p(dgamma), _p(dbeta), npix, C, 1 if relu else 0, _p(ws), nb,
+                   _mask(dout, y, dy), stream())
     return dy
 
 
@@ -198,8 +260,8 @@ def upsample2x(x, align_corners=False):
     B, H, W, C = x.shape
     if not x.is_contiguous():
         raise GdnError("upsample2x needs a dense NHWC tensor")
-    y = torch.empty((B, 2 * H, 2 * W, C), dtype=torch.float32, device=x.device)
-    lib.gdn_upsample2x_fwd(_p(x), _p(y), B, H, W, C, 1 if align_corners else 0, stream())
+    y = torch.empty((B, 2 * H, 2 * W, C), dtype=x.dtype, device=x.device)
+    lib.gdn_upsample2x_fwd(_p(x), _p(y), B, H, W, C, 1 if align_corners else 0, _mask(x, y), stream())
     return y
 
 
@@ -207,30 +269,30 @@ def upsample2x_bwd(dy, align_corners=False):
     B, H2, W2, C = dy.shape
     if not dy.is_contiguous():
         raise GdnError("upsample2x_bwd needs a dense NHWC tensor")
-    dx = torch.empty((B, H2 // 2, W2 // 2, C), dtype=torch.float32, device=dy.device)
-    lib.gdn_upsample2x_bwd(_p(dy), _p(dx), B, H2 // 2, W2 // 2, C, 1 if align_corners else 0, stream())
+    dx = torch.empty((B, H2 // 2, W2 // 2, C), dtype=dy.dtype, device=dy.device)
+    lib.gdn_upsample2x_bwd(_p(dy), _p(dx), B, H2 // 2, W2 // 2, C, 1 if align_corners else 0, _mask(dy, dx), stream())
     return dx
 
 
-def nchw_to_nhwc(x):
+def nchw_to_nhwc(x, dtype=None):
     B, C, H, W = x.shape
-    y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
-    lib.gdn_nchw_to_nhwc(_p(x), _p(y), B, C, H, W, stream())
+    y = torch.empty((B, H, W, C), dtype=dtype or x.dtype, device=x.device)
+    lib.gdn_nchw_to_nhwc(_p(x), _p(y), B, C, H, W, _mask(x, y), stream())
     return y
 
 
-def nhwc_to_nchw(x):
+def nhwc_to_nchw(x, dtype=None):
     B, H, W, C = x.shape
-    y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
-    lib.gdn_nhwc_to_nchw(_p(x), _p(y), B, C, H, W, stream())
+    y = torch.empty((B, C, H, W), dtype=dtype or x.dtype, device=x.device)
+    lib.gdn_nhwc_to_nchw(_p(x), _p(y), B, C, H, W, _mask(x, y), stream())
     return y
 
 
-def add(a, b):
+def add(a, b, out_dtype=None):
     if not (a.is_contiguous() and b.is_contiguous()):
         raise GdnError("add needs dense tensors")
-    o = torch.empty_like(a)
-    lib.gdn_add(_p(a), _p(b), _p(o), a.numel(), stream())
+    o = torch.empty(a.shape, dtype=out_dtype or a.dtype, device=a.device)
+    lib.gdn_add(_p(a), _p(b), _p(o), a.numel(), _mask(a, b, o), stream())
     return o
 
 
@@ -277,7 +339,7 @@ def smoothness(depth, img, ddepth, loss):
 
 def mse_accum(a, b, weight, loss, accumulate):
     ws, nb = _loss_ws(0, a.device)
-    lib.gdn_mse(_p(a), _p(b), a.numel(), float(weight), 1 if accumulate else 0, _p(loss), _p(ws), nb, stream())
+    lib.gdn_mse(_p(a), _p(b), a.numel(), float(weight), 1 if accumulate else 0, _p(loss), _p(ws), nb, _mask(a, b), stream())
 
 
 def depth_metrics(gt_sparse, gt, pred, crop=True):

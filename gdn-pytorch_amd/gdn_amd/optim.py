@@ -51,6 +51,7 @@ class Adam(torch.optim.Optimizer):
                 st["step"] += 1
                 ops.adam_step(ar.data, ar.grad, st["m"], st["v"], group["lr"], b1, b2, group["eps"],
                               group["weight_decay"], st["step"], self.grad_scale)
+                ar.touch()        # the kernel wrote the parameters behind torch's back: bf16 shadows are stale
             for p in loose:
                 if p.grad is None:
                     continue
@@ -67,4 +68,6 @@ class Adam(torch.optim.Optimizer):
                     g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
                 ops.adam_step(p.data, g, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"],
                               st["step"], self.grad_scale)
+                if getattr(p, "_gdn_arena", None) is not None:
+                    p._gdn_arena.touch()
         return loss

@@ -62,6 +62,15 @@ typedef struct {
 
 enum { GDN_ACT_NONE = 0, GDN_ACT_TANH = 1 };
 
+/* tile_cfg flag bits shared by the conv entry points (low byte: tile id, 0 = automatic).
+ * GDN_CFG_BF16: x/x2/w/y/addsrc (dy/wt/dx for dgrad) hold bfloat16 instead of float
+ * (BASELINE configs[2]); accumulation, BatchNorm statistics and split-K partials stay fp32.
+ * Needs Cin, C1 (dgrad: Cout) multiples of 64 and pixel pitches multiples of 8.
+ * Exception: the 1-channel 9x9 heads (Cout == 1) take a bf16 x but fp32 weights and write an
+ * fp32 depth map; their backward runs through the fp32 entry points.
+ * The workspace/slot queries must be given the same tile_cfg as the launch. */
+enum { GDN_CFG_KC64 = 0x200, GDN_CFG_NO_SPLITK = 0x800, GDN_CFG_BF16 = 0x10000 };
+
 /* Output spatial dims of the layer. */
 int gdn_conv_out_dims(const gdn_conv_geom* g, int32_t* Ho, int32_t* Wo);
 
@@ -82,12 +91,13 @@ int64_t gdn_conv_stats_slots(const gdn_conv_geom* g, int32_t tile_cfg);
  * their partial sums live in `workspace` (gdn_conv_fwd_workspace_bytes, 0 when
  * no split is planned) and are combined -- with the same fusions -- by a second
  * kernel inside the call.
- * tile_cfg: 0 = automatic; >0 forces a tile configuration (tuning/testing). */
+ * tile_cfg: 0 = automatic; low byte >0 forces a tile configuration (tuning/testing);
+ * flag bits above.  x, x2, w, y, addsrc: float (default) or bfloat16 (GDN_CFG_BF16). */
 size_t gdn_conv_fwd_workspace_bytes(const gdn_conv_geom* g, int32_t tile_cfg);
 int gdn_conv_fwd(const gdn_conv_geom* g,
-                 const float* x, int32_t ldx, const float* x2, int32_t ldx2, int32_t C1,
-                 const float* w, float* y, int32_t ldy,
-                 const float* addsrc, int32_t ld_add,
+                 const void* x, int32_t ldx, const void* x2, int32_t ldx2, int32_t C1,
+                 const void* w, void* y, int32_t ldy,
+                 const void* addsrc, int32_t ld_add,
                  float* stats, int32_t act, int32_t tile_cfg,
                  void* workspace, size_t workspace_bytes, void* stream);
 
@@ -97,24 +107,42 @@ int gdn_conv_fwd(const gdn_conv_geom* g,
  * Reflection-padded layers need a workspace for the gradient on the padded
  * domain, folded back onto dx inside the call. */
 size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g, int32_t tile_cfg);
-int gdn_conv_dgrad(const gdn_conv_geom* g, const float* dy, int32_t ldy,
-                   const float* wt, float* dx, int32_t ldx,
-                   const float* addsrc, int32_t ld_add,
+int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dy, int32_t ldy,
+                   const void* wt, void* dx, int32_t ldx,
+                   const void* addsrc, int32_t ld_add,
                    void* workspace, size_t workspace_bytes, int32_t tile_cfg, void* stream);
 
 /* Weight gradient (same call sites).  x is the layer input ([B,H,W], channel
  * slice [0,Cx) of width ldx), dy the output gradient.  Writes
  * dw[tap][co][ci_off + ci] for ci in [0,Cx), with row stride ld_dw (= total
  * Cin), so the two halves of a concat 1x1 conv are two calls.  Deterministic:
- * split-K partial slabs in `workspace` are summed in a fixed order. */
+ * split-K partial slabs in `workspace` are summed in a fixed order.
+ * dtypes (bit0 x, bit1 dy): 0 = fp32.  On the mixed-precision path the layers with a 1-3 channel
+ * tensor (image-input conv, 64->1 heads) keep that tensor in fp32 and may pass the wide one as bf16. */
 size_t gdn_conv_wgrad_workspace_bytes(const gdn_conv_geom* g, int32_t Cx);
-int gdn_conv_wgrad(const gdn_conv_geom* g, const float* x, int32_t ldx, int32_t Cx,
-                   const float* dy, int32_t ldy,
+int gdn_conv_wgrad(const gdn_conv_geom* g, const void* x, int32_t ldx, int32_t Cx,
+                   const void* dy, int32_t ldy,
                    float* dw, int32_t ld_dw, int32_t ci_off,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream);
 
-/* [ntaps][R][C] -> [ntaps][C][R] */
-int gdn_transpose_taps(const float* w, float* wt, int32_t ntaps, int32_t R, int32_t C, void* stream);
+/* bf16 weight gradient (BASELINE configs[2]): x and dy hold bfloat16, dw is fp32 (the master
+ * gradient arena).  Same contract as gdn_conv_wgrad otherwise.  Needs Cx and Cout multiples of
+ * 64, pixel pitches multiples of 8 and 16-byte aligned bases.  cfg: 0 automatic, 1/2 force the
+ * small/large staging class (tuning).  v_mfma_f32_32x32x16_bf16 fed by ds_read_b64_tr_b16. */
+size_t gdn_conv_wgrad_bf16_workspace_bytes(const gdn_conv_geom* g, int32_t Cx, int32_t cfg);
+int gdn_conv_wgrad_bf16(const gdn_conv_geom* g, const void* x, int32_t ldx, int32_t Cx,
+                        const void* dy, int32_t ldy,
+                        float* dw, int32_t ld_dw, int32_t ci_off,
+                        void* workspace, size_t workspace_bytes, int32_t cfg, void* stream);
+
+/* `dtypes` of the element-wise entry points below: bit i set = the i-th ACTIVATION-type tensor argument
+ * (in argument order, NULL-able ones included) holds bfloat16 instead of float; 0 = all fp32.
+ * Per-channel coefficient vectors, statistics, parameter gradients and scalars are always fp32. */
+
+/* [ntaps][R][C] -> [ntaps][C][R].  dtypes: bit0 w, bit1 wt (fp32 -> bf16 transposed copy in one pass). */
+int gdn_transpose_taps(const void* w, void* wt, int32_t ntaps, int32_t R, int32_t C, int32_t dtypes, void* stream);
+/* dst[i] = src[i] with dtype conversion.  dtypes: bit0 src, bit1 dst. */
+int gdn_cast(const void* src, void* dst, int64_t n, int32_t dtypes, void* stream);
 /* torch layout [A][Bc][ntaps] (Conv2d weight [Cout][Cin][kh][kw], or ConvTranspose2d
  * weight [Cin][Cout][kh][kw]) <-> tap-major [ntaps][Cout][Cin].  a_is_cout selects
  * which of the two leading torch dims is Cout. */
@@ -138,36 +166,39 @@ int gdn_bn_finalize_train(const float* stats, int64_t slots, int32_t C, int64_t 
 int gdn_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, int32_t C,
                        float* scale, float* shift, void* stream);
-/* out = [relu](y*scale[c] + shift[c]) (+ residual).  npix pixels of C channels. */
-int gdn_bn_apply(const float* y, int32_t ldy, const float* scale, const float* shift,
-                 const float* residual, int32_t ld_res, float* out, int32_t ld_out,
-                 int64_t npix, int32_t C, int32_t relu, void* stream);
+/* out = [relu](y*scale[c] + shift[c]) (+ residual).  npix pixels of C channels.
+ * dtypes: bit0 y, bit1 residual, bit2 out. */
+int gdn_bn_apply(const void* y, int32_t ldy, const float* scale, const float* shift,
+                 const void* residual, int32_t ld_res, void* out, int32_t ld_out,
+                 int64_t npix, int32_t C, int32_t relu, int32_t dtypes, void* stream);
 /* Backward of out = [relu](BN_train(y)):
  *   pass 1 (reduce): per-channel sum(dz), sum(dz*xhat) with dz = dout*[z>0];
  *   pass 2 (apply) : dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)),
  *                    dgamma = sum(dz*xhat), dbeta = sum(dz).
- * Both passes inside one call; workspace from gdn_bn_bwd_workspace_bytes. */
+ * Both passes inside one call; workspace from gdn_bn_bwd_workspace_bytes.
+ * dtypes: bit0 dout, bit1 y, bit2 dy. */
 size_t gdn_bn_bwd_workspace_bytes(int64_t npix, int32_t C);
-int gdn_bn_bwd(const float* dout, int32_t ld_dout, const float* y, int32_t ldy,
+int gdn_bn_bwd(const void* dout, int32_t ld_dout, const void* y, int32_t ldy,
                const float* gamma, const float* scale, const float* shift,
                const float* mean, const float* invstd,
-               float* dy, int32_t ld_dy, float* dgamma, float* dbeta,
+               void* dy, int32_t ld_dy, float* dgamma, float* dbeta,
                int64_t npix, int32_t C, int32_t relu,
-               void* workspace, size_t workspace_bytes, void* stream);
+               void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream);
 
 /* ------------------------------------------------------------------------
  * x2 bilinear up-sampling: F.interpolate(align_corners=False) AE_model_unet.py:336,343,349,355
  * and nn.Upsample(align_corners=True) :135,203,215,227.  NHWC, C channels.
  * ---------------------------------------------------------------------- */
-int gdn_upsample2x_fwd(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C,
-                       int32_t align_corners, void* stream);
-int gdn_upsample2x_bwd(const float* dy, float* dx, int32_t B, int32_t H, int32_t W, int32_t C,
-                       int32_t align_corners, void* stream);
+/* dtypes: bit0 input, bit1 output. */
+int gdn_upsample2x_fwd(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                       int32_t align_corners, int32_t dtypes, void* stream);
+int gdn_upsample2x_bwd(const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C,
+                       int32_t align_corners, int32_t dtypes, void* stream);
 
-/* Layout and small element-wise helpers. */
-int gdn_nchw_to_nhwc(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
-int gdn_nhwc_to_nchw(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
-int gdn_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* Layout and small element-wise helpers.  dtypes: bit0 x, bit1 y (gdn_add: bit0 a, bit1 b, bit2 out). */
+int gdn_nchw_to_nhwc(const void* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtypes, void* stream);
+int gdn_nhwc_to_nchw(const void* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtypes, void* stream);
+int gdn_add(const void* a, const void* b, void* out, int64_t n, int32_t dtypes, void* stream);
 /* dpre = dout * (1 - out^2): backward of x15.tanh() (AE_model_unet.py:363,571). */
 int gdn_tanh_bwd(const float* dout, const float* out, float* dpre, int64_t n, void* stream);
 int gdn_fill(float* p, float value, int64_t n, void* stream);
@@ -192,9 +223,9 @@ int gdn_sobel_l1(const float* pred, const float* gt, int32_t B, int32_t H, int32
 int gdn_smoothness(const float* depth, const float* img, int32_t Ci, int32_t B, int32_t H, int32_t W,
                    float* loss, float* ddepth, void* workspace, size_t workspace_bytes, void* stream);
 /* loss_accum (+)= weight * mean((a-b)^2): the latent MSE terms, trainer.py:728-733
- * (value only, F3).  accumulate != 0 adds to the existing *loss. */
-int gdn_mse(const float* a, const float* b, int64_t n, float weight, int32_t accumulate,
-            float* loss, void* workspace, size_t workspace_bytes, void* stream);
+ * (value only, F3).  accumulate != 0 adds to the existing *loss.  dtypes: bit0 a, bit1 b. */
+int gdn_mse(const void* a, const void* b, int64_t n, float weight, int32_t accumulate,
+            float* loss, void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Depth metrics, calculate_error.py:10-103: per image min-max -> x80, Godard

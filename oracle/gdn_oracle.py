@@ -167,6 +167,64 @@ def init_state_dict(model, seed=None, input_dim=None):
 # Blocks
 # ----------------------------------------------------------------------------
 
+# bf16 emulation (BASELINE configs[2]): the SAME fp32 arithmetic with every tensor the HIP bf16 path
+# stores as bfloat16 rounded at the point it is stored -- conv outputs, BN/ReLU(+residual) outputs,
+# up-sampling outputs, the bf16 copies of the weights -- and, in backward, the gradient flowing
+# through each of those points.  Layers the HIP path keeps in fp32 (a conv whose Cin or Cout is not a
+# multiple of 64: the image-input conv and the 64->1 head) are left alone.  This is the reference
+# for the bf16 parity tests: bf16 against fp32 is dominated by the networks' sensitivity to rounding
+# (see DESIGN.md), bf16 against this emulation isolates the implementation.
+_EMU_BF16 = False
+
+
+class bf16_emulation:
+    def __enter__(self):
+        global _EMU_BF16
+        self._old, _EMU_BF16 = _EMU_BF16, True
+        return self
+
+    def __exit__(self, *a):
+        global _EMU_BF16
+        _EMU_BF16 = self._old
+
+
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+class _RoundFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g            # master weights and their gradients stay fp32
+
+
+def _q(x):
+    return _RoundBF16.apply(x) if _EMU_BF16 else x
+
+
+def _bf16_layer(w, transposed=False):
+    return _EMU_BF16 and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
+
+
+def _conv(x, w, stride, pad, transposed=False):
+    """Convolution as the HIP path runs it: bf16 operands + bf16-stored result when the layer is a bf16 layer."""
+    bf = _bf16_layer(w)
+    if bf:
+        w = _RoundFwd.apply(w)
+    y = F.conv_transpose2d(x, w, None, stride, pad) if transposed else F.conv2d(x, w, None, stride, pad)
+    return _q(y) if bf else y
+
+
 def _bn(x, sd, key, training):
     """nn.BatchNorm2d(affine, track_running_stats) -- AE_model_unet.py:51,54,68,86."""
     nbt = sd.get(key + ".num_batches_tracked")
@@ -180,23 +238,23 @@ def conv_block(x, sd, name, k, stride, pad, training):
     """ConvBlock: ReflectionPad -> Conv(pad 0, no bias) -> BN -> ReLU. AE_model_unet.py:60-77."""
     if pad:
         x = F.pad(x, (pad, pad, pad, pad), mode="reflect")
-    y = F.conv2d(x, sd[name + ".main.1.weight"], None, stride, 0)
-    return F.relu(_bn(y, sd, name + ".main.2", training))
+    y = _conv(x, sd[name + ".main.1.weight"], stride, 0)
+    return _q(F.relu(_bn(y, sd, name + ".main.2", training)))
 
 
 def convt_block(x, sd, name, k, stride, pad, training):
     """ConvTBlock: ConvTranspose2d -> BN -> ReLU. AE_model_unet.py:79-94."""
-    y = F.conv_transpose2d(x, sd[name + ".main.0.weight"], None, stride, pad)
-    return F.relu(_bn(y, sd, name + ".main.1", training))
+    y = _conv(x, sd[name + ".main.0.weight"], stride, pad, transposed=True)
+    return _q(F.relu(_bn(y, sd, name + ".main.1", training)))
 
 
 def residual_block(x, sd, name, k, pad, training):
     """ResidualBlock: x + BN(Conv(ReLU(BN(Conv x)))), zero pad, no post-add act. AE_model_unet.py:45-57."""
-    y = F.conv2d(x, sd[name + ".main.0.weight"], None, 1, pad)
-    y = F.relu(_bn(y, sd, name + ".main.1", training))
-    y = F.conv2d(y, sd[name + ".main.3.weight"], None, 1, pad)
+    y = _conv(x, sd[name + ".main.0.weight"], 1, pad)
+    y = _q(F.relu(_bn(y, sd, name + ".main.1", training)))
+    y = _conv(y, sd[name + ".main.3.weight"], 1, pad)
     y = _bn(y, sd, name + ".main.4", training)
-    return x + y
+    return _q(x + y)
 
 
 _RB = {"res64": (9, 4), "res128": (7, 3), "res256": (5, 2), "res512": (3, 1)}
@@ -209,12 +267,12 @@ def _rb(x, sd, name, training):
 
 def _up_ac0(x):
     """F.interpolate(scale_factor=2, bilinear, align_corners=False). AE_model_unet.py:336."""
-    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    return _q(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False))
 
 
 def _up_ac1(x):
     """nn.Upsample(scale_factor=2, bilinear, align_corners=True). AE_model_unet.py:135."""
-    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    return _q(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True))
 
 
 # ----------------------------------------------------------------------------
@@ -301,11 +359,11 @@ def forward_legacy(sd, x, istrain=True, training=False, height=None, width=None)
     t = training
 
     def cbr(v, conv, bn, stride, pad):
-        return F.relu(_bn(F.conv2d(v, sd[conv + ".weight"], None, stride, pad), sd, bn, t))
+        return _q(F.relu(_bn(_conv(v, sd[conv + ".weight"], stride, pad), sd, bn, t)))
 
     def up(v, convt, bn, pad):
-        y = F.conv_transpose2d(_up_ac1(v), sd[convt + ".weight"], None, 1, pad)
-        return F.relu(_bn(y, sd, bn, t))
+        y = _conv(_up_ac1(v), sd[convt + ".weight"], 1, pad, transposed=True)
+        return _q(F.relu(_bn(y, sd, bn, t)))
 
     x3 = cbr(x, "downconv0", "N64_down", 1, 4)
     x5 = _rb(_rb(x3, sd, "res64_down1", t), sd, "res64_down2", t)
@@ -318,13 +376,13 @@ def forward_legacy(sd, x, istrain=True, training=False, height=None, width=None)
     for i in range(1, 7):
         x23 = _rb(x23, sd, "res512_%d" % i, t)
     x27 = up(x23, "upconv0", "N256_up", 1)
-    x27 = F.conv2d(torch.cat((x27, x15), 1), sd["conv1x1_256.weight"])
+    x27 = _conv(torch.cat((x27, x15), 1), sd["conv1x1_256.weight"], 1, 0)
     x29 = _rb(_rb(x27, sd, "res256_up1", t), sd, "res256_up2", t)
     x33 = up(x29, "upconv1", "N128_up", 2)
-    x33 = F.conv2d(torch.cat((x33, x10), 1), sd["conv1x1_128.weight"])
+    x33 = _conv(torch.cat((x33, x10), 1), sd["conv1x1_128.weight"], 1, 0)
     x35 = _rb(_rb(x33, sd, "res128_up1", t), sd, "res128_up2", t)
     x39 = up(x35, "upconv2", "N64_up", 3)
-    x39 = F.conv2d(torch.cat((x39, x5), 1), sd["conv1x1_64.weight"])
+    x39 = _conv(torch.cat((x39, x5), 1), sd["conv1x1_64.weight"], 1, 0)
     x41 = _rb(_rb(x39, sd, "res64_up1", t), sd, "res64_up2", t)
     x44 = F.conv2d(x41, sd["upconv3.weight"], None, 1, 4).tanh().clone().view(-1, 1, H, W)
     if istrain is True:

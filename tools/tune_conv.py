@@ -9,7 +9,9 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "gdn-pytorch_amd"))
 import torch
 from gdn_amd import ops
 
+import os
 dev = torch.device("cuda:0")
+BF16 = os.environ.get("GDN_TUNE_BF16", "0") == "1"     # time the bf16 fwd/dgrad kernels (wgrad stays fp32)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 # (name, Cin, Cout, k, s, p, reflect, transposed, H, W)  -- H, W = layer input
 L = [(128, 416), (64, 208), (32, 104), (16, 52), (8, 26)]
@@ -66,6 +68,11 @@ for (name, ci, co, k, s, p, refl, tr, H, W) in SHAPES:
     x = torch.randn(B, H, W, ci, device=dev)
     w = torch.randn(k * k, co, ci, device=dev) * 0.02
     wt = ops.transpose_taps(w)
+    if BF16 and (ci % 64 or co % 64):
+        continue
+    xf, gyf_src = x, None
+    if BF16:
+        x, w, wt = x.bfloat16(), w.bfloat16(), wt.bfloat16()
     y = op.fwd(x, w)
     gy = torch.randn_like(y)
     Ho, Wo = y.shape[1], y.shape[2]
@@ -82,6 +89,17 @@ for (name, ci, co, k, s, p, refl, tr, H, W) in SHAPES:
         for c in dcfgs:
             ms = timeit(lambda: op.dgrad(gy, wt, (H, W), tile_cfg=c))
             dg.append(gf / ms)
+    if BF16:
+        dw = torch.empty(w.shape, device=dev)
+        wg = []
+        for c in (0, 1):
+            try:
+                wg.append(gf / timeit(lambda: op.wgrad(x, gy, dw, cfg=c), reps=3))
+            except Exception:
+                wg.append(0.0)
+        print("%-16s %9.1f | %-32s | %-32s | %s" % (name, gf, " ".join("%6.1f" % v for v in fw),
+                                                    " ".join("%6.1f" % v for v in dg), " ".join("%6.1f" % v for v in wg)))
+        continue
     dw = torch.empty_like(w)
     msw = timeit(lambda: op.wgrad(x, gy, dw), reps=3)
     print("%-16s %9.1f | %-32s | %-32s | %6.1f  (%.2f ms)" % (

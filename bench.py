@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--fast-guide", action="store_true",
                     help="RtoD: one batched encoder-only guide pass (identical features) instead of the reference's "
                          "two full guide forwards")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="storage dtype of activations/MFMA operands; bf16 = BASELINE configs[2] (fp32 accumulate, fp32 "
+                         "master weights/BN statistics/losses/Adam). The headline line is fp32 DtoD.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -194,7 +197,9 @@ def main():
         model = M.AutoEncoder_2(input_dim=3).to(dev)
         torch.manual_seed(1)
         G = M.AutoEncoder_DtoD(input_dim=1).to(dev).eval()
-    model.train()
+    model.train().compute_dtype(args.dtype)
+    if G is not None:
+        G.compute_dtype(args.dtype)
     opt = Adam(model.parameters(), 2e-5, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
 
     def step():
@@ -240,14 +245,14 @@ def main():
             "metric": "training images/sec at 128x416 batch=20",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": "%s training step (fwd + losses + bwd + fused Adam), batch %d per GPU, 128x416, "
-                                   "fp32, BASELINE configs[%d]" % (args.mode, B, 1 if args.mode == "DtoD" else 2),
+                                   "%s, BASELINE configs[%d]" % (args.mode, B, args.dtype, 1 if args.mode == "DtoD" else 2),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "model_tflops_per_gpu": round(gflop_img * B * args.steps / dt / 1e3, 2),
                        "final_loss": round(final_loss, 6)},
         }
-        if not args.no_roofline:
+        if not args.no_roofline and args.dtype == "fp32":
             ms3, fl3 = conv3x3_roofline(dev, B, 3)
             ms4, fl4 = conv3x3_roofline(dev, B, 4)
             a3 = fl3 / (ms3 * 1e-3) / 1e12

@@ -228,8 +228,11 @@ def test_bf16_mini_unet_vs_fp32_path(gpu):
         e = rel_l2(p, q)
         assert e < 2e-2, "mini-unet feature %s: rel L2 %.3e" % (nm, e)
     worst = 0.0
+    # a BN bias that feeds a conv + train-mode BN has an analytically zero gradient (pure rounding noise):
+    # measure every tensor on the scale of the typical gradient
+    typical = float(np.median([q.grad.double().norm().item() for q in ref.parameters()]))
     for (k, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
-        e = rel_l2(p.grad, q.grad)
+        e = float((p.grad.double() - q.grad.double()).norm() / (q.grad.double().norm() + 5e-2 * typical))
         worst = max(worst, e)
         assert e < 1.5e-1, "mini-unet grad %s: rel L2 %.3e (|ref| %.3e)" % (k, e, float(q.grad.norm()))
     print("mini-unet bf16 vs fp32: worst parameter-gradient rel L2 %.3e" % worst)

@@ -101,7 +101,7 @@ def infer_main(args):
     torch.manual_seed(0)
     B = args.batch if args.batch != 20 else 64
     H, W = 256, 832
-    model = M.AutoEncoder(height=H, width=W).to(dev).eval()
+    model = M.AutoEncoder(height=H, width=W).to(dev).eval().compute_dtype(args.dtype)
     x = (torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(rank)) * 2 - 1).to(dev)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -143,9 +143,9 @@ def infer_main(args):
         rec = {"metric": "inference images/sec at 256x832 batch=64 (legacy AutoEncoder forward)",
                "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "legacy AutoEncoder eval forward, batch %d per GPU, 256x832, fp32, %s, "
-                                      "BASELINE configs[4]" % (B, "hipGraph replay" if graph is not None else "eager"),
+               "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+               "config": {"workload": "legacy AutoEncoder eval forward, batch %d per GPU, 256x832, %s, %s, "
+                                      "BASELINE configs[4]" % (B, args.dtype, "hipGraph replay" if graph is not None else "eager"),
                           "global_batch": B * world, "parallelism": "dp%d" % world,
                           "model_tflops_per_gpu": round(2733.39 * B * args.steps / dt / 1e3, 2),
                           "out_checksum": round(float(o.double().abs().mean().item()), 6)}}

@@ -56,7 +56,7 @@ def run(args, train_loader=None, val_loader=None):
     logger = object() if args.evaluate else None     # reference: validation only when --evaluate
 
     if args.mode == 'DtoD':
-        G = AutoEncoder_DtoD(norm=args.norm, input_dim=1, height=H, width=W).to(dev)
+        G = AutoEncoder_DtoD(norm=args.norm, input_dim=1, height=H, width=W).to(dev).compute_dtype(args.dtype)
         opt = _make_optimizer(G, args)
         loss = train_AE_DtoD(args, G, None, None, opt, train_loader, val_loader, args.batch_size, args.epochs,
                              args.lr, logger, None)
@@ -66,22 +66,22 @@ def run(args, train_loader=None, val_loader=None):
     if args.mode in ('RtoD', 'RtoD_single'):
         G = None
         if args.mode == 'RtoD':
-            G = AutoEncoder_DtoD(norm=args.norm, input_dim=1, height=H, width=W).to(dev)
+            G = AutoEncoder_DtoD(norm=args.norm, input_dim=1, height=H, width=W).to(dev).compute_dtype(args.dtype)
             if os.path.exists(args.model_dir):
                 load_checkpoint(G, args.model_dir)
             elif rank == 0:
                 print("=> no guide checkpoint at %s: using a randomly initialised guide" % args.model_dir)
             G.eval()
-        R = AutoEncoder_2(norm=args.norm, input_dim=3, height=H, width=W).to(dev)
+        R = AutoEncoder_2(norm=args.norm, input_dim=3, height=H, width=W).to(dev).compute_dtype(args.dtype)
         opt = _make_optimizer(R, args)
         return train_AE_RtoD(args, R, G, None, None, opt, train_loader, val_loader, args.batch_size, args.epochs,
                              args.lr, logger, None)
     if args.mode in ('DtoD_test', 'RtoD_test'):
         if args.mode == 'DtoD_test':
-            model = AutoEncoder_DtoD(norm=args.norm, input_dim=1, height=H, width=W).to(dev)
+            model = AutoEncoder_DtoD(norm=args.norm, input_dim=1, height=H, width=W).to(dev).compute_dtype(args.dtype)
             ckpt = args.model_dir
         else:
-            model = AutoEncoder(norm=args.norm, height=H, width=W).to(dev)
+            model = AutoEncoder(norm=args.norm, height=H, width=W).to(dev).compute_dtype(args.dtype)
             ckpt = args.RtoD_model_dir
         if os.path.exists(ckpt):
             load_checkpoint(model, ckpt)

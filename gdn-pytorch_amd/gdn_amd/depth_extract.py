@@ -39,6 +39,7 @@ def main(argv=None):
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=416)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     a = ap.parse_args(argv)
     from PIL import Image
     dev = torch.device("cuda", 0)
@@ -47,7 +48,7 @@ def main(argv=None):
         load_checkpoint(model, a.model_dir)
     else:
         print("=> no --model_dir: running with randomly initialised weights")
-    model = model.to(dev).eval()
+    model = model.to(dev).eval().compute_dtype(a.dtype)
     files = sorted(p for p in pathlib.Path(a.img_dir).iterdir() if p.suffix.lower() in EXTS)
     out = pathlib.Path(a.out_dir)
     out.mkdir(parents=True, exist_ok=True)

@@ -1,5 +1,5 @@
 """Command-line flags: every flag name and default of the reference's option.py:5-48,
-plus the few the MI355X build adds (--synthetic, --local_rank, --global_berhu).
+plus the few the MI355X build adds (--synthetic, --local_rank, --dtype, --global_berhu).
 
 Unlike the reference the parser is not evaluated at import time; call ``parse_args()``.
 """
@@ -41,6 +41,9 @@ def build_parser():
     # --- additions of this build ---
     p.add_argument('--synthetic', action='store_true', help='train on synthetic KITTI-shaped batches (no dataset)')
     p.add_argument('--local_rank', type=int, default=0, help='set by the launcher; RANK/LOCAL_RANK env win')
+    p.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
+                   help='activation / MFMA operand storage type: fp32 (the reference\'s) or bf16 with fp32 accumulation, '
+                        'fp32 master weights, BatchNorm statistics, losses and Adam')
     p.add_argument('--faithful_guide', action='store_true',
                    help='RtoD: run the frozen guide as two full forwards like the reference (default: one '
                         'batched encoder-only pass, identical features)')

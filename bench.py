@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--fast-guide", action="store_true",
                     help="RtoD: one batched encoder-only guide pass (identical features) instead of the reference's "
                          "two full guide forwards")
+    ap.add_argument("--latent-grad", action="store_true",
+                    help="RtoD: back-propagate the latent loss through the frozen guide (--latent_grad of GDN_main)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="storage dtype of activations/MFMA operands; bf16 = BASELINE configs[2] (fp32 accumulate, fp32 "
                          "master weights/BN statistics/losses/Adam). The headline line is fp32 DtoD.")
@@ -200,6 +202,8 @@ def main():
     model.train().compute_dtype(args.dtype)
     if G is not None:
         G.compute_dtype(args.dtype)
+        if args.latent_grad:
+            G.requires_grad_(False)
     opt = Adam(model.parameters(), 2e-5, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
 
     def step():
@@ -208,7 +212,7 @@ def main():
             loss, _, _ = U.dtod_loss(out, depth, sparse)
         else:
             out = model(rgb, istrain=False)
-            lat = T.guide_latent_loss(G, depth, out, faithful=not args.fast_guide)
+            lat = T.guide_latent_loss(G, depth, out, faithful=not args.fast_guide, latent_grad=args.latent_grad)
             pix, _, _ = U.rtod_pixel_loss(out, depth, rgb, sparse)
             loss = pix + lat
         opt.zero_grad()

@@ -851,6 +851,34 @@ __global__ void reflect_fold_kernel(const void* __restrict__ dxp, void* __restri
     }
 }
 
+// Same fold for channel counts that are not a multiple of 4 (the 1- and 3-channel network inputs), fp32 only.
+__global__ void reflect_fold_scalar_kernel(const float* __restrict__ dxp, float* __restrict__ dx,
+                                           const float* __restrict__ addsrc, int ld_add, int ldx,
+                                           int B, int H, int W, int C, int p) {
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        int qy[3], qx[3], ny = 0, nx = 0;
+        qy[ny++] = y + p;
+        if (y >= 1 && y <= p) qy[ny++] = p - y;
+        if (y <= H - 2 && y >= H - 1 - p) qy[ny++] = 2 * (H - 1) - y + p;
+        qx[nx++] = x + p;
+        if (x >= 1 && x <= p) qx[nx++] = p - x;
+        if (x <= W - 2 && x >= W - 1 - p) qx[nx++] = 2 * (W - 1) - x + p;
+        float s = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int e = 0; e < nx; ++e) s += dxp[((size_t)(b * Hp + qy[a]) * Wp + qx[e]) * C + c];
+        const size_t op = (size_t)(b * H + y) * W + x;
+        if (addsrc) s += addsrc[op * ld_add + c];
+        dx[op * ldx + c] = s;
+    }
+}
+
 }  // namespace
 
 extern "C" int gdn_conv_out_dims(const gdn_conv_geom* g, int32_t* Ho, int32_t* Wo) {
@@ -1005,7 +1033,7 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t l
     if (!scalar && (ldy % 4)) return GDN_ERR_UNSUPPORTED;
     if (bf && (scalar || (g->Cout % 64) || (ldy % 8) || (g->Cin % 4))) return GDN_ERR_UNSUPPORTED;
     P.bf16 = bf ? 1 : 0;
-    if (fold && (g->Cin % 4)) return GDN_ERR_UNSUPPORTED;
+    if (fold && (g->Cin % 4) && bf) return GDN_ERR_UNSUPPORTED;
     const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg);
     const int ksplit = pick_ksplit(P, cfg, scalar, tile_cfg);
     const size_t fb = fold ? fold_bytes(g) : 0, need = fb + ksplit_bytes(P, ksplit);
@@ -1016,7 +1044,13 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t l
     P.kc = (!scalar && g->Cout % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
     int rc = launch_igemm(P, cfg, st, ksplit, ksplit > 1 ? (char*)workspace + fb : nullptr);
     if (rc != GDN_OK) return rc;
-    if (fold) {
+    if (fold && (g->Cin % 4)) {
+        const int64_t total = (int64_t)g->B * g->H * g->W * g->Cin;
+        const int blocks = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+        hipLaunchKernelGGL(reflect_fold_scalar_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dx, addsrc,
+                           ld_add, ldx, g->B, g->H, g->W, g->Cin, g->pad);
+        rc = gdn_launch_status();
+    } else if (fold) {
         const int64_t total = (int64_t)g->B * g->H * g->W * (g->Cin / 4);
         const int blocks = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
         hipLaunchKernelGGL(reflect_fold_kernel, dim3(blocks), dim3(256), 0, st, (const void*)workspace, (void*)dx,

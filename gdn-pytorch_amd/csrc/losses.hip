@@ -213,6 +213,18 @@ __global__ __launch_bounds__(256) void sqdiff_kernel(const void* __restrict__ a,
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
+// da = (*gscale) * coef * (a - b): gradient of coef/2 * sum((a-b)^2) scaled by a device-side upstream scalar
+__global__ __launch_bounds__(256) void sqdiff_grad_kernel(const void* __restrict__ a, const void* __restrict__ b,
+                                                          int64_t n, float coef, const float* __restrict__ gscale,
+                                                          void* __restrict__ da, int dt) {
+    const float k = coef * (gscale ? *gscale : 1.f);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+        st4_any(da, i * 4, k * (ld4_any(a, i * 4, dt & 1) - ld4_any(b, i * 4, dt & 2)), dt & 4);
+    for (int64_t i = (n4 << 2) + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        st1_any(da, i, k * (ld1_any(a, i, dt & 1) - ld1_any(b, i, dt & 2)), dt & 4);
+}
+
 }  // namespace
 
 #define ST(s) ((hipStream_t)(s))
@@ -282,5 +294,15 @@ extern "C" int gdn_mse(const void* a, const void* b, int64_t n, float weight, in
     hipLaunchKernelGGL(sqdiff_kernel, dim3(nb), dim3(256), 0, ST(stream), a, b, n, w.part, dtypes);
     hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)w.part, nb,
                        (double)weight / (double)n, accumulate, loss);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_mse_grad(const void* a, const void* b, int64_t n, float weight, const float* gscale, void* da,
+                            int32_t dtypes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    if (!a || !b || !da || n <= 0) return GDN_ERR_BAD_ARG;
+    const int nb = loss_blocks(n / 4 + 1);
+    hipLaunchKernelGGL(sqdiff_grad_kernel, dim3(nb), dim3(256), 0, ST(stream), a, b, n,
+                       (float)(2.0 * (double)weight / (double)n), gscale, da, dtypes);
     return gdn_launch_status();
 }

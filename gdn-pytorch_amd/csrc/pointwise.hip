@@ -416,6 +416,43 @@ extern "C" int gdn_bn_bwd(const void* dout, int32_t ld_dout, const void* y, int3
     return gdn_launch_status();
 }
 
+// Backward of out = [relu](y*scale + shift) with FIXED per-channel coefficients (eval-mode BatchNorm of a frozen
+// network): dy = scale * dout * [z > 0].  No reductions, no parameter gradients.
+__global__ __launch_bounds__(256) void bn_eval_bwd_kernel(const void* __restrict__ dout, int ld_dout,
+                                                          const void* __restrict__ y, int ldy,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, void* __restrict__ dy,
+                                                          int ld_dy, int64_t npix, int C, int relu, int dt) {
+    const int cq = C >> 2;
+    const int64_t total = npix * cq;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / cq;
+        const int c = (int)(i - pix * cq) * 4;
+        const f32x4 d = ld4_any(dout, pix * ld_dout + c, dt & 1);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c);
+        f32x4 o = d * s;
+        if (relu) {
+            const f32x4 v = ld4_any(y, pix * ldy + c, dt & 2);
+            const f32x4 t = *reinterpret_cast<const f32x4*>(shift + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (!(v[e] * s[e] + t[e] > 0.f)) o[e] = 0.f;
+        }
+        st4_any(dy, pix * ld_dy + c, o, dt & 4);
+    }
+}
+
+extern "C" int gdn_bn_eval_bwd(const void* dout, int32_t ld_dout, const void* y, int32_t ldy, const float* scale,
+                               const float* shift, void* dy, int32_t ld_dy, int64_t npix, int32_t C, int32_t relu,
+                               int32_t dtypes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    if (!dout || !y || !scale || !shift || !dy || npix <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
+    if ((C % 4) || (ldy % 4) || (ld_dout % 4) || (ld_dy % 4)) return GDN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_eval_bwd_kernel, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, ST(stream), dout, ld_dout,
+                       y, ldy, scale, shift, dy, ld_dy, npix, C, relu, dtypes);
+    return gdn_launch_status();
+}
+
 extern "C" int gdn_upsample2x_fwd(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C,
                                   int32_t align_corners, int32_t dtypes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread

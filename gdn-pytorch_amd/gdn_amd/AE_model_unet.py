@@ -52,8 +52,9 @@ class _HipModule(nn.Module):
                 raise GdnError("move the model to %s before calling it (model.cuda())" % dev)
             break
         arena = E.ensure_arena(self, dev)
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        outs = _Bridge.apply(self, arena, need_grad, select, x, self._anchor(dev) if need_grad else None)
+        trainable = any(p.requires_grad for p in self.parameters())
+        need_grad = torch.is_grad_enabled() and (trainable or x.requires_grad)
+        outs = _Bridge.apply(self, arena, need_grad, select, x, self._anchor(dev) if need_grad and trainable else None)
         return outs
 
     def _anchor(self, dev):
@@ -89,7 +90,8 @@ class _Bridge(torch.autograd.Function):
             raise GdnError("this forward's tape was already consumed (retain_graph is not supported on the HIP path)")
         ctx, outs, arena = fctx.gdn
         fctx.gdn = None
-        pending = arena.bind_grads()
+        trainable = any(p.requires_grad for p in fctx.gdn_module.parameters())
+        pending = arena.bind_grads() if trainable else []      # a frozen network (the guide) only passes dx through
         red = getattr(fctx.gdn_module, "_gdn_reducer", None)
         if red is not None and red.arena is arena and not pending:
             red.begin()
@@ -253,7 +255,7 @@ class AutoEncoder_2(_EncDec):
         self._finish(init_weights, height, width)
 
     def _run(self, ctx, x):
-        x1_cat = self.downconv0.run(ctx, x, need_dx=False)
+        x1_cat = self.downconv0.run(ctx, x)
         x1 = self.res64_down1.run(ctx, x1_cat)
         x2_cat = self.downconv1.run(ctx, x1)
         x2 = self.res128_down1.run(ctx, x2_cat)
@@ -308,7 +310,7 @@ class AutoEncoder_DtoD(_EncDec):
     _encoder_only = False
 
     def _run(self, ctx, x):
-        x1 = self.res64_down1.run(ctx, self.downconv0.run(ctx, x, need_dx=False))
+        x1 = self.res64_down1.run(ctx, self.downconv0.run(ctx, x))
         x2 = self.res128_down1.run(ctx, self.downconv1.run(ctx, x1))
         x3 = self.res256_down1.run(ctx, self.downconv2.run(ctx, x2))
         x4 = self.res512_down1.run(ctx, self.downconv3.run(ctx, x3))
@@ -365,7 +367,7 @@ class AutoEncoder(_HipModule):
 
     def _run(self, ctx, x):
         cba = E.conv_bn_act
-        x3 = cba(ctx, x, self.downconv0, self.N64_down, relu=True, need_dx=False)
+        x3 = cba(ctx, x, self.downconv0, self.N64_down, relu=True)
         x5 = self.res64_down2.run(ctx, self.res64_down1.run(ctx, x3))
         x8 = cba(ctx, x5, self.downconv1, self.N128_down, relu=True)
         x10 = self.res128_down2.run(ctx, self.res128_down1.run(ctx, x8))

@@ -72,6 +72,8 @@ def run(args, train_loader=None, val_loader=None):
             elif rank == 0:
                 print("=> no guide checkpoint at %s: using a randomly initialised guide" % args.model_dir)
             G.eval()
+            if getattr(args, "latent_grad", False):
+                G.requires_grad_(False)       # the guide only passes d(latent)/d(outputs) through
         R = AutoEncoder_2(norm=args.norm, input_dim=3, height=H, width=W).to(dev).compute_dtype(args.dtype)
         opt = _make_optimizer(R, args)
         return train_AE_RtoD(args, R, G, None, None, opt, train_loader, val_loader, args.batch_size, args.epochs,

@@ -51,6 +51,7 @@ _SIGS = {
     "gdn_bn_apply": (c_int32, [_P, _i32, _P, _P, _P, _i32, _P, _i32, _i64, _i32, _i32, _i32, _P]),
     "gdn_bn_bwd_workspace_bytes": (_sz, [_i64, _i32]),
     "gdn_bn_bwd": (c_int32, [_P, _i32, _P, _i32, _P, _P, _P, _P, _P, _P, _i32, _P, _P, _i64, _i32, _i32, _P, _sz, _i32, _P]),
+    "gdn_bn_eval_bwd": (c_int32, [_P, _i32, _P, _i32, _P, _P, _P, _i32, _i64, _i32, _i32, _i32, _P]),
     "gdn_upsample2x_fwd": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "gdn_upsample2x_bwd": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "gdn_nchw_to_nhwc": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _i32, _P]),
@@ -63,6 +64,7 @@ _SIGS = {
     "gdn_sobel_l1": (c_int32, [_P, _P, _i32, _i32, _i32, _f, _P, _P, _P, _sz, _P]),
     "gdn_smoothness": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P, _P, _P, _sz, _P]),
     "gdn_mse": (c_int32, [_P, _P, _i64, _f, _i32, _P, _P, _sz, _i32, _P]),
+    "gdn_mse_grad": (c_int32, [_P, _P, _i64, _f, _P, _P, _i32, _P]),
     "gdn_depth_metrics_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "gdn_depth_metrics": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, _P, _P, _sz, _P]),
     "gdn_adam_step": (c_int32, [_P, _P, _P, _P, _i64, _f, _f, _f, _f, _f, _i32, _f, _P]),

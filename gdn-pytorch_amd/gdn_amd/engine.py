@@ -276,13 +276,20 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
             da = ctx.pop_grad(a)
             if da is None:
                 return
-            if not bn_training:       # forward in eval mode is fine; only an actual backward needs this
-                raise GdnError("backward through eval-mode BatchNorm is not implemented on the HIP path")
+            frozen = not (conv.weight.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad)
+            if not bn_training and not frozen:
+                raise GdnError("backward through an eval-mode BatchNorm is only implemented for frozen layers "
+                               "(requires_grad False on the conv and BN parameters): the guide network of --latent_grad")
             if residual is not None:
                 ctx.add_grad(residual, da)
-            dy = ops.bn_bwd(da, y, bn.weight.data, co, relu, bn.weight.grad, bn.bias.grad, out_dtype=ldt)
-            _wgrad_into(ctx, conv, x, dy, x2)
-            ctx.grads_done(bn.weight, bn.bias, conv.weight)
+            if bn_training:
+                dy = ops.bn_bwd(da, y, bn.weight.data, co, relu, bn.weight.grad if not frozen else None,
+                                bn.bias.grad if not frozen else None, out_dtype=ldt)
+            else:
+                dy = ops.bn_eval_bwd(da, y, co, relu, out_dtype=ldt)
+            if not frozen:
+                _wgrad_into(ctx, conv, x, dy, x2)
+                ctx.grads_done(bn.weight, bn.bias, conv.weight)
             if need_dx and ctx.wants_dx(x):
                 wt = ops.transpose_taps(_w_tap(conv)[0], dtype=ldt)
                 if x2 is None:
@@ -311,8 +318,9 @@ def conv_head_tanh(ctx, x, conv):
             if do is None:
                 return
             dpre = ops.tanh_bwd(do.contiguous(), out)
-            _wgrad_into(ctx, conv, x, dpre)
-            ctx.grads_done(conv.weight)
+            if conv.weight.requires_grad:
+                _wgrad_into(ctx, conv, x, dpre)
+                ctx.grads_done(conv.weight)
             wt = ops.transpose_taps(w)
             dx = op.dgrad(dpre, wt, in_hw, addsrc=ctx.pop_grad_as(x, torch.float32))
             ctx.grads[id(x)] = (x, dx)

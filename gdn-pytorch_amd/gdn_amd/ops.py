@@ -256,6 +256,15 @@ def bn_bwd(dout, y, gamma, coeffs, relu, dgamma, dbeta, out_dtype=None):
     return dy
 
 
+def bn_eval_bwd(dout, y, coeffs, relu, out_dtype=None):
+    """Backward through an eval-mode BN (+ReLU): coeffs = [scale, shift] from bn_eval_coeffs. Returns dy."""
+    B, H, W, C = y.shape
+    dy = torch.empty((B, H, W, C), dtype=out_dtype or y.dtype, device=y.device)
+    lib.gdn_bn_eval_bwd(_p(dout), _ld(dout), _p(y), _ld(y), _p(coeffs[0]), _p(coeffs[1]), _p(dy), _ld(dy), B * H * W, C,
+                        1 if relu else 0, _mask(dout, y, dy), stream())
+    return dy
+
+
 def upsample2x(x, align_corners=False):
     B, H, W, C = x.shape
     if not x.is_contiguous():
@@ -340,6 +349,15 @@ def smoothness(depth, img, ddepth, loss):
 def mse_accum(a, b, weight, loss, accumulate):
     ws, nb = _loss_ws(0, a.device)
     lib.gdn_mse(_p(a), _p(b), a.numel(), float(weight), 1 if accumulate else 0, _p(loss), _p(ws), nb, _mask(a, b), stream())
+
+
+def mse_grad(a, b, weight, gscale, out_dtype=None):
+    """d/da of weight*mean((a-b)^2), times the device scalar gscale (or None)."""
+    da = torch.empty_like(a, dtype=out_dtype or a.dtype)       # preserves a's (dense) memory order
+    if da.stride() != a.stride():
+        raise GdnError("mse_grad needs a dense tensor")
+    lib.gdn_mse_grad(_p(a), _p(b), a.numel(), float(weight), _p(gscale), _p(da), _mask(a, b, da), stream())
+    return da
 
 
 def depth_metrics(gt_sparse, gt, pred, crop=True):

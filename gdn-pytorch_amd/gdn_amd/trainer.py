@@ -106,20 +106,27 @@ def train_AE_DtoD(args, model, criterion_L2, criterion_L1, optimizer, dataset_lo
     return loss
 
 
-def guide_latent_loss(G, depths, outputs, faithful=False):
-    """Latent loss of trainer.py:699-733: G's features of the ground truth vs. of the estimate, both under
-    no_grad (value only, F3).
+def guide_latent_loss(G, depths, outputs, faithful=False, latent_grad=False):
+    """Latent loss of trainer.py:699-733: G's features of the ground truth vs. of the estimate.
 
+    Default (the reference as shipped, F3): both under no_grad, value only.
     faithful=True runs the guide exactly like the reference: two full forwards with ``istrain=True``.
-    The default gives bit-identical features with 52 % of that work: the frozen eval-mode guide has no
-    cross-sample coupling, so both inputs go through ONE batched, encoder-only pass."""
+    Otherwise the four features come from encoder-only passes (bit-identical, 52 % of the work); without
+    latent_grad the frozen eval-mode guide has no cross-sample coupling, so both inputs share ONE batched pass.
+    latent_grad=True is the guided training the paper describes: the estimate's features keep their autograd
+    history, so d(latent)/d(outputs) flows back through the frozen, eval-mode G into the trained network."""
+    feats = (lambda x: G(x, istrain=True)[:4]) if faithful or not hasattr(G, "guide_features") else G.guide_features
+    if latent_grad:
+        if G.training or any(p.requires_grad for p in G.parameters()):
+            raise U.GdnError("--latent_grad needs a frozen guide: G.eval() and G.requires_grad_(False)")
+        with torch.no_grad():
+            ft_tar = feats(depths)
+        return U.latent_loss(feats(outputs), ft_tar)
     with torch.no_grad():
-        if faithful or not hasattr(G, "guide_features"):
-            ft_tar = G(depths, istrain=True)[:4]
-            ft = G(outputs, istrain=True)[:4]
-        elif G.training:      # batch statistics would couple the two halves: keep them separate
-            ft_tar = G.guide_features(depths)
-            ft = G.guide_features(outputs.detach())
+        if faithful or not hasattr(G, "guide_features") or G.training:
+            # (training-mode batch statistics would couple the two halves of a batched pass: keep them separate)
+            ft_tar = feats(depths)
+            ft = feats(outputs.detach())
         else:
             B = depths.shape[0]
             both = G.guide_features(torch.cat((depths, outputs.detach()), 0))
@@ -153,7 +160,8 @@ def train_AE_RtoD(args, model, DtoD_model, criterion_L2, criterion_L1, optimizer
             sparse = _to_dev(gt_data_2, dev) if kitti else None
             outputs = model(inputs, istrain=False)
             if not single:
-                latent = guide_latent_loss(DtoD_model, depths, outputs, faithful=getattr(args, "faithful_guide", False))
+                latent = guide_latent_loss(DtoD_model, depths, outputs, faithful=getattr(args, "faithful_guide", False),
+                                           latent_grad=getattr(args, "latent_grad", False))
             pix, output_loss, smooth = U.rtod_pixel_loss(outputs, depths, inputs, sparse)
             loss = pix + latent
             optimizer.zero_grad()

@@ -122,15 +122,51 @@ def rtod_pixel_loss(outputs, depths, rgb, sparse_depths=None, box=None):
 LATENT_WEIGHTS = (1.0, 2.5, 14.0, 12.0)
 
 
-def latent_loss(feats, feats_tar):
-    """1.5*(mse1 + 2.5*mse2 + 14*mse3 + 12*mse4)/4, value only (F3). trainer.py:726-733."""
+class _LatentLoss(torch.autograd.Function):
+    """Differentiable form of the latent loss (w.r.t. the estimate's features only): --latent_grad."""
+
+    @staticmethod
+    def forward(fctx, n, *tensors):
+        feats, tars = tensors[:n], tensors[n:]
+        loss = _latent_value(feats, tars)
+        fctx.pairs = [(f.detach(), t.detach()) for f, t in zip(feats, tars)]
+        return loss
+
+    @staticmethod
+    def backward(fctx, gout):
+        gout = gout.contiguous()
+        grads = []
+        for w, (f, t) in zip(LATENT_WEIGHTS, fctx.pairs):
+            a, b = f, t
+            if a.stride() != b.stride() or not _dense_any_order(a):
+                a, b = a.contiguous(), b.contiguous()
+            g = ops.mse_grad(a, b, 1.5 * w / 4.0, gout)          # same memory order as a
+            grads.append(g)
+        return (None, *grads, *([None] * len(grads)))
+
+
+def _dense_any_order(t):
+    """True if t covers a dense block of memory in some dimension order (NCHW view of an NHWC buffer)."""
+    return t.is_contiguous() or t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def _latent_value(feats, feats_tar):
     loss = torch.empty((), dtype=torch.float32, device=feats[0].device)
     for i, (w, f, t) in enumerate(zip(LATENT_WEIGHTS, feats, feats_tar)):
         a, b = f.detach(), t.detach()
-        if a.stride() != b.stride():
+        if a.stride() != b.stride() or not _dense_any_order(a):
             b = b.contiguous(); a = a.contiguous()
         ops.mse_accum(a, b, 1.5 * w / 4.0, loss, accumulate=i > 0)
     return loss
+
+
+def latent_loss(feats, feats_tar):
+    """1.5*(mse1 + 2.5*mse2 + 14*mse3 + 12*mse4)/4. trainer.py:726-733.  Value only when the features carry no
+    autograd history (the reference, F3); differentiable w.r.t. `feats` when they do (--latent_grad)."""
+    feats, feats_tar = list(feats)[:4], list(feats_tar)[:4]
+    if torch.is_grad_enabled() and any(f.requires_grad for f in feats):
+        return _LatentLoss.apply(len(feats), *feats, *feats_tar)
+    return _latent_value(feats, feats_tar)
 
 
 def save_path_formatter(args, parser):

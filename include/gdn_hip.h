@@ -185,6 +185,13 @@ int gdn_bn_bwd(const void* dout, int32_t ld_dout, const void* y, int32_t ldy,
                int64_t npix, int32_t C, int32_t relu,
                void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream);
 
+/* Backward of out = [relu](y*scale + shift) through an EVAL-mode BatchNorm (fixed coefficients from
+ * gdn_bn_eval_coeffs): dy = scale*dout*[z>0].  Used when a gradient crosses the frozen guide network
+ * (--latent_grad, the guided training of trainer.py:699-703 without the no_grad).  dtypes: bit0 dout, bit1 y, bit2 dy. */
+int gdn_bn_eval_bwd(const void* dout, int32_t ld_dout, const void* y, int32_t ldy,
+                    const float* scale, const float* shift, void* dy, int32_t ld_dy,
+                    int64_t npix, int32_t C, int32_t relu, int32_t dtypes, void* stream);
+
 /* ------------------------------------------------------------------------
  * x2 bilinear up-sampling: F.interpolate(align_corners=False) AE_model_unet.py:336,343,349,355
  * and nn.Upsample(align_corners=True) :135,203,215,227.  NHWC, C channels.
@@ -226,6 +233,10 @@ int gdn_smoothness(const float* depth, const float* img, int32_t Ci, int32_t B, 
  * (value only, F3).  accumulate != 0 adds to the existing *loss.  dtypes: bit0 a, bit1 b. */
 int gdn_mse(const void* a, const void* b, int64_t n, float weight, int32_t accumulate,
             float* loss, void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream);
+/* Gradient of weight*mean((a-b)^2) w.r.t. a, times the device scalar *gscale (NULL = 1):
+ * da = gscale * 2*weight/n * (a-b).  dtypes: bit0 a, bit1 b, bit2 da.  (--latent_grad) */
+int gdn_mse_grad(const void* a, const void* b, int64_t n, float weight, const float* gscale,
+                 void* da, int32_t dtypes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Depth metrics, calculate_error.py:10-103: per image min-max -> x80, Godard

@@ -485,14 +485,20 @@ def dtod_loss(outputs, depths, sparse):
     return ol + gl, ol, gl
 
 
-def rtod_loss(outputs, depths, rgb, sparse, g_sd=None):
-    """RtoD total = BerHu + latent (value only, F3) + smoothness. trainer.py:696-757."""
+def rtod_loss(outputs, depths, rgb, sparse, g_sd=None, latent_grad=False):
+    """RtoD total = BerHu + latent + smoothness. trainer.py:696-757.  The latent term is value only as shipped
+    (both guide passes under no_grad, F3); latent_grad=True drops the no_grad around the estimate's pass --
+    the guided training of the paper -- so its gradient reaches `outputs` through the frozen eval-mode guide."""
     ol = berhu_masked(outputs, depths, sparse)
     lat = torch.zeros(())
     if g_sd is not None:
         with torch.no_grad():
             ft_tar = forward_dtod(g_sd, depths, istrain=True, training=False)[:4]
+        if latent_grad:
             ft = forward_dtod(g_sd, outputs, istrain=True, training=False)[:4]
+        else:
+            with torch.no_grad():
+                ft = forward_dtod(g_sd, outputs, istrain=True, training=False)[:4]
         lat = latent_loss(ft, ft_tar)
     sm = smoothness_loss(outputs, rgb)
     return ol + lat + sm, ol, lat, sm
@@ -554,7 +560,7 @@ def trainable_keys(sd):
     return [k for k in sd if k.endswith(".weight") or k.endswith(".bias")]
 
 
-def train_step(mode, sd, batch, opt_state, g_sd=None, lr=2e-5):
+def train_step(mode, sd, batch, opt_state, g_sd=None, lr=2e-5, latent_grad=False):
     """One reference training step on CPU (forward, losses, backward, Adam).
 
     mode 'DtoD': trainer.py:411-468; mode 'RtoD' / 'RtoD_single': trainer.py:670-768.
@@ -572,7 +578,7 @@ def train_step(mode, sd, batch, opt_state, g_sd=None, lr=2e-5):
         comps = {"loss": loss, "output_loss": ol, "gradient_loss": gl}
     else:
         out = forward_r(work, rgb, istrain=False, training=True)
-        loss, ol, lat, sm = rtod_loss(out, depths, rgb, sparse, g_sd if mode == "RtoD" else None)
+        loss, ol, lat, sm = rtod_loss(out, depths, rgb, sparse, g_sd if mode == "RtoD" else None, latent_grad)
         comps = {"loss": loss, "output_loss": ol, "latent_loss": lat, "smoothness_loss": sm}
     out.retain_grad()
     loss.backward()

@@ -143,3 +143,79 @@ def test_cli_synthetic_smoke(gpu, tmp_path, monkeypatch):
                            "--epoch_size", "2", "--height", "32", "--width", "64", "--gpu_num", "0"])
     loss = GDN_main.run(a)
     assert torch.isfinite(loss)
+
+
+def test_latent_grad_vs_oracle(gpu):
+    """--latent_grad: d(latent)/d(outputs) through the frozen eval-mode guide, and from there
+    into the trained network's parameters, against the oracle's autograd through the same graph."""
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import trainer as T
+    from gdn_amd import utils as U
+    from gdn_amd._lib import GdnError
+    H, W = 32, 64
+    depth, rgb, sparse = O.synthetic_batch(2, H, W, seed=6)
+    sd = O.init_state_dict("AutoEncoder_2", seed=5)
+    g_sd = O.init_state_dict("AutoEncoder_DtoD", seed=7)
+    ref = O.train_step("RtoD", {k: v.clone() for k, v in sd.items()}, (depth, rgb, sparse), {},
+                       g_sd={k: v.clone() for k, v in g_sd.items()}, latent_grad=True)
+    ref0 = O.train_step("RtoD", {k: v.clone() for k, v in sd.items()}, (depth, rgb, sparse), {},
+                        g_sd={k: v.clone() for k, v in g_sd.items()}, latent_grad=False)
+    assert (ref["dout"] - ref0["dout"]).abs().max() > 1e-6          # the extension changes the gradient
+    R = M.AutoEncoder_2(input_dim=3, height=H, width=W)
+    R.load_state_dict(sd)
+    G = M.AutoEncoder_DtoD(input_dim=1, height=H, width=W)
+    G.load_state_dict(g_sd)
+    R, G = R.to(gpu).train(), G.to(gpu).eval()
+    d, r, s = depth.to(gpu), rgb.to(gpu), sparse.to(gpu)
+    out = R(r, istrain=False)
+    with pytest.raises(GdnError):                                    # the guide must be frozen
+        T.guide_latent_loss(G, d, out, latent_grad=True)
+    G.requires_grad_(False)
+    # (1) the guide alone, at the oracle's own estimate: d(latent)/d(outputs) == dout(latent_grad) - dout(value only)
+    for faithful in (False, True):
+        xo = ref["outputs"].to(gpu).requires_grad_(True)
+        lat = T.guide_latent_loss(G, d, xo, faithful=faithful, latent_grad=True)
+        lat.backward()
+        assert lat.item() == pytest.approx(ref["latent_loss"], rel=1e-3)
+        close(xo.grad, ref["dout"] - ref0["dout"], rtol=5e-3, atol_scale=5e-3, what="d latent / d outputs")
+    # (2) end to end: the trained network's estimate differs from the oracle's by its own rounding (amplified by
+    # train-mode BN at this tiny size), so the total gradient is compared at the looser bar of the train-step tests
+    R.zero_grad()
+    out = R(r, istrain=False)
+    out.retain_grad()
+    lat = T.guide_latent_loss(G, d, out, latent_grad=True)
+    pix, ol, sm = U.rtod_pixel_loss(out, d, r, s)
+    (pix + lat).backward()
+    assert lat.item() == pytest.approx(ref["latent_loss"], rel=5e-3)
+    close(out.grad, ref["dout"], rtol=5e-2, atol_scale=3e-2, what="dL/dout with latent grad", outliers=2e-3)
+    typical = float(np.median([ref["grads"][k].double().norm().item() for k, _ in R.named_parameters()]))
+    worst = 0.0
+    for k, p in R.named_parameters():
+        gr, rr = p.grad.detach().cpu().double(), ref["grads"][k].double()
+        rel = float((gr - rr).norm() / (rr.norm() + 1e-2 * typical))
+        worst = max(worst, rel)
+        assert rel < 5e-2, "%s: relative gradient error %.3e" % (k, rel)
+    print("latent_grad end to end: worst relative parameter-gradient error %.3e" % worst)
+    assert all(p.grad is None for p in G.parameters())
+
+
+@pytest.mark.parametrize("name", ["AutoEncoder_DtoD", "AutoEncoder_2"])
+def test_input_gradient_vs_oracle(gpu, name):
+    """d(out)/d(input) of the whole network (1- and 3-channel inputs: N<4 data gradient + scalar reflect fold)."""
+    import gdn_amd.AE_model_unet as M
+    H, W = 32, 64
+    depth, rgb, _ = O.synthetic_batch(1, H, W, seed=8)
+    x = depth if name == "AutoEncoder_DtoD" else rgb
+    sd = O.init_state_dict(name, seed=9)
+    xr = x.clone().requires_grad_(True)
+    out_ref = O.FORWARD[name]({k: v.clone() for k, v in sd.items()}, xr, istrain=False, training=False)
+    gy = torch.randn(out_ref.shape, generator=torch.Generator().manual_seed(1))
+    out_ref.backward(gy)
+    model = getattr(M, name)(input_dim=x.shape[1], height=H, width=W)
+    model.load_state_dict(sd)
+    model = model.to(gpu).eval().requires_grad_(False)
+    xg = x.to(gpu).requires_grad_(True)
+    out = model(xg, istrain=False)
+    close(out, out_ref, atol_scale=1e-3, what=name + " eval forward")
+    out.backward(gy.to(gpu))
+    close(xg.grad, xr.grad, rtol=5e-3, atol_scale=5e-3, what=name + " d out / d input")

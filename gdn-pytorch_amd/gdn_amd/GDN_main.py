@@ -44,12 +44,29 @@ def run(args, train_loader=None, val_loader=None):
         print('=> number of GPU processes: ', world)
         print("=> creating model")
     if train_loader is None:
-        if not args.synthetic:
-            raise RuntimeError("the dataset file pipeline is outside this build's scope; use --synthetic or "
-                               "call run(args, train_loader, val_loader)")
+        from .datasets import GpuAugmentLoader, SequenceFolder, SyntheticRawKitti
         steps = args.epoch_size or 100
-        train_loader = SyntheticLoader(args.batch_size, steps, H, W, seed=args.seed + rank, device=dev)
-        val_loader = SyntheticLoader(args.batch_size, 2, H, W, seed=args.seed + 1000 + rank, device=dev)
+        if not args.synthetic and os.path.isdir(str(args.data)):
+            # the reference's file layout (datasets_list.py:61-76); decode on the host, augment on the GPU
+            if args.dataset != "KITTI":
+                raise RuntimeError("only the KITTI pipeline (GDN_main.py:56-80) is implemented; NYU is out of scope")
+            train_set = SequenceFolder(args.data, args, seed=args.seed + rank, train=True, mode=args.mode)
+            val_set = SequenceFolder(args.data, args, seed=args.seed, train=False, mode=args.mode)
+            train_loader = GpuAugmentLoader(train_set, args.batch_size, dev, train=True, seed=args.seed + rank,
+                                            workers=args.workers, drop_last=True)
+            val_loader = GpuAugmentLoader(val_set, args.batch_size, dev, train=False, workers=args.workers)
+        elif not args.synthetic:
+            raise RuntimeError("dataset directory %r not found; pass a KITTI root laid out like the reference's "
+                               "(train.txt, val.txt, <scene>/*.jpg, color_gt2/, gt/) or --synthetic" % (args.data,))
+        elif getattr(args, "augment", False):
+            # synthetic RAW uint8 samples through the same GPU augmentation the file pipeline uses
+            raw = SyntheticRawKitti(args.batch_size * min(steps, 8), H, W, seed=args.seed + rank)
+            train_loader = GpuAugmentLoader(raw, args.batch_size, dev, train=True, seed=args.seed + rank, drop_last=True)
+            val_loader = GpuAugmentLoader(SyntheticRawKitti(args.batch_size * 2, H, W, seed=args.seed + 1000 + rank),
+                                          args.batch_size, dev, train=False)
+        else:
+            train_loader = SyntheticLoader(args.batch_size, steps, H, W, seed=args.seed + rank, device=dev)
+            val_loader = SyntheticLoader(args.batch_size, 2, H, W, seed=args.seed + 1000 + rank, device=dev)
     if args.epoch_size == 0:
         args.epoch_size = len(train_loader)
     args.local_rank = local_rank

@@ -64,6 +64,8 @@ _SIGS = {
     "gdn_sobel_l1": (c_int32, [_P, _P, _i32, _i32, _i32, _f, _P, _P, _P, _sz, _P]),
     "gdn_smoothness": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P, _P, _P, _sz, _P]),
     "gdn_mse": (c_int32, [_P, _P, _i64, _f, _i32, _P, _P, _sz, _i32, _P]),
+    "gdn_kitti_augment_workspace_bytes": (_sz, [_i32]),
+    "gdn_kitti_augment": (c_int32, [_P, _i32, _i32, _i32, _i32, _i32, _P, _i32, _P, _P, _sz, _P]),
     "gdn_mse_grad": (c_int32, [_P, _P, _i64, _f, _P, _P, _i32, _P]),
     "gdn_depth_metrics_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "gdn_depth_metrics": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, _P, _P, _sz, _P]),

@@ -372,3 +372,19 @@ def depth_metrics(gt_sparse, gt, pred, crop=True):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     lib.gdn_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, int(step),
                       float(grad_scale), stream())
+
+
+def kitti_augment(src, params, train=True):
+    """src [B,H,W,C] uint8/float32 as decoded; params int32 [B,5] on the device (or None when not train).
+    Returns the normalised NCHW float32 batch."""
+    if not src.is_cuda or src.dtype not in (torch.uint8, torch.float32) or src.dim() != 4 or not src.is_contiguous():
+        raise GdnError("kitti_augment: src must be a dense [B,H,W,C] uint8/float32 tensor on the GPU")
+    B, H, W, C = src.shape
+    if train and (params is None or params.dtype != torch.int32 or tuple(params.shape) != (B, 5) or not params.is_cuda):
+        raise GdnError("kitti_augment: params must be a device int32 [B,5] tensor")
+    dst = torch.empty((B, C, H, W), dtype=torch.float32, device=src.device)
+    nb = int(lib.gdn_kitti_augment_workspace_bytes(B))
+    ws = workspace(nb, src.device, "augment")
+    lib.gdn_kitti_augment(_p(src), 1 if src.dtype == torch.float32 else 0, B, H, W, C, _p(params), 1 if train else 0,
+                          _p(dst), _p(ws), nb, stream())
+    return dst

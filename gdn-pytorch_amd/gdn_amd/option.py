@@ -44,6 +44,9 @@ def build_parser():
     p.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
                    help='activation / MFMA operand storage type: fp32 (the reference\'s) or bf16 with fp32 accumulation, '
                         'fp32 master weights, BatchNorm statistics, losses and Adam')
+    p.add_argument('--augment', action='store_true',
+                   help='with --synthetic: feed synthetic RAW uint8 samples through the GPU augmentation kernel '
+                        '(flip / scale-crop / normalise) instead of ready-made tensors')
     p.add_argument('--latent_grad', action='store_true',
                    help='RtoD: let the latent loss back-propagate through the frozen guide into the trained network '
                         '(the guided training of the paper; the reference as shipped computes it under no_grad, value only)')

@@ -249,6 +249,23 @@ int gdn_depth_metrics(const float* gt_sparse, const float* gt, const float* pred
                       float* errors, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * KITTI training-time augmentation on the device.  Replaces the host pipeline
+ * datasets_list.py:82-101 -> transform_list.py RandomHorizontalFlip :158-166, RandomScaleCrop :185-199
+ * (scipy.misc.imresize = bytescale + Pillow bilinear), ArrayToTensor :100-118, Normalize :84-92,
+ * bit-exactly (uint8 resampling in Pillow's 22-bit fixed point, IEEE float32 normalisation).
+ *   src    [B][H][W][C] as decoded from the image files: uint8, or float32 when src_is_f32 (then the
+ *          per-image min/max stretch of scipy's bytescale is applied first); C <= 4
+ *   params device int32 [B][5] = {flip, scaled_h, scaled_w, off_y, off_x}: the sample is flipped, resized to
+ *          scaled_h x scaled_w (>= H x W) and cropped back to H x W at (off_y, off_x); ignored when train == 0
+ *   train  0: validation transform (GDN_main.py:49-52): ArrayToTensor + Normalize only
+ *   dst    [B][C][H][W] float32 = (v/255 - 0.5)/0.5
+ * ---------------------------------------------------------------------- */
+size_t gdn_kitti_augment_workspace_bytes(int32_t B);
+int gdn_kitti_augment(const void* src, int32_t src_is_f32, int32_t B, int32_t H, int32_t W, int32_t C,
+                      const int32_t* params, int32_t train, float* dst,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * Fused Adam with coupled L2 weight decay over one flat arena
  * (torch.optim.Adam(..., weight_decay=5e-4), GDN_main.py:157,173; step at
  * trainer.py:468,768).  grad_scale multiplies the gradient first (1/world

@@ -219,3 +219,37 @@ def test_input_gradient_vs_oracle(gpu, name):
     close(out, out_ref, atol_scale=1e-3, what=name + " eval forward")
     out.backward(gy.to(gpu))
     close(xg.grad, xr.grad, rtol=5e-3, atol_scale=5e-3, what=name + " d out / d input")
+
+
+def test_cli_augment_latent_grad_bf16_smoke(gpu, tmp_path, monkeypatch):
+    """RtoD from the CLI with every opt-in of this build at once: raw samples through the GPU augmentation,
+    --latent_grad through the frozen guide, bf16 compute."""
+    from gdn_amd import GDN_main, option
+    monkeypatch.chdir(tmp_path)
+    a = option.parse_args(["synthetic", "--mode", "RtoD", "--synthetic", "--augment", "--latent_grad", "--dtype", "bf16",
+                           "--batch_size", "2", "--epochs", "1", "--epoch_size", "2", "--height", "64", "--width", "128",
+                           "--gpu_num", "0", "--model_dir", "none.pkl"])
+    out = GDN_main.run(a)
+    assert len(out) == 3 and all(torch.isfinite(t) for t in out) and float(out[2].detach()) > 0.0
+
+
+def test_cli_kitti_directory(gpu, tmp_path, monkeypatch):
+    """DtoD from a directory laid out like the reference's KITTI root (datasets_list.py:61-76)."""
+    from PIL import Image
+    from gdn_amd import GDN_main, option
+    r = np.random.RandomState(0)
+    root = tmp_path / "kitti"
+    for scene in ("s1", "s2"):
+        (root / scene / "color_gt2").mkdir(parents=True)
+        (root / scene / "gt").mkdir()
+        for i in range(2):
+            Image.fromarray(r.randint(0, 256, (32, 64, 3)).astype(np.uint8)).save(root / scene / ("%07d.jpg" % i))
+            Image.fromarray(r.randint(0, 256, (32, 64)).astype(np.uint8)).save(root / scene / "color_gt2" / ("%07d.png" % i))
+            Image.fromarray(r.randint(0, 256, (32, 64)).astype(np.uint8)).save(root / scene / "gt" / ("%07d.png" % i))
+    (root / "train.txt").write_text("s1\ns2\n")
+    (root / "val.txt").write_text("s2\n")
+    monkeypatch.chdir(tmp_path)
+    a = option.parse_args([str(root), "--mode", "DtoD", "--batch_size", "2", "--epochs", "1", "--height", "32",
+                           "--width", "64", "--gpu_num", "0", "-e"])
+    loss = GDN_main.run(a)
+    assert torch.isfinite(loss)

@@ -233,9 +233,19 @@ extern "C" size_t gdn_loss_workspace_bytes(int64_t npix) {
     return LOSS_HDR + 2 * LOSS_MAXBLK * sizeof(double) + 2 * (size_t)npix * sizeof(float);
 }
 
+// max |a - b| over n elements -> *max_out (device float).  A non-negative float's bit pattern orders like the float,
+// so the atomicMax on bits IS the float max; exposed so a data-parallel run can all-reduce(MAX) the 4 bytes.
+extern "C" int gdn_absdiff_max(const float* a, const float* b, int64_t n, float* max_out, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    if (!a || !b || !max_out || n <= 0) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, ST(stream), (unsigned*)max_out);
+    hipLaunchKernelGGL(absdiff_max_kernel, dim3(loss_blocks(n)), dim3(256), 0, ST(stream), a, b, n, (unsigned*)max_out);
+    return gdn_launch_status();
+}
+
 extern "C" int gdn_berhu_masked(const float* out, const float* gt, const float* sparse, int32_t Cs, int32_t B, int32_t H,
-                                int32_t W, const int32_t box[4], float* loss, float* dout, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                int32_t W, const int32_t box[4], const float* ext_max, float* loss, float* dout,
+                                void* workspace, size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!out || !gt || !loss || B <= 0 || H <= 0 || W <= 0) return GDN_ERR_BAD_ARG;
     const int64_t n = (int64_t)B * H * W;
@@ -244,10 +254,12 @@ extern "C" int gdn_berhu_masked(const float* out, const float* gt, const float* 
     const int nb = loss_blocks(n);
     int y1 = 0, y2 = H, x1 = 0, x2 = W;
     if (box) { y1 = box[0]; y2 = box[1]; x1 = box[2]; x2 = box[3]; }
-    hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, ST(stream), w.maxbits);
-    hipLaunchKernelGGL(absdiff_max_kernel, dim3(nb), dim3(256), 0, ST(stream), out, gt, n, w.maxbits);
+    if (!ext_max) {
+        hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, ST(stream), w.maxbits);
+        hipLaunchKernelGGL(absdiff_max_kernel, dim3(nb), dim3(256), 0, ST(stream), out, gt, n, w.maxbits);
+    }
     hipLaunchKernelGGL(berhu_kernel, dim3(nb), dim3(256), 0, ST(stream), out, gt, sparse, Cs, B, H, W, y1, y2, x1, x2,
-                       (const unsigned*)w.maxbits, w.part, dout);
+                       ext_max ? (const unsigned*)ext_max : (const unsigned*)w.maxbits, w.part, dout);
     hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)w.part, nb,
                        3.0 / (double)n, 0, loss);
     return gdn_launch_status();

@@ -18,10 +18,13 @@ from . import engine as E
 from ._lib import GdnError
 
 
-def _check_norm(norm):
-    if norm != 'Batch':
-        raise NotImplementedError("norm=%r: only 'Batch' is implemented on the HIP path" % (norm,))
-    print("- norm : Batch")
+def _check_norm(norm, reaches_layers=False):
+    """The reference's AutoEncoder_2 / AutoEncoder_DtoD only PRINT the norm (AE_model_unet.py:266-269, :488-491):
+    their blocks are built without it and are always BatchNorm, so 'Instance' changes nothing there.  Only the legacy
+    AutoEncoder instantiates InstanceNorm layers (:136-155), which the HIP path does not implement."""
+    if norm != 'Batch' and reaches_layers:
+        raise NotImplementedError("norm=%r: InstanceNorm layers are not implemented on the HIP path" % (norm,))
+    print("- norm : Batch" if norm == 'Batch' else "- norm : Instance")
 
 
 class _HipModule(nn.Module):
@@ -354,7 +357,7 @@ class AutoEncoder(_HipModule):
         self.conv1x1_128 = nn.Conv2d(256, 128, kernel_size=1, stride=1, padding=0, bias=False)
         self.conv1x1_256 = nn.Conv2d(512, 256, kernel_size=1, stride=1, padding=0, bias=False)
         self.upsampling = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
-        _check_norm(norm)
+        _check_norm(norm, reaches_layers=True)
         for name, c in (("N64_down", 64), ("N128_down", 128), ("N256_down", 256), ("N512_down", 512),
                         ("N64_up", 64), ("N128_up", 128), ("N256_up", 256)):
             setattr(self, name, nn.BatchNorm2d(c, affine=True, track_running_stats=True))

@@ -39,6 +39,8 @@ def run(args, train_loader=None, val_loader=None):
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
     torch.manual_seed(args.seed)          # identical init on every rank
+    from . import utils as _U
+    _U.GLOBAL_BERHU = bool(getattr(args, "global_berhu", False))
     H, W = args.height, args.width
     if rank == 0:
         print('=> number of GPU processes: ', world)

@@ -60,7 +60,8 @@ _SIGS = {
     "gdn_tanh_bwd": (c_int32, [_P, _P, _P, _i64, _P]),
     "gdn_fill": (c_int32, [_P, _f, _i64, _P]),
     "gdn_loss_workspace_bytes": (_sz, [_i64]),
-    "gdn_berhu_masked": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, POINTER(c_int32), _P, _P, _P, _sz, _P]),
+    "gdn_absdiff_max": (c_int32, [_P, _P, _i64, _P, _P]),
+    "gdn_berhu_masked": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, POINTER(c_int32), _P, _P, _P, _P, _sz, _P]),
     "gdn_sobel_l1": (c_int32, [_P, _P, _i32, _i32, _i32, _f, _P, _P, _P, _sz, _P]),
     "gdn_smoothness": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P, _P, _P, _sz, _P]),
     "gdn_mse": (c_int32, [_P, _P, _i64, _f, _i32, _P, _P, _sz, _i32, _P]),

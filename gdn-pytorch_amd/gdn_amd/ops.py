@@ -325,13 +325,20 @@ def _loss_ws(npix, device):
     return workspace(nb, device, "loss"), nb
 
 
-def berhu_masked(out, gt, sparse, box, dout, loss):
+def absdiff_max(a, b):
+    """max|a-b| as a device scalar (the BerHu threshold's maximum; all-reduce it for --global_berhu)."""
+    m = torch.empty((), dtype=torch.float32, device=a.device)
+    lib.gdn_absdiff_max(_p(a), _p(b), a.numel(), _p(m), stream())
+    return m
+
+
+def berhu_masked(out, gt, sparse, box, dout, loss, ext_max=None):
     """out/gt [B,1,H,W]; sparse [B,Cs,H,W] or None; adds the gradient into dout; writes loss[()]."""
     B, _, H, W = out.shape
     ws, nb = _loss_ws(B * H * W, out.device)
     cbox = (ctypes.c_int32 * 4)(*box) if box is not None else None
     lib.gdn_berhu_masked(_p(out), _p(gt), _p(sparse), 0 if sparse is None else sparse.shape[1], B, H, W, cbox,
-                         _p(loss), _p(dout), _p(ws), nb, stream())
+                         _p(ext_max), _p(loss), _p(dout), _p(ws), nb, stream())
 
 
 def sobel_l1(pred, gt, weight, dpred, loss):

@@ -42,6 +42,20 @@ def crop_box_kitti(H, W):
     return (int(0.40810811 * H), int(0.99189189 * H), int(0.03594771 * W), int(0.96405229 * W))
 
 
+# --global_berhu: take the BerHu threshold's max|out-gt| over ALL ranks' shards (4-byte all-reduce MAX),
+# which is what nn.DataParallel's gathered batch gives the reference; default: each rank's own shard.
+GLOBAL_BERHU = False
+
+
+def _berhu(p, g, sparse, box, dp, loss):
+    ext = None
+    if GLOBAL_BERHU:
+        from . import distributed as D
+        if D.world_size() > 1:
+            ext = D.allreduce_max_scalar(ops.absdiff_max(p, g))
+    ops.berhu_masked(p, g, sparse, box, dp, loss, ext_max=ext)
+
+
 class _PixelLoss(torch.autograd.Function):
     """loss = f(pred, *consts); the kernel that evaluates f also writes dloss/dpred."""
 
@@ -53,7 +67,7 @@ class _PixelLoss(torch.autograd.Function):
         dp = ops.zeros(p.shape, p.device) if need else None
         if kind == "berhu":
             gt, sparse, box = args
-            ops.berhu_masked(p, _c1(gt, "gt"), None if sparse is None else _nchw(sparse, "sparse"), box, dp, loss)
+            _berhu(p, _c1(gt, "gt"), None if sparse is None else _nchw(sparse, "sparse"), box, dp, loss)
         elif kind == "sobel":
             gt, weight = args
             ops.sobel_l1(p, _c1(gt, "gt"), weight, dp, loss)
@@ -63,12 +77,12 @@ class _PixelLoss(torch.autograd.Function):
         elif kind == "dtod":          # BerHu + 3*Sobel in one gradient buffer
             gt, sparse, box, parts = args
             g = _c1(gt, "gt")
-            ops.berhu_masked(p, g, None if sparse is None else _nchw(sparse, "sparse"), box, dp, parts[0])
+            _berhu(p, g, None if sparse is None else _nchw(sparse, "sparse"), box, dp, parts[0])
             ops.sobel_l1(p, g, 3.0, dp, parts[1])
             torch.add(parts[0], parts[1], out=loss)
         elif kind == "rtod":          # BerHu + smoothness
             gt, sparse, box, img, parts = args
-            ops.berhu_masked(p, _c1(gt, "gt"), None if sparse is None else _nchw(sparse, "sparse"), box, dp, parts[0])
+            _berhu(p, _c1(gt, "gt"), None if sparse is None else _nchw(sparse, "sparse"), box, dp, parts[0])
             ops.smoothness(p, _nchw(img, "img"), dp, parts[1])
             torch.add(parts[0], parts[1], out=loss)
         else:

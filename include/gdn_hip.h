@@ -217,10 +217,15 @@ int gdn_fill(float* p, float value, int64_t n, void* stream);
  * ---------------------------------------------------------------------- */
 /* Masked BerHu, trainer.py:433-448 == :705-720.  out/gt [B,1,H,W];
  * sparse [B,Cs,H,W] NCHW (channel 0 used) or NULL; box = {y1,y2,x1,x2}.
- * loss = 3*mean(w*rho).  workspace >= gdn_loss_workspace_bytes(). */
+ * loss = 3*mean(w*rho).  workspace >= gdn_loss_workspace_bytes().
+ * ext_max: NULL = the threshold c = 0.2*max|out-gt| is taken over THIS batch (one reference run, and what
+ * each rank of the data-parallel build does); a device float = use that maximum instead -- the value of
+ * gdn_absdiff_max after a 4-byte all-reduce(MAX), which reproduces nn.DataParallel's threshold over the
+ * gathered batch (--global_berhu). */
 size_t gdn_loss_workspace_bytes(int64_t npix);
+int gdn_absdiff_max(const float* a, const float* b, int64_t n, float* max_out, void* stream);
 int gdn_berhu_masked(const float* out, const float* gt, const float* sparse, int32_t Cs,
-                     int32_t B, int32_t H, int32_t W, const int32_t box[4],
+                     int32_t B, int32_t H, int32_t W, const int32_t box[4], const float* ext_max,
                      float* loss, float* dout, void* workspace, size_t workspace_bytes, void* stream);
 /* Sobel L1, utils.py:105-131 with the factor 3 of trainer.py:453 passed as `weight`. */
 int gdn_sobel_l1(const float* pred, const float* gt, int32_t B, int32_t H, int32_t W, float weight,

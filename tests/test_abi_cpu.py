@@ -83,8 +83,13 @@ def test_no_cpu_fallback():
         m(torch.zeros(1, 1, 32, 64))
     with pytest.raises((GdnError, RuntimeError)):
         U.imgrad_loss(torch.zeros(1, 1, 8, 8, requires_grad=True), torch.zeros(1, 1, 8, 8))
+    # the reference's R and G only print the norm (AE_model_unet.py:266-269): 'Instance' still builds BatchNorm blocks
+    r = M.AutoEncoder_2(norm='Instance', height=32, width=64)
+    assert isinstance(r.downconv1.main[2], torch.nn.BatchNorm2d)
     with pytest.raises(NotImplementedError):
-        M.AutoEncoder_2(norm='Instance')
+        M.AutoEncoder(norm='Instance')               # the legacy net does instantiate InstanceNorm layers (:136-155)
+    with pytest.raises(NotImplementedError):
+        M.ConvBlock(3, 8, 3, 1, norm='Instance')
 
 
 def test_tap_major_arena_layout():

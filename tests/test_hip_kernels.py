@@ -316,3 +316,26 @@ def test_adam_matches_oracle(gpu):
         O.adam_step(params, {"w": gr}, st, lr=2e-5)
         ops.adam_step(pd, (gr * 2).to(gpu), m, v, 2e-5, 0.9, 0.999, 1e-8, 5e-4, step, grad_scale=0.5)
     close(pd, params["w"], rtol=1e-6, atol_scale=1e-7, what="adam")
+
+
+def test_berhu_external_max(gpu):
+    """--global_berhu: gdn_absdiff_max + the threshold maximum supplied from outside (after an all-reduce MAX)."""
+    from gdn_amd import ops
+    g = torch.Generator().manual_seed(8)
+    out = (torch.rand(2, 1, 16, 24, generator=g) * 2 - 1).to(gpu)
+    gt = (torch.rand(2, 1, 16, 24, generator=g) * 2 - 1).to(gpu)
+    m = ops.absdiff_max(out, gt)
+    assert float(m) == float((out - gt).abs().max())
+    l0, l1, l2 = (torch.empty((), device=gpu) for _ in range(3))
+    d0, d1, d2 = (torch.zeros_like(out) for _ in range(3))
+    ops.berhu_masked(out, gt, None, None, d0, l0)
+    ops.berhu_masked(out, gt, None, None, d1, l1, ext_max=m)
+    assert float(l0) == float(l1) and torch.equal(d0, d1)
+    big = (m * 1.5).clone()                       # another rank saw a larger error: the threshold moves
+    ops.berhu_masked(out, gt, None, None, d2, l2, ext_max=big)
+    ref = O.berhu_masked(out.cpu(), gt.cpu())      # oracle with its own max ...
+    assert float(l0) == pytest.approx(float(ref), rel=1e-5)
+    dd = (out - gt).cpu()
+    c = 0.2 * float(big)
+    rho = torch.where(dd.abs() > c, (dd * dd + c * c) / (2 * c), dd.abs())
+    assert float(l2) == pytest.approx(float(3 * rho.mean()), rel=1e-5)      # ... and the formula with the external one

@@ -598,6 +598,276 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const IgemmParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// Row-patch bf16 kernel for the stride-1 layers with k >= 3 (the residual blocks: 80 % of the FLOPs).
+// At bf16 MFMA speed the tap-major kernel above is bound by L2->LDS traffic: a 128x64 tile pulls 24.5 KB per
+// 1 MFLOP, ~14.5 TB/s at the measured rate on the 9x9 layers.  Here a workgroup owns 256 consecutive output
+// pixels (flattened over image rows) and, per filter ROW and 64-channel slab, stages the input rows those
+// pixels need -- each with its k-1 halo, <= 288 positions -- in LDS ONCE; the k taps of the row are the same
+// image read at a shifted row address, so activations are fetched k times instead of k*k times and only the
+// weight tile (BN x 64 channels per tap) streams.  Traffic per FLOP drops 2.4x (3x3) to 4x (9x9).
+// Same fragment byte geometry, epilogues (BN statistics, residual, tanh) and XCD mapping as conv_igemm_bf16.
+// ---------------------------------------------------------------------------
+#define RP_BM 256
+#define RP_PMAX 288          // staged positions: 256 pixels + (k-1) halo per touched image row
+#define RP_NRMAX 12          // image rows a 256-pixel tile may touch (W >= 26)
+#define RP_KMAX 9
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_rowpatch_bf16(const IgemmParams p) {
+    constexpr int BM = RP_BM, KC = 64, PITCH = 144;                  // bytes per staged row (128 data + 16 pad)
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int AV = RP_PMAX * 8 / 256, BV = BN * 8 / 256;         // 16-B loads per thread: patch, weight tile
+    __shared__ __attribute__((aligned(16))) unsigned char As[RP_PMAX * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * PITCH];
+    __shared__ int row_out[BM];
+    __shared__ int rowoff[RP_KMAX][RP_NRMAX];        // byte offset of input row (filter row, patch row) or -1
+    __shared__ int rbase[RP_NRMAX + 1];              // first patch position of each touched image row
+    __shared__ int rxlo[RP_NRMAX];                   // first output column of the tile in that row
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const IgemmPhase ph = p.ph[0];
+    const int bid = blockIdx.x, xcd = bid & 7, q8 = bid >> 3;
+    const int per_xcd = (p.grid_m + 7) >> 3;
+    const int nt = q8 % p.grid_n, mt = xcd * per_xcd + q8 / p.grid_n;
+    if (q8 / p.grid_n >= per_xcd || mt >= p.grid_m) return;
+    const int Wo = ph.Wo, Ho = ph.Ho;
+    const int M = p.B * Ho * Wo;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int slot = mt;
+    const int ntap = ph.tap_end - ph.tap_begin;
+    int kw = 1;                                       // taps per filter row (consecutive taps sharing tdy)
+    while (kw < ntap && p.tdy[ph.tap_begin + kw] == p.tdy[ph.tap_begin]) ++kw;
+    const int kh = ntap / kw;
+    int dxmin = p.tdx[ph.tap_begin];
+    for (int t = 1; t < kw; ++t) dxmin = min(dxmin, (int)p.tdx[ph.tap_begin + t]);
+    const int mlast = min(m0 + BM, M) - 1;
+    const int row0 = m0 / Wo, nrows = mlast / Wo - row0 + 1;
+    const int b_first = row0 / Ho;
+
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        if (m < M) {
+            const int ox = m % Wo, t = m / Wo, oy = t % Ho, b = t / Ho;
+            row_out[r] = (b * p.Hy + oy * p.osy + ph.oy0) * p.Wy + ox * p.osx + ph.ox0;
+        } else row_out[r] = -1;
+    }
+    if (tid <= nrows) {
+        // pixels of the tile that precede row j: 0 for j = 0, else (Wo - xlo0) + (j-1)*Wo
+        const int xlo0 = m0 - row0 * Wo;
+        const int before = tid == 0 ? 0 : (Wo - xlo0) + (tid - 1) * Wo;
+        rbase[tid] = (tid == nrows ? min(BM, M - m0) : before) + tid * (kw - 1);
+        if (tid < nrows) rxlo[tid] = tid == 0 ? xlo0 : 0;
+    }
+    for (int i = tid; i < kh * RP_NRMAX; i += 256) {
+        const int ky = i / RP_NRMAX, j = i - ky * RP_NRMAX;
+        int off = -1;
+        if (j < nrows) {
+            const int t = row0 + j, oy = t % Ho, b = t / Ho;
+            int iy = oy * p.stride + p.tdy[ph.tap_begin + ky * kw];
+            if (p.pad_mode == 1) iy = reflect_idx(iy, p.Hi);
+            if ((unsigned)iy < (unsigned)p.Hi) off = (((b - b_first) * p.Hi + iy) * p.Wi) * p.ldx1 * 2;
+        }
+        rowoff[ky][j] = off;
+    }
+    __syncthreads();
+
+    // ---- staging constants ----
+    const unsigned OOB = 0xFFFFFF00u;
+    const unsigned lane_b = (unsigned)(tid & 7) * 16u;
+    const int pos0 = tid >> 3;
+    const int npatch = rbase[nrows];
+    unsigned pk_x[AV]; int pk_j[AV];
+#pragma unroll
+    for (int e = 0; e < AV; ++e) {
+        const int q = pos0 + 32 * e;
+        int j = 0;
+        for (int jj = 1; jj < nrows; ++jj) j += (q >= rbase[jj]) ? 1 : 0;
+        int ix = rxlo[j] + dxmin + (q - rbase[j]);
+        if (p.pad_mode == 1) ix = reflect_idx(ix, p.Wi);
+        const bool ok = q < npatch && (unsigned)ix < (unsigned)p.Wi;
+        pk_x[e] = ok ? (unsigned)(ix * p.ldx1) * 2u + lane_b : OOB;
+        pk_j[e] = j;
+    }
+    const unsigned long long img1 = (unsigned long long)p.Hi * p.Wi * p.ldx1 * 2ull * b_first;
+    const unsigned long long rem1 = p.x_bytes - img1, cap = 0xFF000000ull;
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x) + img1), 0, (int)(unsigned)(rem1 < cap ? rem1 : cap), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+    unsigned boff[BV];
+#pragma unroll
+    for (int e = 0; e < BV; ++e) {
+        const int n = n0 + e * 32 + pos0;
+        boff[e] = n < p.N ? (unsigned)(n * p.Cred) * 2u + lane_b : OOB;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // A fragment rows: pixel r of the tile sits at patch row r + j(r)*(kw-1)
+    unsigned arow[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * TM * 32 + i * 32 + (lane & 31);
+        int j = 0;
+        const int m = min(m0 + r, mlast);
+        j = m / Wo - row0;
+        arow[i] = (unsigned)(min(r, mlast - m0) + j * (kw - 1)) * PITCH + (unsigned)(lane >> 5) * 64u;
+    }
+    const unsigned brow = (unsigned)(wn * TN * 32 + (lane & 31)) * PITCH + (unsigned)(lane >> 5) * 64u;
+
+    const int nchunks = p.Cred / KC;
+    const int nstage = kh * nchunks;                 // (filter row, channel slab)
+    f32x4 ra[AV], rb[BV];
+    auto load_a = [&](int stage) {
+        const int ky = stage / nchunks, ci0 = (stage - ky * nchunks) * KC;
+#pragma unroll
+        for (int e = 0; e < AV; ++e) {
+            const int ro = rowoff[ky][pk_j[e]];
+            const unsigned vo = (ro >= 0 && pk_x[e] != OOB) ? (unsigned)ro + pk_x[e] : OOB;
+            ra[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, ci0 * 2, 0));
+        }
+    };
+    auto load_b = [&](int stage, int kx) {
+        const int ky = stage / nchunks, ci0 = (stage - ky * nchunks) * KC;
+        const int wi = p.twi[ph.tap_begin + ky * kw + kx];
+        const int soff = (wi * p.w_tap_stride + ci0) * 2;
+#pragma unroll
+        for (int e = 0; e < BV; ++e)
+            rb[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, boff[e], soff, 0));
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int e = 0; e < AV; ++e)
+            *reinterpret_cast<f32x4*>(&As[(pos0 + 32 * e) * PITCH + (tid & 7) * 16]) = ra[e];
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int e = 0; e < BV; ++e)
+            *reinterpret_cast<f32x4*>(&Bs[(pos0 + 32 * e) * PITCH + (tid & 7) * 16]) = rb[e];
+    };
+
+    // Pipeline: a tap step is only 16-32 MFMAs (0.5-1k cycles) against ~2.5k cycles of load latency, so loads run
+    // ahead of their use: the next stage's patch is requested at the FIRST tap of the current stage (its registers are
+    // idle until the stage ends anyway) and weight tiles two taps ahead (two register sets, alternating).
+    const int nsteps = nstage * kw;
+    auto load_b_step = [&](int step, f32x4* dst) {
+        const int stage = step / kw, kx = step - stage * kw;
+        const int ky = stage / nchunks, ci0 = (stage - ky * nchunks) * KC;
+        const int wi = p.twi[ph.tap_begin + ky * kw + kx];
+        const int soff = (wi * p.w_tap_stride + ci0) * 2;
+#pragma unroll
+        for (int e = 0; e < BV; ++e)
+            dst[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, boff[e], soff, 0));
+    };
+    auto store_b_from = [&](const f32x4* src) {
+#pragma unroll
+        for (int e = 0; e < BV; ++e)
+            *reinterpret_cast<f32x4*>(&Bs[(pos0 + 32 * e) * PITCH + (tid & 7) * 16]) = src[e];
+    };
+    f32x4 rb2[BV];
+    load_a(0);
+    load_b_step(0, rb);
+    store_a();
+    store_b_from(rb);
+    if (nsteps > 1) load_b_step(1, rb);
+    if (nsteps > 2) load_b_step(2, rb2);
+    __syncthreads();
+    auto step_body = [&](int step, f32x4* cur_next, f32x4* refill) {
+        // cur_next holds the weight tile of step+1 (already requested); refill receives step+3's
+        const int stage = step / kw, kx = step - stage * kw;
+        if (kx == 0 && stage + 1 < nstage) load_a(stage + 1);
+        const unsigned ashift = (unsigned)(p.tdx[ph.tap_begin + (stage / nchunks) * kw + kx] - dxmin) * PITCH;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&As[arow[i] + ashift + g * 16]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&Bs[brow + j * 32 * PITCH + g * 16]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (step + 1 < nsteps) {
+            if (kx + 1 == kw) store_a();
+            store_b_from(cur_next);
+            if (step + 3 < nsteps) load_b_step(step + 3, refill);
+            __syncthreads();
+        }
+    };
+    for (int step = 0; step < nsteps; step += 2) {
+        step_body(step, rb, rb);              // consumes rb (step+1), refills rb with step+3
+        if (step + 1 < nsteps) step_body(step + 1, rb2, rb2);   // consumes rb2 (step+2), refills rb2 with step+4
+    }
+
+    // ---- epilogue (as conv_igemm_bf16) ----
+    const int col_l = lane & 31, rsh = 4 * (lane >> 5);
+    if (p.stats) {
+        float* red = reinterpret_cast<float*>(As);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + rsh;
+                    const float v = row_out[row] >= 0 ? acc[i][j][r] : 0.f;
+                    s1 += v; s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) {
+                const int c = wn * TN * 32 + j * 32 + lane;
+                red[(wm * BN + c) * 2 + 0] = s1;
+                red[(wm * BN + c) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int wmi = 0; wmi < WAVES_M; ++wmi) { s1 += red[(wmi * BN + tid) * 2]; s2 += red[(wmi * BN + tid) * 2 + 1]; }
+            p.stats[((size_t)slot * 2 + 0) * p.N + n0 + tid] = s1;
+            p.stats[((size_t)slot * 2 + 1) * p.N + n0 + tid] = s2;
+        }
+    }
+    unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
+    const unsigned short* ad = reinterpret_cast<const unsigned short*>(p.addsrc);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + rsh;
+            const int op = row_out[row];
+            if (op < 0) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+                if (n < p.N) {
+                    float v = acc[i][j][r];
+                    if (ad) v += bf16_to_f32(ad[(size_t)op * p.ld_add + n]);
+                    if (p.act == GDN_ACT_TANH) v = tanhf(v);
+                    yo[(size_t)op * p.ldy + n] = f32_to_bf16(v);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Host side: geometry -> phases / tap lists, tile selection, launch.
 // ---------------------------------------------------------------------------
 // Second stage of a split-K launch: y = act(sum_z part[z] + addsrc), plus the per-block BatchNorm
@@ -656,12 +926,42 @@ const uint64_t kMaxBufBytes = 0xFF000000ull;
 
 struct TileCfg { int bm, bn; };
 // cfg ids: 1: 128x128  2: 128x64  3: 64x64  4: 128x32  (5: scalar-gather 128x64)  6: 32x128  7: 64x128
-#define NUM_CFG 8
-const TileCfg kCfg[NUM_CFG] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 64}, {32, 128}, {64, 128}};
+//          8: row-patch 256x128  9: row-patch 256x64 (bf16, stride-1 layers with k >= 3)
+#define NUM_CFG 10
+const TileCfg kCfg[NUM_CFG] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 64}, {32, 128}, {64, 128},
+                               {256, 128}, {256, 64}};
+
+// Row-patch kernel eligibility (geometry only, so the slot/workspace queries agree with the launch): one phase,
+// stride 1, >= 3 taps per filter row with consecutive dx, 64-channel slabs, and a 256-pixel tile whose touched
+// image rows + halos fit the staged patch.
+bool rowpatch_ok(const IgemmParams& P) {
+    if (P.nphase != 1 || P.stride != 1 || (P.Cred % 64)) return false;
+    const IgemmPhase& ph = P.ph[0];
+    const int ntap = ph.tap_end - ph.tap_begin;
+    int kw = 1;
+    while (kw < ntap && P.tdy[ph.tap_begin + kw] == P.tdy[ph.tap_begin]) ++kw;
+    if (kw < 3 || kw > RP_KMAX || ntap % kw || ntap / kw > RP_KMAX) return false;
+    for (int r = 0; r < ntap / kw; ++r) {
+        int lo = P.tdx[ph.tap_begin + r * kw], hi = lo;
+        for (int t = 0; t < kw; ++t) {
+            const int i = ph.tap_begin + r * kw + t;
+            if (P.tdy[i] != P.tdy[ph.tap_begin + r * kw]) return false;
+            lo = P.tdx[i] < lo ? P.tdx[i] : lo; hi = P.tdx[i] > hi ? P.tdx[i] : hi;
+        }
+        if (hi - lo != kw - 1) return false;
+    }
+    const int nrows_max = (RP_BM - 1 + ph.Wo - 1) / ph.Wo + 1;
+    return nrows_max <= RP_NRMAX && RP_BM + nrows_max * (kw - 1) <= RP_PMAX;
+}
 
 // bf16: the MFMA is 16x faster, so tiles must be large enough to amortise the staging of a k-step.
-int pick_cfg_bf16(int64_t M, int N, int forced) {
+int pick_cfg_bf16(const IgemmParams& P, int64_t M, int N, int forced) {
+    const bool rp = rowpatch_ok(P);
     if (forced >= 1 && forced <= 3) return forced;
+    if ((forced == 8 || forced == 9) && rp) return forced;
+    // measured (profiles/r01_tune_conv_bf16_rowpatch.txt): the row-patch kernel wins on the 64-channel 9x9 layers
+    // (256x64 tiles, 2 workgroups/CU); its 256x128 form runs at 1 workgroup/CU and loses to the tap-major tiles
+    if (rp && N <= 64 && cdiv64(M, RP_BM) >= 448) return 9;
     if (N <= 64) return 2;
     return cdiv64(M, 128) * cdiv(N, 128) >= 384 ? 1 : 3;
 }
@@ -677,8 +977,10 @@ int pick_cfg_f32(int64_t M, int N, bool scalar, int forced) {
 }
 
 #define CFG_BF16 0x10000     // GDN_CFG_BF16 in tile_cfg: tensors hold bf16
-int pick_cfg(int64_t M, int N, bool scalar, int tile_cfg) {
-    return (tile_cfg & CFG_BF16) ? pick_cfg_bf16(M, N, tile_cfg & 0xff) : pick_cfg_f32(M, N, scalar, tile_cfg & 0xff);
+int64_t max_phase_m(const IgemmParams& P);
+int pick_cfg(const IgemmParams& P, int N, bool scalar, int tile_cfg) {
+    const int64_t M = max_phase_m(P);
+    return (tile_cfg & CFG_BF16) ? pick_cfg_bf16(P, M, N, tile_cfg & 0xff) : pick_cfg_f32(M, N, scalar, tile_cfg & 0xff);
 }
 
 // Builds the phase decomposition of a "transposed-type" gather:
@@ -755,7 +1057,7 @@ void launch_one(const IgemmParams& P, hipStream_t st) {
 // drew three.  Splitting the taps 3-4 ways gives every CU ~8 smaller units (and the level-3 layers four
 // rounds instead of 1.35); the partials cost one extra pass over the (small) output.
 int pick_ksplit(const IgemmParams& P, int cfg, bool scalar, int tile_cfg) {
-    if (scalar || (P.N % 4) || cfg == 4 || (tile_cfg & 0x800)) return 1;
+    if (scalar || (P.N % 4) || cfg == 4 || cfg >= 8 || (tile_cfg & 0x800)) return 1;
     const TileCfg tc = kCfg[cfg];
     const int64_t blocks = cdiv64(cdiv64(max_phase_m(P), tc.bm), 8) * 8 * cdiv(P.N, tc.bn) * P.nphase;
     if (blocks >= 1200) return 1;      // measured: splitting only pays below ~one round of resident workgroups
@@ -792,6 +1094,8 @@ int launch_igemm(IgemmParams& P, int cfg, hipStream_t st, int ksplit = 1, void* 
             case 1: hipLaunchKernelGGL((conv_igemm_bf16<128, 128, 2, 2>), grid, dim3(256), 0, st, P); break;
             case 2: hipLaunchKernelGGL((conv_igemm_bf16<128, 64, 2, 2>), grid, dim3(256), 0, st, P); break;
             case 3: hipLaunchKernelGGL((conv_igemm_bf16<64, 64, 2, 2>), grid, dim3(256), 0, st, P); break;
+            case 8: hipLaunchKernelGGL((conv_rowpatch_bf16<128, 2, 2>), dim3(gm_pad * P.grid_n), dim3(256), 0, st, P); break;
+            case 9: hipLaunchKernelGGL((conv_rowpatch_bf16<64, 4, 1>), dim3(gm_pad * P.grid_n), dim3(256), 0, st, P); break;
             default: return GDN_ERR_BAD_ARG;
         }
     } else
@@ -915,7 +1219,7 @@ extern "C" int64_t gdn_conv_stats_slots(const gdn_conv_geom* g, int32_t tile_cfg
     IgemmParams P{};
     if (fill_fwd(g, P) != GDN_OK) return GDN_ERR_BAD_ARG;
     const bool scalar = (g->Cin % KC_MIN) != 0;
-    const int cfg = pick_cfg(max_phase_m(P), g->Cout, scalar, tile_cfg);
+    const int cfg = pick_cfg(P, g->Cout, scalar, tile_cfg);
     if (pick_ksplit(P, cfg, scalar, tile_cfg) > 1) return cdiv64((int64_t)P.B * P.Hy * P.Wy, SK_ROWS);
     return (int64_t)P.nphase * cdiv64(max_phase_m(P), kCfg[cfg].bm);
 }
@@ -924,7 +1228,7 @@ extern "C" size_t gdn_conv_fwd_workspace_bytes(const gdn_conv_geom* g, int32_t t
     IgemmParams P{};
     if (fill_fwd(g, P) != GDN_OK) return 0;
     const bool scalar = (g->Cin % KC_MIN) != 0;
-    const int cfg = pick_cfg(max_phase_m(P), g->Cout, scalar, tile_cfg);
+    const int cfg = pick_cfg(P, g->Cout, scalar, tile_cfg);
     return ksplit_bytes(P, pick_ksplit(P, cfg, scalar, tile_cfg));
 }
 
@@ -966,7 +1270,9 @@ extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const void* xv, int32_t ldx,
     }
     // 32-channel slabs measured faster than 64 everywhere (6 waves/SIMD vs 4); 0x200 selects 64 for tuning runs
     P.kc = (!scalar && g->Cin % 64 == 0 && C1 % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
-    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg);
+    const int cfg = pick_cfg(P, P.N, scalar, tile_cfg);
+    // the row-patch kernel reads one input tensor; a fused concat with k >= 3 has no call site in the networks
+    if (cfg >= 8 && x2) return GDN_ERR_UNSUPPORTED;
     const int ksplit = pick_ksplit(P, cfg, scalar, tile_cfg);
     if (ksplit > 1 && (!workspace || workspace_bytes < ksplit_bytes(P, ksplit))) return GDN_ERR_WORKSPACE;
     if (ksplit > 1 && ((ldy % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
@@ -1006,7 +1312,7 @@ extern "C" size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g, int32_t
     IgemmParams P{};
     bool fold, scalar;
     if (!fill_dgrad(g, P, fold, scalar)) return 0;
-    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg);
+    const int cfg = pick_cfg(P, P.N, scalar, tile_cfg);
     return (fold ? fold_bytes(g) : 0) + ksplit_bytes(P, pick_ksplit(P, cfg, scalar, tile_cfg));
 }
 
@@ -1034,7 +1340,7 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t l
     if (bf && (scalar || (g->Cout % 64) || (ldy % 8) || (g->Cin % 4))) return GDN_ERR_UNSUPPORTED;
     P.bf16 = bf ? 1 : 0;
     if (fold && (g->Cin % 4) && bf) return GDN_ERR_UNSUPPORTED;
-    const int cfg = pick_cfg(max_phase_m(P), P.N, scalar, tile_cfg);
+    const int cfg = pick_cfg(P, P.N, scalar, tile_cfg);
     const int ksplit = pick_ksplit(P, cfg, scalar, tile_cfg);
     const size_t fb = fold ? fold_bytes(g) : 0, need = fb + ksplit_bytes(P, ksplit);
     if (need && (!workspace || workspace_bytes < need)) return GDN_ERR_WORKSPACE;

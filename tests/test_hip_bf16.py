@@ -29,6 +29,12 @@ BF16_CASES = [
     ("ctb_k4s2", 512, 256, 4, 2, 1, False, True, 2, 8, 12),
     ("ctb_k4s2_b", 128, 64, 4, 2, 1, False, True, 2, 6, 10),
     ("big_m_128x128", 128, 256, 3, 1, 1, False, False, 4, 64, 104),
+    # shapes the row-patch kernel accepts (stride 1, k >= 3, 256-pixel tiles over 2-9 image rows, ragged last tile)
+    ("rp_k9_64", 64, 64, 9, 1, 4, False, False, 1, 24, 128),
+    ("rp_k7_refl", 128, 64, 7, 1, 3, True, False, 1, 12, 64),
+    ("rp_k5", 64, 128, 5, 1, 2, False, False, 2, 10, 40),
+    ("rp_convt_k3", 128, 64, 3, 1, 1, False, True, 2, 16, 32),
+    ("rp_k3_w26", 128, 192, 3, 1, 1, False, False, 3, 8, 26),
 ]
 
 
@@ -55,9 +61,11 @@ def test_conv_bf16_fwd_dgrad(gpu, case):
     yr = y_ref.detach().double()
     close(st[:, 0, :].double().sum(0).cpu(), yr.sum((0, 2, 3)), rtol=1e-3, atol_scale=1e-3, what=name + " stats sum")
     close(st[:, 1, :].double().sum(0).cpu(), (yr * yr).sum((0, 2, 3)), what=name + " stats sumsq")
-    for cfg in (1, 2, 3):
-        yc = op.fwd(xd, wd, tile_cfg=cfg | 0x800)
+    for cfg in (1, 2, 3, 8, 9):       # 8, 9: row-patch kernel where the geometry allows it (else the automatic choice)
+        yc, stc = op.fwd(xd, wd, stats=True, tile_cfg=cfg | 0x800)
         close(nchw(yc.float()), y_ref, rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=name + " fwd cfg%d" % cfg)
+        close(stc[:, 0, :].double().sum(0).cpu(), yr.sum((0, 2, 3)), rtol=1e-3, atol_scale=1e-3, what=name + " stats sum cfg%d" % cfg)
+        close(stc[:, 1, :].double().sum(0).cpu(), (yr * yr).sum((0, 2, 3)), what=name + " stats sumsq cfg%d" % cfg)
     # data gradient
     gyd = nhwc(gy).to(gpu).bfloat16()
     wt = ops.transpose_taps(tapmajor(w.detach(), tr).to(gpu)).bfloat16()
@@ -67,6 +75,9 @@ def test_conv_bf16_fwd_dgrad(gpu, case):
     add = r16(torch.randn(B, H, W, ci, generator=torch.Generator().manual_seed(2)))
     dx2 = op.dgrad(gyd, wt, (H, W), addsrc=add.to(gpu).bfloat16())
     close(nchw(dx2.float()), x.grad + nchw(add), rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=name + " dgrad+addsrc")
+    for cfg in (8, 9):
+        dx3 = op.dgrad(gyd, wt, (H, W), addsrc=add.to(gpu).bfloat16(), tile_cfg=cfg)
+        close(nchw(dx3.float()), x.grad + nchw(add), rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=name + " dgrad cfg%d" % cfg)
     # weight gradient: bf16 operands, fp32 accumulation and fp32 result -> only the summation order differs
     for cfg in (0, 1):
         dw = torch.full(wd.shape, float("nan"), device=gpu)

@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void conv_rowpatch_bf16(const IgemmParams p) {
 // ---------------------------------------------------------------------------
 // Second stage of a split-K launch: y = act(sum_z part[z] + addsrc), plus the per-block BatchNorm
 // partial statistics the single-stage epilogue would have produced.  64 pixels per workgroup.
-#define SK_ROWS 64
+#define SK_ROWS 16
 __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ part, int ksplit, long long npix,
                                                              int N, void* __restrict__ y, int ldy,
                                                              const void* __restrict__ addsrc, int ld_add, int act,

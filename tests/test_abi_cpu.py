@@ -46,7 +46,7 @@ def test_host_queries_without_gpu(built_lib):
     assert (ho.value, wo.value) == (16, 52)
     assert lib.gdn_conv_stats_slots(ctypes.byref(g), 0x800 | 1) == (20 * 16 * 52 + 127) // 128
     assert lib.gdn_conv_stats_slots(ctypes.byref(g), 0x800) == (20 * 16 * 52 + 63) // 64  # 64x64 tiles, single stage
-    assert lib.gdn_conv_stats_slots(ctypes.byref(g4), 0) == (20 * 8 * 26 + 63) // 64       # split-K: 64 pixels per combine block
+    assert lib.gdn_conv_stats_slots(ctypes.byref(g4), 0) == (20 * 8 * 26 + 15) // 16       # split-K: 16 pixels per combine block
     assert lib.gdn_conv_stats_slots(ctypes.byref(gt), 0x800 | 3) == 4 * ((20 * 8 * 26 + 63) // 64)
     gr = ConvGeom(2, 16, 24, 64, 128, 7, 2, 3, 1, 0)            # reflect-padded strided conv
     assert lib.gdn_conv_dgrad_workspace_bytes(ctypes.byref(gr), 0x800) == 2 * 22 * 30 * 64 * 4   # 0x800: no split-K

@@ -31,6 +31,7 @@ struct IgemmPhase { int Ho, Wo, oy0, ox0, tap_begin, tap_end; };
 
 struct IgemmParams {
     const float* x; const float* x2; const float* w; float* y; const float* addsrc; float* stats;
+    const float* ep_scale; const float* ep_shift;   // optional per-channel affine of the epilogue (eval-mode BN fold)
     int B, Hi, Wi, C1, C2, ldx1, ldx2;
     int N, ldy, ld_add, Hy, Wy, osy, osx;
     int stride, pad_mode, act, nphase;
@@ -341,6 +342,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
             p.stats[((size_t)slot * 2 + 1) * p.N + n0 + tid] = s2;
         }
     }
+    const bool has_affine = p.ep_scale != nullptr;
+    float es[TN], et[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+        es[j] = (has_affine && n < p.N) ? p.ep_scale[n] : 1.f;
+        et[j] = (has_affine && n < p.N) ? p.ep_shift[n] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -353,8 +362,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const IgemmParams p) {
                 const int n = n0 + wn * TN * 32 + j * 32 + col_l;
                 if (n < p.N) {
                     float v = acc[i][j][r];
+                    if (has_affine) v = v * es[j] + et[j];
+                    if (p.act & GDN_ACT_RELU) v = fmaxf(v, 0.f);
                     if (p.addsrc) v += p.addsrc[(size_t)op * p.ld_add + n];
-                    if (p.act == GDN_ACT_TANH) v = tanhf(v);
+                    if (p.act & GDN_ACT_TANH) v = tanhf(v);
                     p.y[(size_t)op * p.ldy + n] = v;
                 }
             }
@@ -576,6 +587,14 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const IgemmParams p) {
     }
     unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
     const unsigned short* ad = reinterpret_cast<const unsigned short*>(p.addsrc);
+    const bool has_affine = p.ep_scale != nullptr;
+    float es[TN], et[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+        es[j] = (has_affine && n < p.N) ? p.ep_scale[n] : 1.f;
+        et[j] = (has_affine && n < p.N) ? p.ep_shift[n] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -588,8 +607,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const IgemmParams p) {
                 const int n = n0 + wn * TN * 32 + j * 32 + col_l;
                 if (n < p.N) {
                     float v = acc[i][j][r];
+                    if (has_affine) v = v * es[j] + et[j];
+                    if (p.act & GDN_ACT_RELU) v = fmaxf(v, 0.f);
                     if (ad) v += bf16_to_f32(ad[(size_t)op * p.ld_add + n]);
-                    if (p.act == GDN_ACT_TANH) v = tanhf(v);
+                    if (p.act & GDN_ACT_TANH) v = tanhf(v);
                     yo[(size_t)op * p.ldy + n] = f32_to_bf16(v);
                 }
             }
@@ -846,6 +867,14 @@ __global__ __launch_bounds__(256) void conv_rowpatch_bf16(const IgemmParams p) {
     }
     unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
     const unsigned short* ad = reinterpret_cast<const unsigned short*>(p.addsrc);
+    const bool has_affine = p.ep_scale != nullptr;
+    float es[TN], et[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+        es[j] = (has_affine && n < p.N) ? p.ep_scale[n] : 1.f;
+        et[j] = (has_affine && n < p.N) ? p.ep_shift[n] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -858,8 +887,10 @@ __global__ __launch_bounds__(256) void conv_rowpatch_bf16(const IgemmParams p) {
                 const int n = n0 + wn * TN * 32 + j * 32 + col_l;
                 if (n < p.N) {
                     float v = acc[i][j][r];
+                    if (has_affine) v = v * es[j] + et[j];
+                    if (p.act & GDN_ACT_RELU) v = fmaxf(v, 0.f);
                     if (ad) v += bf16_to_f32(ad[(size_t)op * p.ld_add + n]);
-                    if (p.act == GDN_ACT_TANH) v = tanhf(v);
+                    if (p.act & GDN_ACT_TANH) v = tanhf(v);
                     yo[(size_t)op * p.ldy + n] = f32_to_bf16(v);
                 }
             }
@@ -876,7 +907,9 @@ __global__ __launch_bounds__(256) void conv_rowpatch_bf16(const IgemmParams p) {
 __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ part, int ksplit, long long npix,
                                                              int N, void* __restrict__ y, int ldy,
                                                              const void* __restrict__ addsrc, int ld_add, int act,
-                                                             float* __restrict__ stats, int bf16) {
+                                                             float* __restrict__ stats, int bf16,
+                                                             const float* __restrict__ ep_scale,
+                                                             const float* __restrict__ ep_shift) {
     __shared__ float sh[256 * 8];
     const int cq = N >> 2;
     const int CQ = cq < 256 ? cq : 256, PY = 256 / CQ;
@@ -893,8 +926,13 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
                 for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + z * zs + (size_t)pix * N + c);
                 s1 += v;
                 s2 += v * v;
+                if (ep_scale) v = v * *reinterpret_cast<const f32x4*>(ep_scale + c) + *reinterpret_cast<const f32x4*>(ep_shift + c);
+                if (act & GDN_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
                 if (addsrc) v += ld4_any(addsrc, (size_t)pix * ld_add + c, bf16);
-                if (act == GDN_ACT_TANH) {
+                if (act & GDN_ACT_TANH) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
                 }
@@ -1112,7 +1150,8 @@ int launch_igemm(IgemmParams& P, int cfg, hipStream_t st, int ksplit = 1, void* 
     if (ksplit > 1) {
         const int blocks = (int)cdiv64(P.npix_out, SK_ROWS);
         hipLaunchKernelGGL(splitk_combine_kernel, dim3(blocks), dim3(256), 0, st, (const float*)P.part, ksplit,
-                           P.npix_out, P.N, (void*)P.y, P.ldy, (const void*)P.addsrc, P.ld_add, P.act, P.stats, P.bf16);
+                           P.npix_out, P.N, (void*)P.y, P.ldy, (const void*)P.addsrc, P.ld_add, P.act, P.stats, P.bf16,
+                           P.ep_scale, P.ep_shift);
     }
     return gdn_launch_status();
 }
@@ -1234,15 +1273,16 @@ extern "C" size_t gdn_conv_fwd_workspace_bytes(const gdn_conv_geom* g, int32_t t
 
 extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const void* xv, int32_t ldx, const void* x2v, int32_t ldx2,
                             int32_t C1, const void* wv, void* yv, int32_t ldy, const void* addsrcv, int32_t ld_add,
-                            float* stats, int32_t act, int32_t tile_cfg, void* workspace, size_t workspace_bytes,
-                            void* stream) {
+                            float* stats, const float* ep_scale, const float* ep_shift, int32_t act, int32_t tile_cfg,
+                            void* workspace, size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     const float *x = (const float*)xv, *x2 = (const float*)x2v, *w = (const float*)wv, *addsrc = (const float*)addsrcv;
     float* y = (float*)yv;
     const bool bf = (tile_cfg & CFG_BF16) != 0;
     const uint64_t es = bf ? 2 : 4;
     if (!geom_ok(g) || !x || !w || !y) return GDN_ERR_BAD_ARG;
-    if (g->Cout == 1 && !x2 && !stats && !addsrc && (tile_cfg & ~CFG_BF16) == 0) {
+    if ((ep_scale == nullptr) != (ep_shift == nullptr)) return GDN_ERR_BAD_ARG;
+    if (g->Cout == 1 && !x2 && !stats && !addsrc && !ep_scale && !(act & GDN_ACT_RELU) && (tile_cfg & ~CFG_BF16) == 0) {
         // 1-channel heads: with GDN_CFG_BF16 only x is bf16 -- weights and the depth map stay fp32
         const int rc = gdn_conv_head_fwd(g, x, ldx, w, y, ldy, act, bf ? 1 : 0, stream);
         if (rc != GDN_ERR_UNSUPPORTED || bf) return rc;
@@ -1258,6 +1298,7 @@ extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const void* xv, int32_t ldx,
     if (bf && ((g->Cin % 64) || (C1 % 64) || (ldx % 8) || (x2 && (ldx2 % 8)))) return GDN_ERR_UNSUPPORTED;
     P.bf16 = bf ? 1 : 0;
     P.x = x; P.x2 = x2; P.w = w; P.y = y; P.addsrc = addsrc; P.stats = stats;
+    P.ep_scale = ep_scale; P.ep_shift = ep_shift;
     P.C1 = C1; P.C2 = g->Cin - C1; P.ldx1 = ldx; P.ldx2 = ldx2; P.ldy = ldy; P.ld_add = ld_add; P.act = act;
     {
         const uint64_t npix = (uint64_t)g->B * g->H * g->W;

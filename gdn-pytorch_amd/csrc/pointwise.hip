@@ -435,8 +435,11 @@ __global__ __launch_bounds__(256) void bn_eval_bwd_kernel(const void* __restrict
             const f32x4 v = ld4_any(y, pix * ldy + c, dt & 2);
             const f32x4 t = *reinterpret_cast<const f32x4*>(shift + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (!(v[e] * s[e] + t[e] > 0.f)) o[e] = 0.f;
+            for (int e = 0; e < 4; ++e) {
+                // relu == 2: y already IS the activated output (conv + BN + ReLU fused in the conv epilogue)
+                const bool on = relu == 2 ? v[e] > 0.f : v[e] * s[e] + t[e] > 0.f;
+                if (!on) o[e] = 0.f;
+            }
         }
         st4_any(dy, pix * ld_dy + c, o, dt & 4);
     }

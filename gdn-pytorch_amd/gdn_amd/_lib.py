@@ -35,7 +35,7 @@ _SIGS = {
     "gdn_conv_out_dims": (c_int32, [_PG, POINTER(c_int32), POINTER(c_int32)]),
     "gdn_conv_stats_slots": (_i64, [_PG, _i32]),
     "gdn_conv_fwd_workspace_bytes": (_sz, [_PG, _i32]),
-    "gdn_conv_fwd": (c_int32, [_PG, _P, _i32, _P, _i32, _i32, _P, _P, _i32, _P, _i32, _P, _i32, _i32, _P, _sz, _P]),
+    "gdn_conv_fwd": (c_int32, [_PG, _P, _i32, _P, _i32, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _i32, _P, _sz, _P]),
     "gdn_conv_dgrad_workspace_bytes": (_sz, [_PG, _i32]),
     "gdn_conv_dgrad": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _sz, _i32, _P]),
     "gdn_conv_wgrad_workspace_bytes": (_sz, [_PG, _i32]),

@@ -6,12 +6,15 @@ needed, pushes one closure on a tape; ``backward`` replays the tape in reverse.
 Parameters keep the reference's names/shapes but live, tap-major, in one flat
 arena per model (so Adam and the RCCL all-reduce see a single buffer).
 """
+import os
+
 import torch
 
 from . import ops
 from ._lib import GdnError
 
 _ALIGN = 64  # floats
+_FUSE_EVAL_BN = os.environ.get("GDN_FUSE_EVAL_BN", "1") != "0"     # A/B switch for measurements
 
 
 # ----------------------------------------------------------------------------
@@ -265,9 +268,16 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
             bn.num_batches_tracked.add_(1)
         bn._gdn_stats_ver = getattr(bn, "_gdn_stats_ver", 0) + 1
     else:
-        y = op.fwd(x, w, x2=x2)
         co = _eval_coeffs(bn)
-    a = ops.bn_apply(y, co[0], co[1], relu, residual, out_dtype=ctx.dtype)
+    fused = (_FUSE_EVAL_BN and not bn.training and ldt == ctx.dtype and not (relu and residual is not None)
+             and (residual is None or residual.dtype == ldt) and conv.out_channels > 1)
+    if fused:
+        # eval-mode BN folded into the conv epilogue: conv + scale/shift + ReLU (+ residual) in one pass
+        y = a = op.fwd(x, w, x2=x2, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
+    else:
+        if not bn.training:
+            y = op.fwd(x, w, x2=x2)
+        a = ops.bn_apply(y, co[0], co[1], relu, residual, out_dtype=ctx.dtype)
     if ctx.record:
         in_hw = (x.shape[1], x.shape[2])
         bn_training = bn.training
@@ -286,7 +296,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                 dy = ops.bn_bwd(da, y, bn.weight.data, co, relu, bn.weight.grad if not frozen else None,
                                 bn.bias.grad if not frozen else None, out_dtype=ldt)
             else:
-                dy = ops.bn_eval_bwd(da, y, co, relu, out_dtype=ldt)
+                dy = ops.bn_eval_bwd(da, y, co, (2 if fused else 1) if relu else 0, out_dtype=ldt)
             if not frozen:
                 _wgrad_into(ctx, conv, x, dy, x2)
                 ctx.grads_done(bn.weight, bn.bias, conv.weight)

@@ -10,7 +10,7 @@ import torch
 
 from ._lib import ConvGeom, GdnError, lib
 
-ACT_NONE, ACT_TANH = 0, 1
+ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2       # bit flags
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 
@@ -103,15 +103,17 @@ class Conv:
         _, ref, _, _ = self.geom(B, H, W)
         return int(lib.gdn_conv_stats_slots(ref, tile_cfg))
 
-    def fwd(self, x, w_tap, x2=None, stats=False, act=ACT_NONE, addsrc=None, tile_cfg=0, out=None, stats_out=None):
-        """y = conv(cat(x, x2)); returns y, or (y, stats_partials) when stats."""
+    def fwd(self, x, w_tap, x2=None, stats=False, act=ACT_NONE, addsrc=None, tile_cfg=0, out=None, stats_out=None,
+            affine=None):
+        """y = tanh?(relu?(conv(cat(x, x2)) * scale + shift) + addsrc); returns y, or (y, stats_partials) when stats.
+        affine = (scale, shift) per output channel (an eval-mode BatchNorm folded into the epilogue) or None."""
         _chk(x, "x", bf16_ok=True)
         bf = x.dtype == torch.bfloat16
         head_mixed = bf and self.cout == 1       # 1-channel heads: bf16 x, fp32 weights and depth map
         if head_mixed:
             _chk(w_tap, "head weight")
-            if x2 is not None or addsrc is not None or stats:
-                raise GdnError("the bf16 head takes no concat / addsrc / stats")
+            if x2 is not None or addsrc is not None or stats or affine is not None:
+                raise GdnError("the bf16 head takes no concat / addsrc / stats / affine")
         else:
             _same_dtype(x, x2, w_tap, addsrc, out)
         if bf:
@@ -136,8 +138,9 @@ class Conv:
         ws = workspace(nb, x.device, "splitk") if nb else None
         try:
             lib.gdn_conv_fwd(ref, _p(x), _ld(x), _p(x2), 0 if x2 is None else _ld(x2), C1, _p(w_tap), _p(y), _ld(y),
-                             _p(addsrc), 0 if addsrc is None else _ld(addsrc), _p(st), act, tile_cfg, _p(ws), nb,
-                             stream())
+                             _p(addsrc), 0 if addsrc is None else _ld(addsrc), _p(st),
+                             None if affine is None else _p(affine[0]), None if affine is None else _p(affine[1]),
+                             act, tile_cfg, _p(ws), nb, stream())
         except GdnError as e:
             raise GdnError("%s [conv %d->%d k%d s%d p%d reflect=%s transposed=%s, x %s ld %d, x2 %s]" % (
                 e, self.cin, self.cout, self.k, self.stride, self.pad, self.reflect, self.transposed,
@@ -257,11 +260,12 @@ def bn_bwd(dout, y, gamma, coeffs, relu, dgamma, dbeta, out_dtype=None):
 
 
 def bn_eval_bwd(dout, y, coeffs, relu, out_dtype=None):
-    """Backward through an eval-mode BN (+ReLU): coeffs = [scale, shift] from bn_eval_coeffs. Returns dy."""
+    """Backward through an eval-mode BN (+ReLU): coeffs = [scale, shift] from bn_eval_coeffs. Returns dy.
+    relu: False/0 none, True/1 y is the raw conv output, 2 y is the activated output of a fused epilogue."""
     B, H, W, C = y.shape
     dy = torch.empty((B, H, W, C), dtype=out_dtype or y.dtype, device=y.device)
     lib.gdn_bn_eval_bwd(_p(dout), _ld(dout), _p(y), _ld(y), _p(coeffs[0]), _p(coeffs[1]), _p(dy), _ld(dy), B * H * W, C,
-                        1 if relu else 0, _mask(dout, y, dy), stream())
+                        int(relu), _mask(dout, y, dy), stream())
     return dy
 
 

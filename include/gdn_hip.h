@@ -60,7 +60,7 @@ typedef struct {
     int32_t transposed; /* 0 Conv2d, 1 ConvTranspose2d */
 } gdn_conv_geom;
 
-enum { GDN_ACT_NONE = 0, GDN_ACT_TANH = 1 };
+enum { GDN_ACT_NONE = 0, GDN_ACT_TANH = 1, GDN_ACT_RELU = 2 };   /* bit flags */
 
 /* tile_cfg flag bits shared by the conv entry points (low byte: tile id, 0 = automatic).
  * GDN_CFG_BF16: x/x2/w/y/addsrc (dy/wt/dx for dgrad) hold bfloat16 instead of float
@@ -84,7 +84,11 @@ int64_t gdn_conv_stats_slots(const gdn_conv_geom* g, int32_t tile_cfg);
  * torch.cat(...)+1x1 ConvBlock pair (:338-339,:345-346,:351-352,:357-358)
  * without materialising the concat: reduction channels [0,C1) come from x,
  * [C1,Cin) from x2 (x2 may be NULL when C1 == Cin).
- *   y[pixel][0..Cout)        = act( conv(x) ) (+ addsrc[pixel][..] if addsrc)
+ *   y[pixel][c] = tanh?( relu?( conv(x)[c] * ep_scale[c] + ep_shift[c] ) + addsrc[pixel][c] )
+ *                 ep_scale/ep_shift (both or neither; NULL = identity) fold an eval-mode BatchNorm
+ *                 (gdn_bn_eval_coeffs) into the epilogue: conv + BN + ReLU (+ residual) in one pass --
+ *                 the frozen guide network and the inference path (depth_extract.py); act is a bit mask
+ *                 of GDN_ACT_RELU (before the add) and GDN_ACT_TANH (after it)
  *   stats[slot][0][c], [1][c] = per-block sum / sum of squares of the raw conv
  *                               output (feeds train-mode BatchNorm, K7).
  * Launches that cannot fill the chip are split over the filter taps (split-K);
@@ -98,7 +102,7 @@ int gdn_conv_fwd(const gdn_conv_geom* g,
                  const void* x, int32_t ldx, const void* x2, int32_t ldx2, int32_t C1,
                  const void* w, void* y, int32_t ldy,
                  const void* addsrc, int32_t ld_add,
-                 float* stats, int32_t act, int32_t tile_cfg,
+                 float* stats, const float* ep_scale, const float* ep_shift, int32_t act, int32_t tile_cfg,
                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* Data gradient.  Replaces autograd's conv backward-data for the call sites
@@ -187,7 +191,9 @@ int gdn_bn_bwd(const void* dout, int32_t ld_dout, const void* y, int32_t ldy,
 
 /* Backward of out = [relu](y*scale + shift) through an EVAL-mode BatchNorm (fixed coefficients from
  * gdn_bn_eval_coeffs): dy = scale*dout*[z>0].  Used when a gradient crosses the frozen guide network
- * (--latent_grad, the guided training of trainer.py:699-703 without the no_grad).  dtypes: bit0 dout, bit1 y, bit2 dy. */
+ * (--latent_grad, the guided training of trainer.py:699-703 without the no_grad).  relu: 0 none, 1 y is the raw conv
+ * output (mask = y*scale+shift > 0), 2 y is the activated output of a fused conv+BN+ReLU epilogue (mask = y > 0).
+ * dtypes: bit0 dout, bit1 y, bit2 dy. */
 int gdn_bn_eval_bwd(const void* dout, int32_t ld_dout, const void* y, int32_t ldy,
                     const float* scale, const float* shift, void* dy, int32_t ld_dy,
                     int64_t npix, int32_t C, int32_t relu, int32_t dtypes, void* stream);

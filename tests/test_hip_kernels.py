@@ -339,3 +339,35 @@ def test_berhu_external_max(gpu):
     c = 0.2 * float(big)
     rho = torch.where(dd.abs() > c, (dd * dd + c * c) / (2 * c), dd.abs())
     assert float(l2) == pytest.approx(float(3 * rho.mean()), rel=1e-5)      # ... and the formula with the external one
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 8, 26), (4, 32, 52)])        # split-K combine epilogue / single-stage epilogue
+def test_conv_affine_relu_residual_epilogue(gpu, dtype, shape):
+    """Eval-mode BatchNorm folded into the conv epilogue: relu(conv*scale + shift) (+ residual) in one launch."""
+    from gdn_amd import ops
+    B, H, W = shape
+    C = 128
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    res = torch.randn(B, C, H, W, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    bf = dtype == "bf16"
+    if bf:
+        x, w, res = (t.bfloat16().float() for t in (x, w, res))
+    conv = F.conv2d(x, w, None, 1, 1)
+    aff = conv * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    cast = (lambda t: t.to(gpu).bfloat16()) if bf else (lambda t: t.to(gpu))
+    tol = dict(rtol=6e-3, atol_scale=4e-3) if bf else {}
+    op = ops.Conv(C, C, 3, 1, 1)
+    xd, wd, rd = cast(nhwc(x)), cast(tapmajor(w, False)), cast(nhwc(res))
+    affine = (sc.to(gpu), sh.to(gpu))
+    y1 = op.fwd(xd, wd, affine=affine, act=ops.ACT_RELU)
+    close(nchw(y1.float()), torch.relu(aff), what="conv+affine+relu", **tol)
+    y2 = op.fwd(xd, wd, affine=affine, addsrc=rd)
+    close(nchw(y2.float()), aff + res, what="conv+affine+residual", **tol)
+    y3 = op.fwd(xd, wd, act=ops.ACT_RELU, addsrc=rd)
+    close(nchw(y3.float()), torch.relu(conv) + res, what="conv+relu+residual", **tol)
+    y4 = op.fwd(xd, wd, affine=affine, act=ops.ACT_RELU, tile_cfg=0x800)        # split-K off
+    close(nchw(y4.float()), torch.relu(aff), what="conv+affine+relu single stage", **tol)

@@ -253,3 +253,28 @@ def test_cli_kitti_directory(gpu, tmp_path, monkeypatch):
                            "--width", "64", "--gpu_num", "0", "-e"])
     loss = GDN_main.run(a)
     assert torch.isfinite(loss)
+
+
+def test_legacy_inference_at_config4_resolution(gpu):
+    """BASELINE configs[4]'s path at its own resolution (256x832, eval-mode BN folded into the conv epilogues), one
+    image: fp32 against the oracle at the north-star bar, bf16 against the oracle's bf16 emulation (eval mode has no
+    batch statistics to amplify rounding, so the comparison stays meaningful end to end)."""
+    import gdn_amd.AE_model_unet as M
+    H, W = 256, 832
+    _, rgb, _ = O.synthetic_batch(1, H, W, seed=31)
+    sd = O.init_state_dict("AutoEncoder", seed=6)
+    with torch.no_grad():
+        ref = O.forward_legacy({k: v.clone() for k, v in sd.items()}, rgb, istrain=True, training=False, height=H, width=W)
+        with O.bf16_emulation():
+            emu = O.forward_legacy({k: v.clone() for k, v in sd.items()}, rgb, istrain=True, training=False, height=H, width=W)
+    m = M.AutoEncoder(height=H, width=W)
+    m.load_state_dict(sd)
+    m = m.to(gpu).eval()
+    got = m(rgb.to(gpu), istrain=True)
+    for i in range(8):
+        close(got[i], ref[i], rtol=1e-3, atol_scale=1e-3, what="legacy 256x832 fp32 f%d" % i)
+    got16 = m.compute_dtype("bf16")(rgb.to(gpu), istrain=True)
+    assert got16[0].dtype == torch.bfloat16 and got16[7].dtype == torch.float32
+    for i in range(8):
+        e = float((got16[i].float().cpu() - emu[i]).norm() / (emu[i].norm() + 1e-30))
+        assert e < 2e-2, "legacy 256x832 bf16 f%d: rel L2 %.3e vs the bf16 emulation" % (i, e)

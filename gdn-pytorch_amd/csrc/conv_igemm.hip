@@ -1104,8 +1104,11 @@ int pick_ksplit(const IgemmParams& P, int cfg, bool scalar, int tile_cfg) {
         const int n = P.ph[i].tap_end - P.ph[i].tap_begin;
         if (n < min_taps) min_taps = n;
     }
-    int ks = (int)cdiv64(4608, blocks);
-    const int ks_max = (tile_cfg >> 12) & 15 ? (tile_cfg >> 12) & 15 : 4;     // bits 12..15: tuning override
+    // fp32: ~3 rounds of resident workgroups, at most 4 ways.  bf16: the fp32 partials cost relatively 16x more against
+    // the faster MFMA, so split less (measured, profiles/r01_tune_conv_bf16_rowpatch.txt): fill ~one round, at most 3 ways.
+    const bool bf = (tile_cfg & CFG_BF16) != 0;
+    int ks = (int)cdiv64(bf ? 1024 : 4608, blocks);
+    const int ks_max = (tile_cfg >> 12) & 15 ? (tile_cfg >> 12) & 15 : (bf ? 3 : 4);     // bits 12..15: tuning override
     if (ks > ks_max) ks = ks_max;
     if (ks > min_taps) ks = min_taps;
     return ks < 1 ? 1 : ks;

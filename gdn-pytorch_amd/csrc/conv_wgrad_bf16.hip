@@ -268,7 +268,9 @@ bool make_plan_bf(const gdn_conv_geom* g, int Cx_in, int cfg, PlanBf& pl) {
         if (n >= 1) { tw = P.Wg; nr = n; }
     }
     if (tw == 0) {
-        if (cfg == 1) { tw = 32; pl.cls = 1; }
+        // a row that must be cut into pieces: for stride-2 layers the 104-pixel pieces of the large class (7 X passes per
+        // piece, 7 k-steps) run 2.6x slower than 32-pixel pieces of the small class (measured: 128 vs 325-337 TFLOP/s)
+        if (cfg == 1 || (cfg == 0 && s == 2)) { tw = 32; pl.cls = 1; }
         else {
             // widest piece of one row (multiple of 16) the large staging class holds, best row coverage first
             double best_eff = 0.0;

@@ -1,0 +1,46 @@
+"""Worker of tests/test_hip_model.py::test_data_parallel_two_ranks (spawned, one process per rank, both on cuda:0 with
+the gloo backend: RCCL refuses two ranks on one device, gloo moves the same buckets through the host)."""
+import os
+import sys
+
+import torch
+
+
+def run(rank, world, port, steps, out_dir, overlap):
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    for p in (root, os.path.join(root, "gdn-pytorch_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0",
+                      WORLD_SIZE=str(world), GDN_OVERLAP_ALLREDUCE="1" if overlap else "0")
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import distributed as D
+    from gdn_amd import utils as U
+    from gdn_amd.optim import Adam
+    from oracle import gdn_oracle as O
+    D.init(backend="gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0 if rank == 0 else 123)          # rank 1 starts from different weights: the broadcast must fix it
+    model = M.AutoEncoder_DtoD(input_dim=1, height=32, width=64).to(dev).train()
+    x0 = O.synthetic_batch(2, 32, 64, seed=100 + rank)[0].to(dev)
+    model(x0, istrain=False)                             # builds the arena
+    D.broadcast_parameters(model, src=0)
+    opt = Adam(model.parameters(), 2e-4, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
+    losses = []
+    for s in range(steps):
+        depth, _, sparse = [t.to(dev) for t in O.synthetic_batch(2, 32, 64, seed=10 * s + rank)]
+        out = model(depth, istrain=False)
+        loss, _, _ = U.dtod_loss(out, depth, sparse)
+        opt.zero_grad()
+        loss.backward()
+        D.sync_gradients(model, opt)
+        opt.step()
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "losses": losses,
+                "reducer": getattr(model, "_gdn_reducer", None) is not None},
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()

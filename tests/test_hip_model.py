@@ -298,3 +298,52 @@ def test_guide_fast_path_identical(gpu):
         enc = G.guide_features(depth)
     for f, e in zip(full, enc):
         assert torch.equal(f, e)
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_data_parallel_two_ranks(gpu, tmp_path, overlap):
+    """Two real processes (one per rank, gloo, both on cuda:0) train 3 steps on their own shards with
+    broadcast_parameters + sync_gradients (+ the overlapped GradReducer) + the fused Adam's 1/world scale.
+    A single process that runs both shards with the same weights, sums the two gradient arenas and applies the
+    same Adam must end with BITWISE identical parameters; BatchNorm running statistics stay rank-local (8(e))."""
+    import torch.multiprocessing as mp
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import utils as U
+    from gdn_amd.optim import Adam
+    import dp_worker
+    steps = 3
+    port = 29600 + (1 if overlap else 0)
+    mp.spawn(dp_worker.run, args=(2, port, steps, str(tmp_path), overlap), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert r0["reducer"] == overlap
+    # single-process emulation: replica A plays rank 0, replica B rank 1 (own BN buffers, shared weights)
+    torch.manual_seed(0)
+    A = M.AutoEncoder_DtoD(input_dim=1, height=32, width=64).to(gpu).train()
+    torch.manual_seed(123)
+    Bm = M.AutoEncoder_DtoD(input_dim=1, height=32, width=64).to(gpu).train()
+    for r, m in ((0, A), (1, Bm)):
+        m(O.synthetic_batch(2, 32, 64, seed=100 + r)[0].to(gpu), istrain=False)      # same warm-up forward as the workers
+    with torch.no_grad():                                    # broadcast_parameters: weights AND buffers from rank 0
+        Bm._gdn_param_arena.data.copy_(A._gdn_param_arena.data)
+        for bb, ba in zip(Bm.buffers(), A.buffers()):
+            bb.copy_(ba)
+    opt = Adam(A.parameters(), 2e-4, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
+    opt.grad_scale = 0.5
+    for s in range(steps):
+        for r, m in ((0, A), (1, Bm)):
+            depth, _, sparse = [t.to(gpu) for t in O.synthetic_batch(2, 32, 64, seed=10 * s + r)]
+            out = m(depth, istrain=False)
+            loss, _, _ = U.dtod_loss(out, depth, sparse)
+            m.zero_grad()
+            loss.backward()
+            assert float(loss.detach()) == (r0 if r == 0 else r1)["losses"][s]
+        A._gdn_param_arena.grad.add_(Bm._gdn_param_arena.grad)          # the SUM all-reduce
+        opt.step()
+        with torch.no_grad():
+            Bm._gdn_param_arena.data.copy_(A._gdn_param_arena.data)
+    for k, v in A.state_dict().items():
+        assert torch.equal(v.cpu(), r0["sd"][k]), "rank 0 differs from the single-process run at %s" % k
+    for k, v in Bm.state_dict().items():
+        assert torch.equal(v.cpu(), r1["sd"][k]), "rank 1 differs at %s" % k
+    assert not torch.equal(r0["sd"]["downconv1.main.2.running_mean"], r1["sd"]["downconv1.main.2.running_mean"])
+    assert torch.equal(r0["sd"]["downconv1.main.1.weight"], r1["sd"]["downconv1.main.1.weight"])

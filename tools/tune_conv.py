@@ -46,7 +46,6 @@ SHAPES = [
 ]
 only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != '-' else None
 CF = [int(c) for c in sys.argv[3].split(',')] if len(sys.argv) > 3 else [0, 1, 2, 3]
-WG = os.environ.get('GDN_TUNE_WGRAD', '1') == '1' if 'os' in dir() else True
 
 
 def timeit(fn, reps=5):

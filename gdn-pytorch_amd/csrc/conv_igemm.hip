@@ -1111,7 +1111,10 @@ int pick_ksplit(const IgemmParams& P, int cfg, bool scalar, int tile_cfg) {
     const int ks_max = (tile_cfg >> 12) & 15 ? (tile_cfg >> 12) & 15 : (bf ? 3 : 4);     // bits 12..15: tuning override
     if (ks > ks_max) ks = ks_max;
     if (ks > min_taps) ks = min_taps;
-    return ks < 1 ? 1 : ks;
+    if (ks < 1) ks = 1;
+    // the slowest split sets the pace: 9 taps four ways is 2,2,2,3 -- no faster than 3,3,3 but a quarter more partials
+    while (ks > 1 && cdiv(min_taps, ks - 1) == cdiv(min_taps, ks)) --ks;
+    return ks;
 }
 
 size_t ksplit_bytes(const IgemmParams& P, int ksplit) {

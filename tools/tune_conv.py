@@ -48,6 +48,17 @@ only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != '-' else None
 CF = [int(c) for c in sys.argv[3].split(',')] if len(sys.argv) > 3 else [0, 1, 2, 3]
 
 
+def _warm():
+    """Bring the clocks up before the first timed configuration (the first columns of a sweep otherwise read ~15 % low)."""
+    a = torch.randn(4096, 4096, device=dev)
+    for _ in range(60):
+        a @ a
+    torch.cuda.synchronize()
+
+
+_warm()
+
+
 def timeit(fn, reps=5):
     fn(); fn()
     torch.cuda.synchronize()

@@ -1098,7 +1098,7 @@ int pick_ksplit(const IgemmParams& P, int cfg, bool scalar, int tile_cfg) {
     if (scalar || (P.N % 4) || cfg == 4 || cfg >= 8 || (tile_cfg & 0x800)) return 1;
     const TileCfg tc = kCfg[cfg];
     const int64_t blocks = cdiv64(cdiv64(max_phase_m(P), tc.bm), 8) * 8 * cdiv(P.N, tc.bn) * P.nphase;
-    if (blocks >= 1200) return 1;      // measured: splitting only pays below ~one round of resident workgroups
+    if (blocks >= 1200 && !(tile_cfg & 0x400)) return 1;      // measured: splitting only pays below ~one round of resident workgroups (0x400: tuning override)
     int min_taps = MAX_TAPS;
     for (int i = 0; i < P.nphase; ++i) {
         const int n = P.ph[i].tap_end - P.ph[i].tap_begin;

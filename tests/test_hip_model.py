@@ -66,7 +66,7 @@ def test_full_forward_vs_reference(gpu, golden, name):
         feats = m(x, istrain=True)
     assert len(feats) == 8
     # depth maps live in (-1,1): "within 1e-3 of the reference" is an absolute bar at full scale.  (Measured
-    # with tools/diag_forward.py: the HIP path is closer to an fp64 evaluation than the fp32 CPU reference is.)
+    # with tests/diag/diag_forward.py: the HIP path is closer to an fp64 evaluation than the fp32 CPU reference is.)
     close(feats[7], torch.from_numpy(g[name + ".train.out"]), atol_scale=1e-3, what=name + " train out")
     for i in range(7):
         f = feats[i]

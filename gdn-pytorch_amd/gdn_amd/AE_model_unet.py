@@ -18,13 +18,21 @@ from . import engine as E
 from ._lib import GdnError
 
 
-def _check_norm(norm, reaches_layers=False):
+def _check_norm(norm):
     """The reference's AutoEncoder_2 / AutoEncoder_DtoD only PRINT the norm (AE_model_unet.py:266-269, :488-491):
     their blocks are built without it and are always BatchNorm, so 'Instance' changes nothing there.  Only the legacy
-    AutoEncoder instantiates InstanceNorm layers (:136-155), which the HIP path does not implement."""
-    if norm != 'Batch' and reaches_layers:
-        raise NotImplementedError("norm=%r: InstanceNorm layers are not implemented on the HIP path" % (norm,))
+    AutoEncoder (:136-155) and standalone ConvBlock/ConvTBlock(norm='Instance') instantiate InstanceNorm layers."""
     print("- norm : Batch" if norm == 'Batch' else "- norm : Instance")
+
+
+def _norm_layer(norm, c):
+    """nn.BatchNorm2d, or the reference's nn.InstanceNorm2d(c, affine=True, track_running_stats=True) (:73, :91, :147-155).
+    With tracked running statistics an InstanceNorm in eval() normalises with the running mean/var exactly like an
+    eval-mode BatchNorm, which is what the HIP path executes; per-instance statistics (train mode) are not implemented
+    and raise at the first forward (engine.conv_bn_act)."""
+    if norm == 'Batch':
+        return nn.BatchNorm2d(c, affine=True, track_running_stats=True)
+    return nn.InstanceNorm2d(c, affine=True, track_running_stats=True)
 
 
 class _HipModule(nn.Module):
@@ -145,12 +153,10 @@ class ConvBlock(_HipModule):
 
     def __init__(self, dim_in, dim_out, kernel_size, padding, stride=1, norm='Batch'):
         super().__init__()
-        if norm != 'Batch':
-            raise NotImplementedError("InstanceNorm ConvBlock is not implemented on the HIP path")
         self.main = nn.Sequential(
             nn.ReflectionPad2d(padding),
             nn.Conv2d(dim_in, dim_out, kernel_size, stride, padding=0, bias=False),
-            nn.BatchNorm2d(dim_out, affine=True, track_running_stats=True),
+            _norm_layer(norm, dim_out),
             nn.ReLU(inplace=True))
         self._pad = padding
 
@@ -170,11 +176,9 @@ class ConvTBlock(_HipModule):
 
     def __init__(self, dim_in, dim_out, kernel_size, padding, stride=1, norm='Batch'):
         super().__init__()
-        if norm != 'Batch':
-            raise NotImplementedError("InstanceNorm ConvTBlock is not implemented on the HIP path")
         self.main = nn.Sequential(
             nn.ConvTranspose2d(dim_in, dim_out, kernel_size, stride, padding, bias=False),
-            nn.BatchNorm2d(dim_out, affine=True, track_running_stats=True),
+            _norm_layer(norm, dim_out),
             nn.ReLU(inplace=True))
 
     def run(self, ctx, x):
@@ -357,10 +361,10 @@ class AutoEncoder(_HipModule):
         self.conv1x1_128 = nn.Conv2d(256, 128, kernel_size=1, stride=1, padding=0, bias=False)
         self.conv1x1_256 = nn.Conv2d(512, 256, kernel_size=1, stride=1, padding=0, bias=False)
         self.upsampling = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
-        _check_norm(norm, reaches_layers=True)
+        _check_norm(norm)
         for name, c in (("N64_down", 64), ("N128_down", 128), ("N256_down", 256), ("N512_down", 512),
                         ("N64_up", 64), ("N128_up", 128), ("N256_up", 256)):
-            setattr(self, name, nn.BatchNorm2d(c, affine=True, track_running_stats=True))
+            setattr(self, name, _norm_layer(norm, c))
         self.ReLU = nn.ReLU(inplace=True)
         if init_weights:
             self._initialize_weights()

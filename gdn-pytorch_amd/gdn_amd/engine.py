@@ -259,6 +259,9 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     if x.dtype != ldt:
         raise GdnError("layer %d->%d computes in %s but its input is %s" % (conv.in_channels, conv.out_channels, ldt, x.dtype))
     w, tr = _w_for(ctx, conv, ldt)
+    if bn.training and isinstance(bn, torch.nn.InstanceNorm2d):
+        raise NotImplementedError("train-mode InstanceNorm (per-instance statistics) is not implemented on the HIP path; "
+                                  "model.eval() normalises with the tracked running statistics like the reference does")
     if bn.training:
         y, st = op.fwd(x, w, x2=x2, stats=True)
         count = y.shape[0] * y.shape[1] * y.shape[2]

@@ -86,10 +86,10 @@ def test_no_cpu_fallback():
     # the reference's R and G only print the norm (AE_model_unet.py:266-269): 'Instance' still builds BatchNorm blocks
     r = M.AutoEncoder_2(norm='Instance', height=32, width=64)
     assert isinstance(r.downconv1.main[2], torch.nn.BatchNorm2d)
-    with pytest.raises(NotImplementedError):
-        M.AutoEncoder(norm='Instance')               # the legacy net does instantiate InstanceNorm layers (:136-155)
-    with pytest.raises(NotImplementedError):
-        M.ConvBlock(3, 8, 3, 1, norm='Instance')
+    # the legacy net and standalone blocks do instantiate InstanceNorm layers (:73, :91, :136-155); same state_dict keys
+    leg = M.AutoEncoder(norm='Instance', height=32, width=64)
+    assert isinstance(leg.N64_down, torch.nn.InstanceNorm2d) and "N64_down.running_var" in leg.state_dict()
+    assert isinstance(M.ConvBlock(3, 8, 3, 1, norm='Instance').main[2], torch.nn.InstanceNorm2d)
 
 
 def test_tap_major_arena_layout():

@@ -278,3 +278,42 @@ def test_legacy_inference_at_config4_resolution(gpu):
     for i in range(8):
         e = float((got16[i].float().cpu() - emu[i]).norm() / (emu[i].norm() + 1e-30))
         assert e < 2e-2, "legacy 256x832 bf16 f%d: rel L2 %.3e vs the bf16 emulation" % (i, e)
+
+
+def test_legacy_instance_norm_eval(gpu):
+    """AutoEncoder(norm='Instance') (AE_model_unet.py:146-155): InstanceNorm2d(affine, track_running_stats) in eval()
+    normalises with the running statistics; checked against the same layers executed by torch on the CPU."""
+    import gdn_amd.AE_model_unet as M
+    import torch.nn as nn
+    H, W = 32, 64
+    torch.manual_seed(3)
+    m = M.AutoEncoder(norm='Instance', height=H, width=W)
+    for mod in m.modules():                       # non-trivial running statistics and affine parameters
+        if isinstance(mod, (nn.InstanceNorm2d, nn.BatchNorm2d)):
+            mod.running_mean.normal_(0, 0.2); mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5); mod.bias.data.normal_(0, 0.2)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    _, rgb, _ = O.synthetic_batch(2, H, W, seed=41)
+    with torch.no_grad():       # the oracle's legacy graph: F.batch_norm(training=False) == eval InstanceNorm with tracked stats
+        ref = O.forward_legacy(sd, rgb, istrain=False, training=False, height=H, width=W)
+        cb = nn.Sequential(nn.Conv2d(3, 64, 9, 1, 4, bias=False), nn.InstanceNorm2d(64, affine=True, track_running_stats=True)).eval()
+        cb[0].weight.copy_(sd["downconv0.weight"])
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            getattr(cb[1], k).copy_(sd["N64_down." + k])
+        x3_torch = torch.relu(cb(rgb))
+    m = m.to(gpu).eval()
+    out = m(rgb.to(gpu), istrain=False)
+    close(out, ref, atol_scale=1e-3, what="legacy InstanceNorm eval output")
+    blk = M.ConvBlock(3, 64, kernel_size=9, stride=1, padding=4, norm='Instance')
+    with torch.no_grad():
+        blk.main[1].weight.copy_(sd["downconv0.weight"])
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            getattr(blk.main[2], k).copy_(sd["N64_down." + k])
+        refb = torch.relu(cb[1](torch.nn.functional.conv2d(torch.nn.functional.pad(rgb, (4, 4, 4, 4), mode="reflect"), sd["downconv0.weight"])))
+    blk = blk.to(gpu).eval()
+    with torch.no_grad():
+        close(blk(rgb.to(gpu)), refb, what="ConvBlock(norm='Instance') eval")
+    blk.train()
+    with pytest.raises(NotImplementedError):
+        blk(rgb.to(gpu))
+    assert x3_torch.shape == (2, 64, H, W)

@@ -5,6 +5,17 @@
 
 namespace {
 
+// log2 of v if v is a power of two, else -1: the channel-quad counts of these networks (16..128) all are, which turns
+// the per-element 64-bit division of the flat index into a shift (the division alone cost more than the memory traffic).
+inline int pow2_shift(int v) {
+    for (int s = 0; s < 31; ++s)
+        if ((1 << s) == v) return s;
+    return -1;
+}
+#define SPLIT_PIX_C(i, cq, sh, pix, c)                                       \
+    const int64_t pix = (sh) >= 0 ? ((i) >> (sh)) : (i) / (cq);              \
+    const int c = (int)((sh) >= 0 ? ((i) & ((cq) - 1)) : ((i) - pix * (cq))) * 4
+
 inline int stream_blocks(int64_t n_items, int threads = 256, int cap = 2048) {
     int64_t b = cdiv64(n_items, threads);
     if (b < 1) b = 1;
@@ -59,12 +70,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ 
                                                        const float* __restrict__ shift,
                                                        const void* __restrict__ res, int ld_res,
                                                        void* __restrict__ out, int ld_out, int64_t npix, int C,
-                                                       int relu, int dt) {
+                                                       int relu, int dt, int sh) {
     const int cq = C >> 2;
     const int64_t total = npix * cq;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t pix = i / cq;
-        const int c = (int)(i - pix * cq) * 4;
+        SPLIT_PIX_C(i, cq, sh, pix, c);
         const f32x4 v = ld4_any(y, pix * ldy + c, dt & 1);
         const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c);
         const f32x4 t = *reinterpret_cast<const f32x4*>(shift + c);
@@ -154,12 +164,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const void* __restrict__ dout, int ld_dout, const void* __restrict__ y, int ldy,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ k1, const float* __restrict__ k2,
-    void* __restrict__ dy, int ld_dy, int64_t npix, int C, int relu, int dt) {
+    void* __restrict__ dy, int ld_dy, int64_t npix, int C, int relu, int dt, int sh) {
     const int cq = C >> 2;
     const int64_t total = npix * cq;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t pix = i / cq;
-        const int c = (int)(i - pix * cq) * 4;
+        SPLIT_PIX_C(i, cq, sh, pix, c);
         const f32x4 d = ld4_any(dout, pix * ld_dout + c, dt & 1);
         const f32x4 v = ld4_any(y, pix * ldy + c, dt & 2);
         const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c);   // gamma*invstd
@@ -196,24 +205,23 @@ __device__ __forceinline__ void up_src(int o, int in, int align, float& l1, int&
     l1 = src - i0;
 }
 
+// grid.y = output row (b, oy), grid.x covers the Wo * C/4 quads of that row: no per-thread division
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const void* __restrict__ x, void* __restrict__ y,
-                                                             int B, int H, int W, int C, int align, int dt) {
+                                                             int B, int H, int W, int C, int align, int dt, int sh) {
     const int cq = C >> 2, Ho = 2 * H, Wo = 2 * W;
-    const int64_t total = (int64_t)B * Ho * Wo * cq;
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % cq) * 4;
-        int64_t t = i / cq;
-        const int ox = (int)(t % Wo); t /= Wo;
-        const int oy = (int)(t % Ho);
-        const int b = (int)(t / Ho);
-        float ly, lx; int y0, y1, x0, x1;
-        up_src(oy, H, align, ly, y0, y1);
+    const int row = blockIdx.y, b = row / Ho, oy = row - b * Ho;
+    float ly; int y0, y1;
+    up_src(oy, H, align, ly, y0, y1);
+    const size_t xb = (size_t)b * H * W * C;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < Wo * cq; j += gridDim.x * 256) {
+        const int ox = sh >= 0 ? j >> sh : j / cq;
+        const int c = (sh >= 0 ? j & (cq - 1) : j - ox * cq) * 4;
+        float lx; int x0, x1;
         up_src(ox, W, align, lx, x0, x1);
-        const size_t xb = (size_t)b * H * W * C + c;
-        const f32x4 v00 = ld4_any(x, xb + ((size_t)y0 * W + x0) * C, dt & 1);
-        const f32x4 v01 = ld4_any(x, xb + ((size_t)y0 * W + x1) * C, dt & 1);
-        const f32x4 v10 = ld4_any(x, xb + ((size_t)y1 * W + x0) * C, dt & 1);
-        const f32x4 v11 = ld4_any(x, xb + ((size_t)y1 * W + x1) * C, dt & 1);
+        const f32x4 v00 = ld4_any(x, xb + ((size_t)y0 * W + x0) * C + c, dt & 1);
+        const f32x4 v01 = ld4_any(x, xb + ((size_t)y0 * W + x1) * C + c, dt & 1);
+        const f32x4 v10 = ld4_any(x, xb + ((size_t)y1 * W + x0) * C + c, dt & 1);
+        const f32x4 v11 = ld4_any(x, xb + ((size_t)y1 * W + x1) * C + c, dt & 1);
         const f32x4 o = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
         st4_any(y, (((size_t)b * Ho + oy) * Wo + ox) * C + c, o, dt & 2);
     }
@@ -222,22 +230,26 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const void* __restr
 // Gather form of the adjoint (deterministic, no atomics): each input pixel sums
 // the <= 6x6 output pixels whose stencil touches it.
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const void* __restrict__ dy, void* __restrict__ dx,
-                                                             int B, int H, int W, int C, int align, int dt) {
+                                                             int B, int H, int W, int C, int align, int dt, int sh) {
     const int cq = C >> 2, Ho = 2 * H, Wo = 2 * W;
-    const int64_t total = (int64_t)B * H * W * cq;
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % cq) * 4;
-        int64_t t = i / cq;
-        const int ix = (int)(t % W); t /= W;
-        const int iy = (int)(t % H);
-        const int b = (int)(t / H);
-        float wy[6], wx[6];
+    const int row = blockIdx.y, b = row / H, iy = row - b * H;
+    float wy[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int oy = 2 * iy - 2 + j;
+        float l; int a0, a1;
+        wy[j] = 0.f;
+        if (oy >= 0 && oy < Ho) { up_src(oy, H, align, l, a0, a1); if (a0 == iy) wy[j] += 1.f - l; if (a1 == iy) wy[j] += l; }
+    }
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < W * cq; q += gridDim.x * 256) {
+        const int ix = sh >= 0 ? q >> sh : q / cq;
+        const int c = (sh >= 0 ? q & (cq - 1) : q - ix * cq) * 4;
+        float wx[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const int oy = 2 * iy - 2 + j, ox = 2 * ix - 2 + j;
+            const int ox = 2 * ix - 2 + j;
             float l; int a0, a1;
-            wy[j] = 0.f; wx[j] = 0.f;
-            if (oy >= 0 && oy < Ho) { up_src(oy, H, align, l, a0, a1); if (a0 == iy) wy[j] += 1.f - l; if (a1 == iy) wy[j] += l; }
+            wx[j] = 0.f;
             if (ox >= 0 && ox < Wo) { up_src(ox, W, align, l, a0, a1); if (a0 == ix) wx[j] += 1.f - l; if (a1 == ix) wx[j] += l; }
         }
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -379,7 +391,7 @@ extern "C" int gdn_bn_apply(const void* y, int32_t ldy, const float* scale, cons
     if (!y || !scale || !shift || !out || npix <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     if ((C % 4) || (ldy % 4) || (ld_out % 4) || (residual && (ld_res % 4))) return GDN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, ST(stream), y, ldy, scale,
-                       shift, residual, ld_res, out, ld_out, npix, C, relu, dtypes);
+                       shift, residual, ld_res, out, ld_out, npix, C, relu, dtypes, pow2_shift(C / 4));
     return gdn_launch_status();
 }
 
@@ -412,7 +424,7 @@ extern "C" int gdn_bn_bwd(const void* dout, int32_t ld_dout, const void* y, int3
                        (double)npix, dgamma, dbeta, k1, k2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, ST(stream), dout,
                        ld_dout, y, ldy, scale, shift, mean, invstd, (const float*)k1, (const float*)k2, dy, ld_dy, npix,
-                       C, relu, dtypes);
+                       C, relu, dtypes, pow2_shift(C / 4));
     return gdn_launch_status();
 }
 
@@ -422,12 +434,11 @@ __global__ __launch_bounds__(256) void bn_eval_bwd_kernel(const void* __restrict
                                                           const void* __restrict__ y, int ldy,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, void* __restrict__ dy,
-                                                          int ld_dy, int64_t npix, int C, int relu, int dt) {
+                                                          int ld_dy, int64_t npix, int C, int relu, int dt, int sh) {
     const int cq = C >> 2;
     const int64_t total = npix * cq;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t pix = i / cq;
-        const int c = (int)(i - pix * cq) * 4;
+        SPLIT_PIX_C(i, cq, sh, pix, c);
         const f32x4 d = ld4_any(dout, pix * ld_dout + c, dt & 1);
         const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c);
         f32x4 o = d * s;
@@ -452,7 +463,7 @@ extern "C" int gdn_bn_eval_bwd(const void* dout, int32_t ld_dout, const void* y,
     if (!dout || !y || !scale || !shift || !dy || npix <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     if ((C % 4) || (ldy % 4) || (ld_dout % 4) || (ld_dy % 4)) return GDN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(bn_eval_bwd_kernel, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, ST(stream), dout, ld_dout,
-                       y, ldy, scale, shift, dy, ld_dy, npix, C, relu, dtypes);
+                       y, ldy, scale, shift, dy, ld_dy, npix, C, relu, dtypes, pow2_shift(C / 4));
     return gdn_launch_status();
 }
 
@@ -461,8 +472,9 @@ extern "C" int gdn_upsample2x_fwd(const void* x, void* y, int32_t B, int32_t H, 
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     if (C % 4) return GDN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(stream_blocks((int64_t)B * 4 * H * W * (C / 4))), dim3(256), 0,
-                       ST(stream), x, y, B, H, W, C, align_corners, dtypes);
+    if ((int64_t)B * 2 * H > 65535) return GDN_ERR_UNSUPPORTED;      // grid.y limit
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(cdiv(2 * W * (C / 4), 256), B * 2 * H), dim3(256), 0,
+                       ST(stream), x, y, B, H, W, C, align_corners, dtypes, pow2_shift(C / 4));
     return gdn_launch_status();
 }
 
@@ -471,8 +483,9 @@ extern "C" int gdn_upsample2x_bwd(const void* dy, void* dx, int32_t B, int32_t H
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     if (C % 4) return GDN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(stream_blocks((int64_t)B * H * W * (C / 4))), dim3(256), 0,
-                       ST(stream), dy, dx, B, H, W, C, align_corners, dtypes);
+    if ((int64_t)B * H > 65535) return GDN_ERR_UNSUPPORTED;          // grid.y limit
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(cdiv(W * (C / 4), 256), B * H), dim3(256), 0,
+                       ST(stream), dy, dx, B, H, W, C, align_corners, dtypes, pow2_shift(C / 4));
     return gdn_launch_status();
 }
 

@@ -317,3 +317,30 @@ def test_legacy_instance_norm_eval(gpu):
     with pytest.raises(NotImplementedError):
         blk(rgb.to(gpu))
     assert x3_torch.shape == (2, 64, H, W)
+
+
+def test_depth_extract_cli(gpu, tmp_path):
+    """depth_extract.py counterpart: reference-format checkpoint (module.-prefixed legacy AutoEncoder) + image folder ->
+    one depth PNG per image at the source resolution; the batched run equals the one-by-one run."""
+    from PIL import Image
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import depth_extract, trainer
+    r = np.random.RandomState(0)
+    imgs = tmp_path / "imgs"
+    imgs.mkdir()
+    for i, (h, w) in enumerate(((90, 300), (128, 416), (60, 200))):
+        Image.fromarray(r.randint(0, 256, (h, w, 3)).astype(np.uint8)).save(imgs / ("im%d.png" % i))
+    torch.manual_seed(0)
+    m = M.AutoEncoder(height=64, width=128).to(gpu)
+    ck = tmp_path / "legacy.pkl"
+    trainer._save_checkpoint(m, str(ck))
+    assert all(k.startswith("module.") for k in torch.load(ck))
+    depth_extract.main(["--model_dir", str(ck), "--img_dir", str(imgs), "--out_dir", str(tmp_path / "o1"),
+                        "--height", "64", "--width", "128", "--batch", "1"])
+    depth_extract.main(["--model_dir", str(ck), "--img_dir", str(imgs), "--out_dir", str(tmp_path / "o3"),
+                        "--height", "64", "--width", "128", "--batch", "3"])
+    for i, (h, w) in enumerate(((90, 300), (128, 416), (60, 200))):
+        a = np.asarray(Image.open(tmp_path / "o1" / ("im%d_depth.png" % i)))
+        b = np.asarray(Image.open(tmp_path / "o3" / ("im%d_depth.png" % i)))
+        assert a.shape == (h, w) and a.dtype == np.uint16 and a.std() > 0
+        assert np.array_equal(a, b)          # eval-mode BN: no cross-sample coupling, batching changes nothing

@@ -6,7 +6,7 @@ import sys
 import torch
 
 
-def run(rank, world, port, steps, out_dir, overlap):
+def run(rank, world, port, steps, out_dir, overlap, global_berhu=False):
     here = os.path.dirname(os.path.abspath(__file__))
     root = os.path.dirname(here)
     for p in (root, os.path.join(root, "gdn-pytorch_amd")):
@@ -20,6 +20,7 @@ def run(rank, world, port, steps, out_dir, overlap):
     from gdn_amd.optim import Adam
     from oracle import gdn_oracle as O
     D.init(backend="gloo")
+    U.GLOBAL_BERHU = bool(global_berhu)
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     torch.manual_seed(0 if rank == 0 else 123)          # rank 1 starts from different weights: the broadcast must fix it

@@ -300,20 +300,22 @@ def test_guide_fast_path_identical(gpu):
         assert torch.equal(f, e)
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_data_parallel_two_ranks(gpu, tmp_path, overlap):
+@pytest.mark.parametrize("overlap,global_berhu", [(True, False), (False, False), (True, True)])
+def test_data_parallel_two_ranks(gpu, tmp_path, overlap, global_berhu):
     """Two real processes (one per rank, gloo, both on cuda:0) train 3 steps on their own shards with
     broadcast_parameters + sync_gradients (+ the overlapped GradReducer) + the fused Adam's 1/world scale.
     A single process that runs both shards with the same weights, sums the two gradient arenas and applies the
-    same Adam must end with BITWISE identical parameters; BatchNorm running statistics stay rank-local (8(e))."""
+    same Adam must end with BITWISE identical parameters; BatchNorm running statistics stay rank-local (8(e)).
+    global_berhu: the BerHu threshold's max|out-gt| is all-reduced (MAX) over the ranks (--global_berhu)."""
     import torch.multiprocessing as mp
     import gdn_amd.AE_model_unet as M
     from gdn_amd import utils as U
     from gdn_amd.optim import Adam
     import dp_worker
     steps = 3
-    port = 29600 + (1 if overlap else 0)
-    mp.spawn(dp_worker.run, args=(2, port, steps, str(tmp_path), overlap), nprocs=2, join=True)
+    from gdn_amd import ops
+    port = 29600 + (1 if overlap else 0) + (2 if global_berhu else 0)
+    mp.spawn(dp_worker.run, args=(2, port, steps, str(tmp_path), overlap, global_berhu), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert r0["reducer"] == overlap
     # single-process emulation: replica A plays rank 0, replica B rank 1 (own BN buffers, shared weights)
@@ -330,12 +332,27 @@ def test_data_parallel_two_ranks(gpu, tmp_path, overlap):
     opt = Adam(A.parameters(), 2e-4, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
     opt.grad_scale = 0.5
     for s in range(steps):
-        for r, m in ((0, A), (1, Bm)):
-            depth, _, sparse = [t.to(gpu) for t in O.synthetic_batch(2, 32, 64, seed=10 * s + r)]
-            out = m(depth, istrain=False)
-            loss, _, _ = U.dtod_loss(out, depth, sparse)
+        batches = [[t.to(gpu) for t in O.synthetic_batch(2, 32, 64, seed=10 * s + r)] for r in (0, 1)]
+        outs = [m(b[0], istrain=False) for m, b in zip((A, Bm), batches)]
+        ext = None
+        if global_berhu:        # what the 4-byte all-reduce(MAX) hands every rank
+            ext = torch.maximum(*[ops.absdiff_max(o.detach().contiguous(), b[0]) for o, b in zip(outs, batches)])
+        for r, (m, b, out) in enumerate(zip((A, Bm), batches, outs)):
+            depth, _, sparse = b
+            if ext is None:
+                loss, _, _ = U.dtod_loss(out, depth, sparse)
+            else:
+                o = out.detach().contiguous()
+                l0, l1 = torch.empty((), device=gpu), torch.empty((), device=gpu)
+                dp = torch.zeros_like(o)
+                ops.berhu_masked(o, depth, sparse, U.crop_box_kitti(32, 64), dp, l0, ext_max=ext)
+                ops.sobel_l1(o, depth, 3.0, dp, l1)
+                loss = l0 + l1
             m.zero_grad()
-            loss.backward()
+            if ext is None:
+                loss.backward()
+            else:
+                out.backward(dp)
             assert float(loss.detach()) == (r0 if r == 0 else r1)["losses"][s]
         A._gdn_param_arena.grad.add_(Bm._gdn_param_arena.grad)          # the SUM all-reduce
         opt.step()

@@ -47,7 +47,7 @@ __device__ __forceinline__ s16x4 tr_read(const lds_u8* p) {
 }
 
 template <int NTW, int XV, int GV>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16(const WgradBfParams p) {
+__device__ __forceinline__ void wgrad_bf16_body(const WgradBfParams& p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     lds_u8* smem = (lds_u8*)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -205,6 +205,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(const WgradBfParams p) {
     }
 }
 
+template <int NTW, int XV, int GV>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16(const WgradBfParams p) {
+    wgrad_bf16_body<NTW, XV, GV>(p);
+}
+// 7 and 9 accumulator tiles per wave (7x7 / 9x9 filter rows): 112-144 accumulator registers.  Left alone the compiler
+// hoists every fragment read of a k-step and lands at 300+ registers = ONE wave per SIMD; asking for two makes it keep
+// everything within 256 (no spills) and the second resident workgroup hides the LDS/barrier latency:
+// 9x9 586 -> 894, 7x7 616 -> 778, 7x7 stride-2 331 -> 492 TFLOP/s.
+template <int NTW, int XV, int GV>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_occ2(const WgradBfParams p) {
+    wgrad_bf16_body<NTW, XV, GV>(p);
+}
+
 // Sum the split-K slabs in a fixed order and scatter to the destination layout (same contract as
 // wgrad_reduce_kernel of conv_wgrad.hip).
 __global__ void wgrad_bf16_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int KK, int R,
@@ -333,8 +346,9 @@ int launch_cls(const WgradBfParams& P, int blocks, size_t lds, hipStream_t st) {
         case 2: case 3: WB_LAUNCH(3); break;
         case 4: WB_LAUNCH(4); break;
         case 5: WB_LAUNCH(5); break;
-        case 6: case 7: WB_LAUNCH(7); break;
-        default: WB_LAUNCH(9); break;
+        // 7 / 9 tiles: the two-waves-per-SIMD build (measured 9x9 586 -> 894, 7x7 616 -> 778 TFLOP/s)
+        case 6: case 7: hipLaunchKernelGGL((conv_wgrad_bf16_occ2<7, XV, GV>), grid, blk, lds, st, P); break;
+        default: hipLaunchKernelGGL((conv_wgrad_bf16_occ2<9, XV, GV>), grid, blk, lds, st, P); break;
     }
 #undef WB_LAUNCH
     return gdn_launch_status();
@@ -344,7 +358,7 @@ int launch_cls(const WgradBfParams& P, int blocks, size_t lds, hipStream_t st) {
 
 extern "C" size_t gdn_conv_wgrad_bf16_workspace_bytes(const gdn_conv_geom* g, int32_t Cx, int32_t cfg) {
     PlanBf pl;
-    if (!make_plan_bf(g, Cx, cfg, pl)) return 0;
+    if (!make_plan_bf(g, Cx, cfg & 3, pl)) return 0;
     return pl.ws_bytes;
 }
 
@@ -354,7 +368,7 @@ extern "C" int gdn_conv_wgrad_bf16(const gdn_conv_geom* g, const void* x, int32_
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!x || !dy || !dw) return GDN_ERR_BAD_ARG;
     PlanBf pl;
-    if (!make_plan_bf(g, Cx, cfg, pl)) return GDN_ERR_UNSUPPORTED;
+    if (!make_plan_bf(g, Cx, cfg & 3, pl)) return GDN_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < pl.ws_bytes) return GDN_ERR_WORKSPACE;
     WgradBfParams& P = pl.P;
     if (pl.transpose) { P.g = x; P.ldg = ldx; P.x = dy; P.ldx = ldy; }

@@ -96,7 +96,7 @@ def infer_main(args):
     import gdn_amd.AE_model_unet as M
     from gdn_amd import distributed as D
     rank, local_rank, world = D.init()
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if os.environ.get("GDN_SINGLE_DEVICE") == "1" else local_rank)   # (test hook: all ranks on one GPU)
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
     B = args.batch if args.batch != 20 else 64
@@ -186,7 +186,7 @@ def main():
     rank, local_rank, world = D.init()
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if os.environ.get("GDN_SINGLE_DEVICE") == "1" else local_rank)   # (test hook: all ranks on one GPU)
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
     B = args.batch

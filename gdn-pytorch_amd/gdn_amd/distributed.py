@@ -24,7 +24,9 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+            # "nccl" is RCCL on ROCm.  GDN_DIST_BACKEND=gloo is a test hook: RCCL refuses two ranks on one device, gloo
+            # moves the same buckets through the host, so the multi-rank code paths can be exercised on a 1-GPU box.
+            backend = os.environ.get("GDN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -346,3 +346,28 @@ def test_depth_extract_cli(gpu, tmp_path):
         b = np.asarray(Image.open(tmp_path / "o3" / ("im%d_depth.png" % i)))
         assert a.shape == (h, w) and a.dtype == np.uint16 and a.std() > 0
         assert np.array_equal(a, b)          # eval-mode BN: no cross-sample coupling, batching changes nothing
+
+
+def test_bench_contract_two_ranks(gpu):
+    """bench.py under torch.distributed.run with two ranks (test hooks: gloo + both ranks on cuda:0, since RCCL refuses
+    two ranks per device): barrier + max-over-ranks timing, one JSON line from rank 0 with the contract's fields."""
+    import json
+    import os
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = dict(os.environ, GDN_DIST_BACKEND="gloo", GDN_SINGLE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29513", str(root / "bench.py"), "--gpus", "2",
+                        "--steps", "2", "--warmup", "1", "--batch", "4", "--no-roofline"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in rec, k
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["global_batch"] == 8 and "cpu_baseline" not in rec

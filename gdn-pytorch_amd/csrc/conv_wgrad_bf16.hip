@@ -250,6 +250,7 @@ size_t lds_need(int nks, int nr, int rp) { return (size_t)nks * 16 * 128 + (size
 
 // cfg: 0 automatic, 1 force the small staging class (32-pixel pieces of one row), 2 force the large one
 bool make_plan_bf(const gdn_conv_geom* g, int Cx_in, int cfg, PlanBf& pl) {
+    const bool auto_cfg = cfg == 0;
     if (!g || g->k < 1 || g->k > WB_KMAX || g->stride < 1 || g->stride > 2) return false;
     int Ho, Wo;
     if (gdn_conv_out_dims(g, &Ho, &Wo) != GDN_OK) return false;
@@ -269,28 +270,37 @@ bool make_plan_bf(const gdn_conv_geom* g, int Cx_in, int cfg, PlanBf& pl) {
     if ((P.Cg % 64) || (P.Cx % 64)) return false;
     const int s = P.stride, k = P.k;
     // ---- segment geometry ----
+    // staging classes: 1 small (32-pixel pieces of one row: XV 3, GV 1), 3 medium (<= 112 flattened pixels: XV 4, GV 4,
+    // ~28 KB of LDS -> more workgroups per CU), 2 large (<= 208 pixels: XV 8, GV 7, ~55 KB of LDS)
     int tw = 0, nr = 1;
     pl.cls = 2;
-    if (P.Wg <= WB_SEGMAX && cfg != 1) {
+    // measured (profiles/r01_tune_conv_bf16_v4.txt): the medium class wins on the small levels (W <= 52: 3x3 @16x52
+    // 575 -> 644, @8x26 213 -> 355 TFLOP/s) and on 3x3 stride-1 at W = 104; wider rows / larger k prefer 208-pixel segments
+    if (cfg == 0 && (P.Wg <= 52 || (P.Wg <= 104 && s == 1 && k <= 3))) cfg = 3;
+    const int segmax = cfg == 3 ? 112 : WB_SEGMAX, xvmax = cfg == 3 ? 4 : 8;
+    if (cfg == 3) pl.cls = 3;
+    if (P.Wg <= segmax && cfg != 1) {
         // whole rows: as many as fit the staging class and ~60 KB of LDS
         const int npos = (P.Wg - 1) * s + k, xl = cdiv(npos, 32), rp = s == 2 ? 2 * ((npos + 1) / 2) : npos;
-        int n = WB_SEGMAX / P.Wg;
+        int n = segmax / P.Wg;
         if (n > 8) n = 8;
         if (n > P.Hg) n = P.Hg;
-        while (n >= 1 && (n * xl > 8 || lds_need(cdiv(n * P.Wg, 16), n, rp) > 60 * 1024)) --n;
+        while (n >= 1 && (n * xl > xvmax || lds_need(cdiv(n * P.Wg, 16), n, rp) > 60 * 1024)) --n;
         if (n >= 1) { tw = P.Wg; nr = n; }
     }
     if (tw == 0) {
         // a row that must be cut into pieces: for stride-2 layers the 104-pixel pieces of the large class (7 X passes per
         // piece, 7 k-steps) run 2.6x slower than 32-pixel pieces of the small class (measured: 128 vs 325-337 TFLOP/s)
-        if (cfg == 1 || (cfg == 0 && s == 2)) { tw = 32; pl.cls = 1; }
+        if (cfg == 1 || (auto_cfg && s == 2)) { tw = 32; pl.cls = 1; }
         else {
-            // widest piece of one row (multiple of 16) the large staging class holds, best row coverage first
+            // widest piece of one row the staging class holds, best row coverage first (multiples of 16, or an exact
+            // divisor of the row such as 104 = 208/2)
             double best_eff = 0.0;
-            for (int c = WB_SEGMAX; c >= 16; c -= 16) {
+            for (int c = segmax; c >= 16; --c) {
+                if ((c % 16) && (P.Wg % c)) continue;
                 const int npos = (c - 1) * s + k, rp = s == 2 ? 2 * ((npos + 1) / 2) : npos;
-                if (cdiv(npos, 32) > 8 || lds_need(c / 16, 1, rp) > 60 * 1024) continue;
-                const double eff = (double)P.Wg / (double)(cdiv(P.Wg, c) * c);
+                if (cdiv(npos, 32) > xvmax || lds_need(cdiv(c, 16), 1, rp) > 60 * 1024) continue;
+                const double eff = (double)P.Wg / (double)(cdiv(P.Wg, c) * cdiv(c, 16) * 16);
                 if (eff > best_eff + 1e-9) { best_eff = eff; tw = c; }
             }
             if (tw == 0) return false;
@@ -306,6 +316,7 @@ bool make_plan_bf(const gdn_conv_geom* g, int Cx_in, int cfg, PlanBf& pl) {
     const int xv = nr * P.xl, gv = cdiv(P.nks * 16, 32);
     if (pl.cls == 1 && (xv > 3 || gv > 1)) return false;
     if (pl.cls == 2 && (xv > 8 || gv > 7)) return false;
+    if (pl.cls == 3 && (xv > 4 || gv > 4)) return false;
     pl.lds_bytes = lds_need(P.nks, nr, P.rp);
     if (pl.lds_bytes > 64 * 1024) return false;
     P.n_cgt = P.Cg / 64; P.n_cxt = P.Cx / 64;
@@ -382,7 +393,9 @@ extern "C" int gdn_conv_wgrad_bf16(const gdn_conv_geom* g, const void* x, int32_
         P.g_bytes = (unsigned)gb; P.x_bytes = (unsigned)xb;
     }
     hipStream_t st = (hipStream_t)stream;
-    int rc = pl.cls == 1 ? launch_cls<3, 1>(P, pl.blocks, pl.lds_bytes, st) : launch_cls<8, 7>(P, pl.blocks, pl.lds_bytes, st);
+    int rc = pl.cls == 1 ? launch_cls<3, 1>(P, pl.blocks, pl.lds_bytes, st)
+           : pl.cls == 3 ? launch_cls<4, 4>(P, pl.blocks, pl.lds_bytes, st)
+                         : launch_cls<8, 7>(P, pl.blocks, pl.lds_bytes, st);
     if (rc != GDN_OK) return rc;
     const int KK = P.k * P.k;
     const int64_t n = (int64_t)KK * P.Cg * P.Cx;

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradParams p) {
     float* Xs = smem + TWMAX * WG_ROWS;
     // TWMAX == 32 is only launched with tw == 32: compile-time trip counts keep the 9-tile variant
     // at 2 waves/SIMD; every other segment width runs the TWMAX == 64 instantiation.
-    const int WG_TW = (TWMAX == 32) ? 32 : p.tw;
+    const int WG_TW = (TWMAX == 32 && WG_NTW >= 7) ? 32 : p.tw;     // small-tile variants also take tw < 32 (half the LDS: one more wave/SIMD)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave & 1, wc = wave >> 1;
@@ -524,7 +524,8 @@ extern "C" int gdn_conv_wgrad(const gdn_conv_geom* g, const void* xv, int32_t ld
     } else
 #define WG_LAUNCH(N)                                                                          \
     do {                                                                                      \
-        if (P.tw == 32) hipLaunchKernelGGL((conv_wgrad_f32<N, 32>), grid, blk, 0, st, P);     \
+        /* narrow rows (tw < 32, level 4) also fit the 32-pixel instantiation: half the LDS, one more wave per SIMD */  \
+        if (P.tw == 32 || (P.tw < 32 && N <= 5)) hipLaunchKernelGGL((conv_wgrad_f32<N, 32>), grid, blk, 0, st, P);     \
         else hipLaunchKernelGGL((conv_wgrad_f32<N, 64>), grid, blk, 0, st, P);                \
     } while (0)
     if (ntw <= 1) WG_LAUNCH(1);

@@ -633,10 +633,11 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const IgemmParams p) {
 #define RP_NRMAX 12          // image rows a 256-pixel tile may touch (W >= 26)
 #define RP_KMAX 9
 
-// (two waves per SIMD requested: the 256x64 form gains ~8 % from the tighter register allocation, the 256x128 form
-//  goes from one to two workgroups per CU, 503 -> 788 TFLOP/s on the 7x7 layer -- still short of the tap-major tile)
+// (three waves per SIMD requested: left alone the compiler takes 228 registers for the 256x64 form = two workgroups per
+//  CU; within 170 (166 used, no spills) three fit -- 52 KB of LDS each, 157 of 160 KB -- and the 9x9 64-channel layers go
+//  from 790-855 to 990-1040 TFLOP/s.  The 256x128 form cannot fit 170 and spills; it is kept for tuning runs only.)
 template <int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, 2) void conv_rowpatch_bf16(const IgemmParams p) {
+__global__ __launch_bounds__(256, 3) void conv_rowpatch_bf16(const IgemmParams p) {
     constexpr int BM = RP_BM, KC = 64, PITCH = 144;                  // bytes per staged row (128 data + 16 pad)
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -999,9 +1000,11 @@ int pick_cfg_bf16(const IgemmParams& P, int64_t M, int N, int forced) {
     const bool rp = rowpatch_ok(P);
     if (forced >= 1 && forced <= 3) return forced;
     if ((forced == 8 || forced == 9) && rp) return forced;
-    // measured (profiles/r01_tune_conv_bf16_rowpatch.txt): the row-patch kernel wins on the 64-channel 9x9 layers
-    // (256x64 tiles, 2 workgroups/CU); its 256x128 form runs at 1 workgroup/CU and loses to the tap-major tiles
-    if (rp && N <= 64 && cdiv64(M, RP_BM) >= 448) return 9;
+    // measured (profiles/r01_tune_conv_bf16_rowpatch.txt, _v5.txt): the 256x64 row-patch kernel at three workgroups per
+    // CU wins on the layers with <= 128 output channels (9x9 64ch: 1000 vs 640, 7x7 128ch: 900 vs 800 TFLOP/s); with 256+
+    // output channels the 128x128 tap-major tile re-uses each activation tile more and stays ahead; the 256x128 row-patch
+    // form (cfg 8, tuning only) never wins
+    if (rp && N <= 128 && cdiv64(M, RP_BM) * cdiv(N, 64) >= 448) return 9;
     if (N <= 64) return 2;
     return cdiv64(M, 128) * cdiv(N, 128) >= 384 ? 1 : 3;
 }

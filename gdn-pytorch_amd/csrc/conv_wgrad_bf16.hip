@@ -205,16 +205,19 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBfParams& p) {
     }
 }
 
-template <int NTW, int XV, int GV>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16(const WgradBfParams p) {
-    wgrad_bf16_body<NTW, XV, GV>(p);
+// Waves per SIMD the compiler is asked to fit.  Left alone it hoists every fragment read of a k-step and, for the 7- and
+// 9-tile variants, lands at 300+ registers = ONE wave per SIMD; within the budget (no spills) the extra resident
+// workgroups hide the LDS/barrier latency these short k-steps cannot: 9x9 586 -> 948, 7x7 616 -> 834 TFLOP/s.
+// The large staging class (XV 8) is limited to two workgroups per CU by its ~55 KB of LDS anyway.
+template <int NTW, int XV>
+constexpr int wb_min_waves() {
+    if (XV >= 8) return NTW >= 7 ? 2 : 1;
+    if (XV == 4 && NTW >= 7) return 2;          // (three would spill)
+    return NTW >= 9 ? 2 : NTW >= 4 ? 3 : NTW == 3 ? 4 : 1;
 }
-// 7 and 9 accumulator tiles per wave (7x7 / 9x9 filter rows): 112-144 accumulator registers.  Left alone the compiler
-// hoists every fragment read of a k-step and lands at 300+ registers = ONE wave per SIMD; asking for two makes it keep
-// everything within 256 (no spills) and the second resident workgroup hides the LDS/barrier latency:
-// 9x9 586 -> 894, 7x7 616 -> 778, 7x7 stride-2 331 -> 492 TFLOP/s.
+
 template <int NTW, int XV, int GV>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_occ2(const WgradBfParams p) {
+__global__ __launch_bounds__(256, (wb_min_waves<NTW, XV>())) void conv_wgrad_bf16(const WgradBfParams p) {
     wgrad_bf16_body<NTW, XV, GV>(p);
 }
 
@@ -357,9 +360,8 @@ int launch_cls(const WgradBfParams& P, int blocks, size_t lds, hipStream_t st) {
         case 2: case 3: WB_LAUNCH(3); break;
         case 4: WB_LAUNCH(4); break;
         case 5: WB_LAUNCH(5); break;
-        // 7 / 9 tiles: the two-waves-per-SIMD build (measured 9x9 586 -> 894, 7x7 616 -> 778 TFLOP/s)
-        case 6: case 7: hipLaunchKernelGGL((conv_wgrad_bf16_occ2<7, XV, GV>), grid, blk, lds, st, P); break;
-        default: hipLaunchKernelGGL((conv_wgrad_bf16_occ2<9, XV, GV>), grid, blk, lds, st, P); break;
+        case 6: case 7: WB_LAUNCH(7); break;
+        default: WB_LAUNCH(9); break;
     }
 #undef WB_LAUNCH
     return gdn_launch_status();

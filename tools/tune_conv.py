@@ -103,7 +103,7 @@ for (name, ci, co, k, s, p, refl, tr, H, W) in SHAPES:
     if BF16:
         dw = torch.empty(w.shape, device=dev)
         wg = []
-        for c in (0, 1, 3):         # automatic / small / medium staging class
+        for c in (0, 1, 3, 2):      # automatic / small / medium / large staging class
             try:
                 wg.append(gf / timeit(lambda: op.wgrad(x, gy, dw, cfg=c), reps=3))
             except Exception:

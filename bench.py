@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--fast-guide", action="store_true",
                     help="RtoD: one batched encoder-only guide pass (identical features) instead of the reference's "
                          "two full guide forwards")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole training step (forward, losses, backward, capturable fused Adam) in one hipGraph "
+                         "and replay it (single GPU; the RCCL all-reduce is not captured)")
     ap.add_argument("--latent-grad", action="store_true",
                     help="RtoD: back-propagate the latent loss through the frozen guide (--latent_grad of GDN_main)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
@@ -204,9 +207,10 @@ def main():
         G.compute_dtype(args.dtype)
         if args.latent_grad:
             G.requires_grad_(False)
-    opt = Adam(model.parameters(), 2e-5, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
+    use_graph = args.graph and world == 1
+    opt = Adam(model.parameters(), 2e-5, [0.9, 0.999], eps=1e-08, weight_decay=5e-4, capturable=use_graph)
 
-    def step():
+    def step_fn(depth, rgb, sparse):
         if args.mode == "DtoD":
             out = model(depth, istrain=False)
             loss, _, _ = U.dtod_loss(out, depth, sparse)
@@ -219,7 +223,17 @@ def main():
         loss.backward()
         D.sync_gradients(model, opt)
         opt.step()
-        return loss
+        return loss.detach()
+
+    graphed = None
+    if use_graph:
+        from gdn_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(step_fn, (depth, rgb, sparse), opt, warmup=2)     # (its warm-up steps are untimed extras)
+
+    def step():
+        if graphed is not None:
+            return graphed(depth, rgb, sparse)
+        return step_fn(depth, rgb, sparse)
 
     def barrier():
         if world > 1:
@@ -253,6 +267,7 @@ def main():
             "config": {"workload": "%s training step (fwd + losses + bwd + fused Adam), batch %d per GPU, 128x416, "
                                    "%s, BASELINE configs[%d]" % (args.mode, B, args.dtype, 1 if args.mode == "DtoD" else 2),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "launch": "hipGraph replay of the whole step" if graphed is not None else "eager",
                        "model_tflops_per_gpu": round(gflop_img * B * args.steps / dt / 1e3, 2),
                        "final_loss": round(final_loss, 6)},
         }

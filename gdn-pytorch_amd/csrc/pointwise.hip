@@ -360,6 +360,31 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// Capturable Adam: the step counter and the running powers beta^t live in device memory, so a captured training step
+// advances them on every replay.  state = { double beta1^t, double beta2^t, int32 t, float bc1, float bc2s }.
+struct AdamDevState { double p1, p2; int step; float bc1, bc2s; };
+__global__ void adam_prep_kernel(AdamDevState* st, const float* __restrict__ hyper) {
+    st->step += 1;
+    st->p1 *= (double)hyper[1];
+    st->p2 *= (double)hyper[2];
+    st->bc1 = (float)(1.0 - st->p1);
+    st->bc2s = (float)sqrt(1.0 - st->p2);
+}
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                       const float* __restrict__ hyper, const AdamDevState* st) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], gscale = hyper[5];
+    const float step = lr / st->bc1, bc2s = st->bc2s;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float pi = p[i];
+        const float gi = g[i] * gscale + wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = pi - step * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+
 }  // namespace
 
 #define ST(s) ((hipStream_t)(s))
@@ -565,6 +590,16 @@ extern "C" int gdn_adam_step(float* p, const float* g, float* m, float* v, int64
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n, 256, 4096)), dim3(256), 0, ST(stream), p, g, m, v, n, lr,
                        beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, void* state,
+                                 void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    if (!p || !g || !m || !v || n <= 0 || !hyper || !state) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, ST(stream), (AdamDevState*)state, hyper);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(stream_blocks(n, 256, 4096)), dim3(256), 0, ST(stream), p, g, m, v, n, hyper,
+                       (const AdamDevState*)state);
     return gdn_launch_status();
 }
 

@@ -71,6 +71,7 @@ _SIGS = {
     "gdn_depth_metrics_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "gdn_depth_metrics": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, _P, _P, _sz, _P]),
     "gdn_adam_step": (c_int32, [_P, _P, _P, _P, _i64, _f, _f, _f, _f, _f, _i32, _f, _P]),
+    "gdn_adam_step_dev": (c_int32, [_P, _P, _P, _P, _i64, _P, _P, _P]),
 }
 _STATUS_FUNCS = {n for n, (r, _) in _SIGS.items() if r is c_int32} - {"gdn_version", "gdn_device_info"}
 

@@ -15,6 +15,13 @@ from ._lib import GdnError
 
 _ALIGN = 64  # floats
 _FUSE_EVAL_BN = os.environ.get("GDN_FUSE_EVAL_BN", "1") != "0"     # A/B switch for measurements
+_GRAPH_EPOCH = 0
+
+
+def bump_graph_epoch():
+    """A graph replay changed parameters / BN buffers without touching torch's version counters: drop derived caches."""
+    global _GRAPH_EPOCH
+    _GRAPH_EPOCH += 1
 
 
 # ----------------------------------------------------------------------------
@@ -79,7 +86,7 @@ class ParamArena:
 
     def bf16_data(self):
         """bf16 shadow of the parameter arena (same offsets/layout), re-cast when the master changed."""
-        key = (self.generation, self.data._version)
+        key = (self.generation, self.data._version, _GRAPH_EPOCH)
         if self.data16 is None:
             self.data16 = torch.empty(self.numel, dtype=torch.bfloat16, device=self.device)
             self._key16 = None
@@ -242,7 +249,7 @@ def _wgrad_into(ctx, mod, x, dy, x2=None):
 
 def _eval_coeffs(bn):
     """scale/shift of an eval-mode BatchNorm, cached until its tensors change."""
-    key = (getattr(bn, "_gdn_stats_ver", 0), bn.running_mean._version, bn.running_var._version,
+    key = (_GRAPH_EPOCH, getattr(bn, "_gdn_stats_ver", 0), bn.running_mean._version, bn.running_var._version,
            bn.weight._version, bn.bias._version, bn.running_mean.data_ptr(), bn.weight.data_ptr())
     c = getattr(bn, "_gdn_eval_cache", None)
     if c is None or c[0] != key:

@@ -399,3 +399,8 @@ def kitti_augment(src, params, train=True):
     lib.gdn_kitti_augment(_p(src), 1 if src.dtype == torch.float32 else 0, B, H, W, C, _p(params), 1 if train else 0,
                           _p(dst), _p(ws), nb, stream())
     return dst
+
+
+def adam_step_dev(p, g, m, v, hyper, state):
+    """Capturable Adam: hyper float32[6] and state uint8[32] live on the device (see gdn_adam_step_dev)."""
+    lib.gdn_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _p(state), stream())

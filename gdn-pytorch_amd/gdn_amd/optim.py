@@ -12,11 +12,30 @@ from ._lib import GdnError
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self._flat = {}        # id(arena) -> {"m","v","step"}
         self.grad_scale = 1.0  # set to 1/world_size by the data-parallel wrapper
+        # capturable: the step counter, beta^t and the hyper-parameters live in device memory (gdn_adam_step_dev), so
+        # step() can be captured in a hipGraph and replayed; call refresh_hyper() after changing lr outside a capture
+        self.capturable = bool(capturable)
+
+    def refresh_hyper(self):
+        """Push (lr, betas, eps, weight_decay, grad_scale) to the device buffers of the capturable path if they changed."""
+        for group in self.param_groups:
+            for st in list(self._flat.values()) + [self.state[p] for p in group["params"] if p in self.state]:
+                if "hyper" in st and st.get("group") is group:
+                    self._push_hyper(st, group)
+
+    def _push_hyper(self, st, group):
+        vals = (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
+                float(group["weight_decay"]), float(self.grad_scale))
+        if st.get("hyper_host") != vals:
+            if torch.cuda.is_current_stream_capturing():
+                raise GdnError("optimizer hyper-parameters changed inside a graph capture; call refresh_hyper() before it")
+            st["hyper"].copy_(torch.tensor(vals, dtype=torch.float32))
+            st["hyper_host"] = vals
 
     def _arena_groups(self, group):
         """Split a param group into (arena, covers_whole_arena) and stragglers."""
@@ -28,6 +47,24 @@ class Adam(torch.optim.Optimizer):
             else:
                 loose.append(p)
         return arenas, loose
+
+    def _apply(self, pdata, grad, st, group, device):
+        b1, b2 = group["betas"]
+        if self.capturable:
+            if "hyper" not in st:
+                import struct
+                st["hyper"] = torch.zeros(6, dtype=torch.float32, device=device)
+                # {double beta1^t, double beta2^t, int32 t, float bc1, float bc2s}; a host-side step count from before
+                # (resume) is folded in by advancing the powers on the host first
+                t = st["step"] - 1
+                raw = struct.pack("<ddiff", float(b1) ** t, float(b2) ** t, t, 0.0, 0.0)
+                st["state"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+                st["group"] = group
+            self._push_hyper(st, group)
+            ops.adam_step_dev(pdata, grad, st["m"], st["v"], st["hyper"], st["state"])
+        else:
+            ops.adam_step(pdata, grad, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                          st["step"], self.grad_scale)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -49,8 +86,7 @@ class Adam(torch.optim.Optimizer):
                     st = {"m": ops.zeros((ar.numel,), ar.device), "v": ops.zeros((ar.numel,), ar.device), "step": 0}
                     self._flat[id(ar)] = st
                 st["step"] += 1
-                ops.adam_step(ar.data, ar.grad, st["m"], st["v"], group["lr"], b1, b2, group["eps"],
-                              group["weight_decay"], st["step"], self.grad_scale)
+                self._apply(ar.data, ar.grad, st, group, ar.device)
                 ar.touch()        # the kernel wrote the parameters behind torch's back: bf16 shadows are stale
             for p in loose:
                 if p.grad is None:
@@ -66,8 +102,7 @@ class Adam(torch.optim.Optimizer):
                 g = p.grad
                 if g.stride() != p.stride():
                     g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
-                ops.adam_step(p.data, g, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"],
-                              st["step"], self.grad_scale)
+                self._apply(p.data, g, st, group, p.device)
                 if getattr(p, "_gdn_arena", None) is not None:
                     p._gdn_arena.touch()
         return loss

@@ -285,6 +285,12 @@ int gdn_kitti_augment(const void* src, int32_t src_is_f32, int32_t B, int32_t H,
 int gdn_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay,
                   int32_t step, float grad_scale, void* stream);
+/* The same update with every step-dependent scalar in DEVICE memory, so the launch can be captured in a hipGraph and
+ * replayed: hyper = float[6] {lr, beta1, beta2, eps, weight_decay, grad_scale} (the host rewrites it when the schedule
+ * changes the learning rate); state = 32 bytes {double beta1^t, double beta2^t, int32 t, float bc1, float bc2s},
+ * initialised to {1.0, 1.0, 0, 0, 0} and advanced by the call itself. */
+int gdn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
+                      const float* hyper, void* state, void* stream);
 
 #ifdef __cplusplus
 }

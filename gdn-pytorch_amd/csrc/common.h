@@ -66,6 +66,33 @@ __device__ __forceinline__ void st4_any(void* p, size_t idx, f32x4 v, int bf16) 
     u.y = (unsigned)f32_to_bf16_h(v[2]) | ((unsigned)f32_to_bf16_h(v[3]) << 16);
     *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p) + idx) = u;
 }
+// 8 consecutive elements (two f32x4 halves): one 16-byte access for bf16, two for fp32
+__device__ __forceinline__ void ld8_any(const void* p, size_t idx, int bf16, f32x4& lo, f32x4& hi) {
+    if (!bf16) {
+        lo = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + idx);
+        hi = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + idx + 4);
+        return;
+    }
+    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p) + idx);
+    lo[0] = __uint_as_float(u.x << 16); lo[1] = __uint_as_float(u.x & 0xffff0000u);
+    lo[2] = __uint_as_float(u.y << 16); lo[3] = __uint_as_float(u.y & 0xffff0000u);
+    hi[0] = __uint_as_float(u.z << 16); hi[1] = __uint_as_float(u.z & 0xffff0000u);
+    hi[2] = __uint_as_float(u.w << 16); hi[3] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void st8_any(void* p, size_t idx, f32x4 lo, f32x4 hi, int bf16) {
+    if (!bf16) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p) + idx) = lo;
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p) + idx + 4) = hi;
+        return;
+    }
+    uint4 u;
+    u.x = (unsigned)f32_to_bf16_h(lo[0]) | ((unsigned)f32_to_bf16_h(lo[1]) << 16);
+    u.y = (unsigned)f32_to_bf16_h(lo[2]) | ((unsigned)f32_to_bf16_h(lo[3]) << 16);
+    u.z = (unsigned)f32_to_bf16_h(hi[0]) | ((unsigned)f32_to_bf16_h(hi[1]) << 16);
+    u.w = (unsigned)f32_to_bf16_h(hi[2]) | ((unsigned)f32_to_bf16_h(hi[3]) << 16);
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p) + idx) = u;
+}
+
 __device__ __forceinline__ float ld1_any(const void* p, size_t idx, int bf16) {
     return bf16 ? bf16_h_to_f32(reinterpret_cast<const unsigned short*>(p)[idx]) : reinterpret_cast<const float*>(p)[idx];
 }

@@ -88,6 +88,35 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ 
     }
 }
 
+// bf16 tensors: 8 channels per lane (16-byte accesses); same arithmetic
+__global__ __launch_bounds__(256) void bn_apply8_kernel(const void* __restrict__ y, int ldy,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        const void* __restrict__ res, int ld_res,
+                                                        void* __restrict__ out, int ld_out, int64_t npix, int C,
+                                                        int relu, int dt, int sh) {
+    const int co = C >> 3;
+    const int64_t total = npix * co;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = sh >= 0 ? (i >> sh) : i / co;
+        const int c = (int)(sh >= 0 ? (i & (co - 1)) : (i - pix * co)) * 8;
+        f32x4 v0, v1;
+        ld8_any(y, pix * ldy + c, dt & 1, v0, v1);
+        f32x4 o0 = v0 * *reinterpret_cast<const f32x4*>(scale + c) + *reinterpret_cast<const f32x4*>(shift + c);
+        f32x4 o1 = v1 * *reinterpret_cast<const f32x4*>(scale + c + 4) + *reinterpret_cast<const f32x4*>(shift + c + 4);
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o0[e] = fmaxf(o0[e], 0.f); o1[e] = fmaxf(o1[e], 0.f); }
+        }
+        if (res) {
+            f32x4 r0, r1;
+            ld8_any(res, pix * ld_res + c, dt & 2, r0, r1);
+            o0 += r0; o1 += r1;
+        }
+        st8_any(out, pix * ld_out + c, o0, o1, dt & 4);
+    }
+}
+
 // ----------------------------------------------------------------- BN backward
 #define BNB_MAXBLK 1024
 // pass 1: partial[blk][2][C] = sum over the block's pixels of dz, dz*xhat
@@ -186,6 +215,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             o[e] = s[e] * (dz - a[e] - xh * b[e]);
         }
         st4_any(dy, pix * ld_dy + c, o, dt & 4);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(
+    const void* __restrict__ dout, int ld_dout, const void* __restrict__ y, int ldy,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ k1, const float* __restrict__ k2,
+    void* __restrict__ dy, int ld_dy, int64_t npix, int C, int relu, int dt, int sh) {
+    const int co = C >> 3;
+    const int64_t total = npix * co;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = sh >= 0 ? (i >> sh) : i / co;
+        const int c = (int)(sh >= 0 ? (i & (co - 1)) : (i - pix * co)) * 8;
+        f32x4 d[2], v[2], o[2];
+        ld8_any(dout, pix * ld_dout + c, dt & 1, d[0], d[1]);
+        ld8_any(y, pix * ldy + c, dt & 2, v[0], v[1]);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c + 4 * hh);
+            const f32x4 t = *reinterpret_cast<const f32x4*>(shift + c + 4 * hh);
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c + 4 * hh);
+            const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c + 4 * hh);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(k1 + c + 4 * hh);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(k2 + c + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float dz = d[hh][e];
+                if (relu && !(v[hh][e] * s[e] + t[e] > 0.f)) dz = 0.f;
+                const float xh = (v[hh][e] - mu[e]) * is[e];
+                o[hh][e] = s[e] * (dz - a[e] - xh * b[e]);
+            }
+        }
+        st8_any(dy, pix * ld_dy + c, o[0], o[1], dt & 4);
     }
 }
 
@@ -415,6 +477,11 @@ extern "C" int gdn_bn_apply(const void* y, int32_t ldy, const float* scale, cons
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!y || !scale || !shift || !out || npix <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
     if ((C % 4) || (ldy % 4) || (ld_out % 4) || (residual && (ld_res % 4))) return GDN_ERR_UNSUPPORTED;
+    if (dtypes && (C % 8) == 0 && (ldy % 8) == 0 && (ld_out % 8) == 0 && (!residual || (ld_res % 8) == 0)) {
+        hipLaunchKernelGGL(bn_apply8_kernel, dim3(stream_blocks(npix * (C / 8))), dim3(256), 0, ST(stream), y, ldy, scale,
+                           shift, residual, ld_res, out, ld_out, npix, C, relu, dtypes, pow2_shift(C / 8));
+        return gdn_launch_status();
+    }
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, ST(stream), y, ldy, scale,
                        shift, residual, ld_res, out, ld_out, npix, C, relu, dtypes, pow2_shift(C / 4));
     return gdn_launch_status();
@@ -447,6 +514,11 @@ extern "C" int gdn_bn_bwd(const void* dout, int32_t ld_dout, const void* y, int3
                        mean, invstd, partial, npix, C, relu, dtypes);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, ST(stream), (const float*)partial, nblk, C,
                        (double)npix, dgamma, dbeta, k1, k2);
+    if (dtypes && (C % 8) == 0 && (ldy % 8) == 0 && (ld_dout % 8) == 0 && (ld_dy % 8) == 0)
+        hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(stream_blocks(npix * (C / 8))), dim3(256), 0, ST(stream), dout,
+                           ld_dout, y, ldy, scale, shift, mean, invstd, (const float*)k1, (const float*)k2, dy, ld_dy,
+                           npix, C, relu, dtypes, pow2_shift(C / 8));
+    else
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, ST(stream), dout,
                        ld_dout, y, ldy, scale, shift, mean, invstd, (const float*)k1, (const float*)k2, dy, ld_dy, npix,
                        C, relu, dtypes, pow2_shift(C / 4));

@@ -1,0 +1,539 @@
+// FFT-domain convolution for the large-window residual layers (9x9 on 64 channels, 7x7 on 128): 67 % of G's FLOPs.
+//
+// A k x k stride-1 "same" convolution costs k*k MACs per (pixel, cin, cout); in the frequency domain it costs one
+// complex MAC (4 real) per (frequency bin, cin, cout) plus transforms that are linear in the tensor size.  With 32x32
+// tiles (overlap-save: T = 33 - k valid outputs per tile side, T = 24 for 9x9, 26 for 7x7) the multiply count drops
+// 81 -> 4*(32/24)^2*(17/32)*2 = 7.6 (9x9) and 49 -> 6.4 (7x7), and -- at fp32 MFMA speed, where the direct kernels
+// already sit at 0.82 of peak -- that is the only lever left that is worth a factor.  Accuracy is not traded: each output
+// sums 64-128 products per bin instead of 5184-6272, and measured against an fp64 convolution the tiled fp32 FFT result is
+// closer than the direct fp32 sum (oracle experiment in DESIGN.md).
+//
+// Pipeline (all tensors NHWC, channels contiguous, so every global access is a full 256/512-byte line):
+//   rows   x  -> R   [tile][32 rows][17 kx][C] complex     real FFT32 along x of each patch row (zero padding = halo)
+//   cols   R  -> Xf  [bin = ky*17+kx][tile][C] complex      FFT32 along y
+//   wdft   w  -> Wf  [bin][2*Cout][2*Cin] real              direct DFT of the k*k taps, laid out as the REAL embedding of
+//                                                           the complex product (conjugated: correlation)
+//   gemm   Yf[bin] = Xf[bin] * Wf[bin]^T                    one real GEMM per bin, M = tiles, K = 2*Cin, N = 2*Cout (MFMA)
+//   icols  Yf -> S   [tile][T rows][17 kx][Cout] complex    inverse FFT32 along ky
+//   irows  S  -> y                                          Hermitian inverse FFT32 along kx, valid T x T outputs,
+//                                                           1/1024 scale, + residual, BatchNorm sum / sum-of-squares partials
+#include "common.h"
+
+#define FFT_N 32
+#define FFT_NK 17            // kx bins kept of a real row transform
+#define FFT_BINS (FFT_N * FFT_NK)
+
+namespace {
+
+// cos/sin(2*pi*j/32), j = 0..31
+__device__ __constant__ float kCos32[32] = {
+    1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f,
+    0.38268343236508984f, 0.19509032201612833f, 0.0f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f,
+    -0.70710678118654746f, -0.83146961230254535f, -0.92387953251128674f, -0.98078528040323043f, -1.0f,
+    -0.98078528040323043f, -0.92387953251128685f, -0.83146961230254546f, -0.70710678118654768f, -0.55557023301960218f,
+    -0.38268343236509034f, -0.19509032201612866f, 0.0f, 0.19509032201612830f, 0.38268343236509000f, 0.55557023301960184f,
+    0.70710678118654735f, 0.83146961230254524f, 0.92387953251128652f, 0.98078528040323032f};
+__device__ __constant__ float kSin32[32] = {
+    0.0f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f, 0.83146961230254524f,
+    0.92387953251128674f, 0.98078528040323043f, 1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f,
+    0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f, 0.0f,
+    -0.19509032201612836f, -0.38268343236508967f, -0.55557023301960196f, -0.70710678118654746f, -0.83146961230254524f,
+    -0.92387953251128652f, -0.98078528040323032f, -1.0f, -0.98078528040323043f, -0.92387953251128663f,
+    -0.83146961230254546f, -0.70710678118654768f, -0.55557023301960218f, -0.38268343236509039f, -0.19509032201612872f};
+
+// In-register radix-2 decimation-in-time FFT of 32 complex points.  SIGN = -1 forward, +1 inverse (unscaled).
+// The loops are fully unrolled, so every twiddle index is a compile-time constant.
+template <int SIGN>
+__device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
+    // bit reversal (5 bits)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int j = ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
+        if (j > i) {
+            const float tr = re[i], ti = im[i];
+            re[i] = re[j]; im[i] = im[j];
+            re[j] = tr; im[j] = ti;
+        }
+    }
+#pragma unroll
+    for (int s = 1; s <= 5; ++s) {
+        const int half = 1 << (s - 1), span = 1 << s, tstep = 32 >> s;
+#pragma unroll
+        for (int k = 0; k < 32; k += span) {
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const float wr = kCos32[j * tstep], wi = SIGN * kSin32[j * tstep];
+                const int a = k + j, b = a + half;
+                const float xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - xr; im[b] = im[a] - xi;
+                re[a] += xr; im[a] += xi;
+            }
+        }
+    }
+}
+
+struct FftGeom {
+    int B, H, W, C, N;           // input [B,H,W,C], output channels N
+    int k, pad, T, tiles_y, tiles_x, M;      // M = B * tiles_y * tiles_x
+};
+
+// rows: thread = (tile, patch row a, channel c); c fastest -> every load / store of a wave is one contiguous line
+__global__ __launch_bounds__(256) void fft_rows_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ R,
+                                                       FftGeom g, int halo /* 1: patch = outputs - pad (overlap-save); 0: tile only */) {
+    const int C = g.C;
+    const int64_t total = (int64_t)g.M * FFT_N * C;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int a = (int)(r % FFT_N);
+        const int t = (int)(r / FFT_N);
+        const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
+        const int iy = ty * g.T + a - (halo ? g.pad : 0);
+        const int ix0 = tx * g.T - (halo ? g.pad : 0);
+        const int nvalid = halo ? FFT_N : g.T;          // tile-only mode: positions >= T (and rows >= T) are zero padding
+        float re[32], im[32];
+        const bool row_ok = iy >= 0 && iy < g.H && a < nvalid;
+        const float* src = x + ((size_t)(b * g.H + (row_ok ? iy : 0)) * g.W) * ldx + c;
+#pragma unroll
+        for (int bb = 0; bb < 32; ++bb) {
+            const int ix = ix0 + bb;
+            re[bb] = (row_ok && bb < nvalid && ix >= 0 && ix < g.W) ? src[(size_t)ix * ldx] : 0.f;
+            im[bb] = 0.f;
+        }
+        fft32<-1>(re, im);
+        float2* dst = R + (((size_t)t * FFT_N + a) * FFT_NK) * C + c;
+#pragma unroll
+        for (int kx = 0; kx < FFT_NK; ++kx) dst[(size_t)kx * C] = make_float2(re[kx], im[kx]);
+    }
+}
+
+// cols: thread = (tile, kx, channel): FFT32 along the patch rows; output bin-major for the per-bin GEMM
+__global__ __launch_bounds__(256) void fft_cols_kernel(const float2* __restrict__ R, float2* __restrict__ Xf, int C, int M) {
+    const int64_t total = (int64_t)M * FFT_NK * C;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int kx = (int)(r % FFT_NK);
+        const int t = (int)(r / FFT_NK);
+        float re[32], im[32];
+        const float2* src = R + (((size_t)t * FFT_N) * FFT_NK + kx) * C + c;
+#pragma unroll
+        for (int a = 0; a < 32; ++a) { const float2 v = src[(size_t)a * FFT_NK * C]; re[a] = v.x; im[a] = v.y; }
+        fft32<-1>(re, im);
+#pragma unroll
+        for (int ky = 0; ky < 32; ++ky) Xf[((size_t)(ky * FFT_NK + kx) * M + t) * C + c] = make_float2(re[ky], im[ky]);
+    }
+}
+
+// weights: direct DFT of the k*k taps at every kept bin, written as the real embedding of the complex matrix.
+//   mode 0 (forward, correlation): Wc = conj(DFT(w[n][c]))       -> Bm[bin][2n+p][2c+q]
+//   mode 1 (data gradient, convolution with roles swapped): Wc = DFT(w[n][c]), output index c, reduction index n
+// Bm rows are output reals, columns reduction reals: out_re = sum in_re*Wr - in_im*Wi, out_im = sum in_re*Wi + in_im*Wr.
+__global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restrict__ w /* [k*k][N][C] */, float* __restrict__ Bm,
+                                                          int N, int C, int k, int mode) {
+    const int bin = blockIdx.y, ky = bin / FFT_NK, kx = bin % FFT_NK;
+    const int OUT = mode == 0 ? N : C, RED = mode == 0 ? C : N;
+    float* dst = Bm + (size_t)bin * (2 * OUT) * (2 * RED);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N * C; i += gridDim.x * 256) {
+        const int c = i % C, n = i / C;
+        float wr = 0.f, wi = 0.f;
+        for (int ty = 0; ty < k; ++ty)
+            for (int tx = 0; tx < k; ++tx) {
+                const int ph = (ky * ty + kx * tx) & 31;
+                const float v = w[((size_t)(ty * k + tx) * N + n) * C + c];
+                wr += v * kCos32[ph];
+                wi -= v * kSin32[ph];          // e^{-i phi}
+            }
+        if (mode == 0) wi = -wi;              // conjugate: correlation
+        const int o = mode == 0 ? n : c, r = mode == 0 ? c : n;
+        float* row_re = dst + (size_t)(2 * o) * (2 * RED) + 2 * r;
+        float* row_im = dst + (size_t)(2 * o + 1) * (2 * RED) + 2 * r;
+        row_re[0] = wr; row_re[1] = -wi;
+        row_im[0] = wi; row_im[1] = wr;
+    }
+}
+
+// Per-bin real GEMM  Cm[bin][m][n] = sum_k A[bin][m][k] * Bm[bin][n][k]   (M x K times N x K, both K-contiguous).
+// 64x64 tile, 4 waves of one 32x32 MFMA tile, 32-wide k-steps, the LDS image / fragment scheme of conv_igemm_f32.
+__global__ __launch_bounds__(256) void gemm_bins_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                        float* __restrict__ Cm, int M, int N, int K) {
+    constexpr int LD = 36;
+    __shared__ __attribute__((aligned(16))) float As[64 * LD], Bs[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int bin = blockIdx.z, m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const float* Ab = A + (size_t)bin * M * K;
+    const float* Bb = Bm + (size_t)bin * N * K;
+    float* Cb = Cm + (size_t)bin * M * N;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int lr = tid >> 3, lc = (tid & 7) * 4;          // staging: 32 rows per pass, 8 lanes x 16 B per row
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int m = m0 + ps * 32 + lr, n = n0 + ps * 32 + lr;
+            ra[ps] = m < M ? *reinterpret_cast<const f32x4*>(Ab + (size_t)m * K + k0 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[ps] = n < N ? *reinterpret_cast<const f32x4*>(Bb + (size_t)n * K + k0 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            *reinterpret_cast<f32x4*>(&As[(ps * 32 + lr) * LD + lc]) = ra[ps];
+            *reinterpret_cast<f32x4*>(&Bs[(ps * 32 + lr) * LD + lc]) = rb[ps];
+        }
+    };
+    const int a_off = (wm * 32 + (lane & 31)) * LD + (lane >> 5) * 16;
+    const int b_off = (wn * 32 + (lane & 31)) * LD + (lane >> 5) * 16;
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        if (k0 + 32 < K) gload(k0 + 32);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[a_off + g4 * 4]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[b_off + g4 * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+        }
+        __syncthreads();
+        if (k0 + 32 < K) { lstore(); __syncthreads(); }
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M && col < N) Cb[(size_t)m * N + col] = acc[r];
+    }
+}
+
+// icols: thread = (tile, kx, channel n): inverse FFT32 along ky, rows u < nrows kept
+__global__ __launch_bounds__(256) void ifft_cols_kernel(const float2* __restrict__ Yf, float2* __restrict__ S, int C, int M, int nrows) {
+    const int64_t total = (int64_t)M * FFT_NK * C;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int kx = (int)(r % FFT_NK);
+        const int t = (int)(r / FFT_NK);
+        float re[32], im[32];
+#pragma unroll
+        for (int ky = 0; ky < 32; ++ky) {
+            const float2 v = Yf[((size_t)(ky * FFT_NK + kx) * M + t) * C + c];
+            re[ky] = v.x; im[ky] = v.y;
+        }
+        fft32<1>(re, im);
+        float2* dst = S + (((size_t)t * FFT_N) * FFT_NK + kx) * C + c;
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+            if (u < nrows) dst[(size_t)u * FFT_NK * C] = make_float2(re[u], im[u]);
+    }
+}
+
+// irows: thread = (tile, row u, channel n): Hermitian inverse along kx; writes the valid T outputs of the row into y
+// (+ addsrc), and per-workgroup BatchNorm partial sums.  grid.x = ceil(M*T / 4) workgroups of 4 rows x 64 channels ... the
+// host passes rows_per_wg = 256 / C.
+__global__ __launch_bounds__(256) void ifft_rows_kernel(const float2* __restrict__ S, float* __restrict__ y, int ldy,
+                                                        const float* __restrict__ addsrc, int ld_add,
+                                                        float* __restrict__ stats, FftGeom g) {
+    __shared__ float red[256 * 2];
+    const int C = g.N, T = g.T;
+    const int rows_per_wg = 256 / C;
+    const int c = threadIdx.x % C, rl = threadIdx.x / C;
+    const int64_t row_id = (int64_t)blockIdx.x * rows_per_wg + rl;          // = t * T + u
+    float s1 = 0.f, s2 = 0.f;
+    if (rl < rows_per_wg && row_id < (int64_t)g.M * T) {
+        const int t = (int)(row_id / T), u = (int)(row_id % T);
+        const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
+        const int oy = ty * T + u;
+        if (oy < g.H) {
+            float re[32], im[32];
+            const float2* src = S + (((size_t)t * FFT_N + u) * FFT_NK) * C + c;
+#pragma unroll
+            for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = src[(size_t)kx * C]; re[kx] = v.x; im[kx] = v.y; }
+#pragma unroll
+            for (int kx = FFT_NK; kx < 32; ++kx) { re[kx] = re[32 - kx]; im[kx] = -im[32 - kx]; }
+            fft32<1>(re, im);
+            float* dst = y + ((size_t)(b * g.H + oy) * g.W) * ldy + c;
+            const float* ad = addsrc ? addsrc + ((size_t)(b * g.H + oy) * g.W) * ld_add + c : nullptr;
+#pragma unroll
+            for (int v = 0; v < 32; ++v) {
+                const int ox = tx * T + v;
+                if (v < T && ox < g.W) {
+                    const float val = re[v] * (1.0f / 1024.0f);
+                    s1 += val; s2 += val * val;
+                    dst[(size_t)ox * ldy] = ad ? val + ad[(size_t)ox * ld_add] : val;
+                }
+            }
+        }
+    }
+    if (stats) {
+        red[threadIdx.x * 2] = s1; red[threadIdx.x * 2 + 1] = s2;
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float a1 = 0.f, a2 = 0.f;
+            for (int j = 0; j < rows_per_wg; ++j) { a1 += red[(j * C + threadIdx.x) * 2]; a2 += red[(j * C + threadIdx.x) * 2 + 1]; }
+            stats[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = a1;
+            stats[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = a2;
+        }
+    }
+}
+
+
+// Reduction-over-tiles GEMM of the weight gradient:  P[bin][i][j] = sum_m A[bin][m][i] * Bm[bin][m][j]
+// (A = spectrum of dy [M][2N], Bm = spectrum of x [M][2C]; both operands are read as they lie, rows = tiles).
+// 64x64 output tile, 32 tiles of the reduction per step; every MFMA operand is one conflict-free ds_read_b32 row read.
+__global__ __launch_bounds__(256) void gemm_tn_bins_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                           float* __restrict__ P, int M, int NI, int NJ) {
+    constexpr int LD = 64;
+    __shared__ __attribute__((aligned(16))) float As[32 * LD], Bs[32 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wi = wave >> 1, wj = wave & 1;
+    const int bin = blockIdx.z, i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const float* Ab = A + (size_t)bin * M * NI + i0;
+    const float* Bb = Bm + (size_t)bin * M * NJ + j0;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int lr = tid >> 4, lc = (tid & 15) * 4;         // 16 rows per pass, 16 lanes x 16 B per row
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int m0) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int m = m0 + ps * 16 + lr;
+            ra[ps] = m < M ? *reinterpret_cast<const f32x4*>(Ab + (size_t)m * NI + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[ps] = m < M ? *reinterpret_cast<const f32x4*>(Bb + (size_t)m * NJ + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            *reinterpret_cast<f32x4*>(&As[(ps * 16 + lr) * LD + lc]) = ra[ps];
+            *reinterpret_cast<f32x4*>(&Bs[(ps * 16 + lr) * LD + lc]) = rb[ps];
+        }
+    };
+    const int a_off = (lane >> 5) * LD + wi * 32 + (lane & 31);
+    const int b_off = (lane >> 5) * LD + wj * 32 + (lane & 31);
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int m0 = 0; m0 < M; m0 += 32) {
+        if (m0 + 32 < M) gload(m0 + 32);
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[a_off + kk * LD], Bs[b_off + kk * LD], acc, 0, 0, 0);
+        __syncthreads();
+        if (m0 + 32 < M) { lstore(); __syncthreads(); }
+    }
+    float* Pb = P + (size_t)bin * NI * NJ;
+    const int col = j0 + wj * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        Pb[(size_t)i * NJ + col] = acc[r];
+    }
+}
+
+// Inverse DFT of the weight-gradient spectrum at the k*k taps.  P[bin][2n+p][2c+q] = sum_m D_p X_q;
+// dWf = conj(D) X = (P00 + P11) + i (P01 - P10); Hermitian weights 1 (kx = 0, 16) / 2 over the 17 kept kx bins.
+// thread = (n, c); one tap row (fixed ty) per blockIdx.y so the accumulators stay in registers.
+template <int K>
+__global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C) {
+    const int ty = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int c = i % C, n = i / C;
+    float acc[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) acc[t] = 0.f;
+    const size_t rs = (size_t)2 * C;
+    for (int ky = 0; ky < FFT_N; ++ky) {
+        for (int kx = 0; kx < FFT_NK; ++kx) {
+            const float* pb = P + (size_t)(ky * FFT_NK + kx) * (2 * N) * rs + (size_t)(2 * n) * rs + 2 * c;
+            const float2 p0 = *reinterpret_cast<const float2*>(pb);
+            const float2 p1 = *reinterpret_cast<const float2*>(pb + rs);
+            const float alpha = (kx == 0 || kx == 16) ? 1.f : 2.f;
+            const float fr = (p0.x + p1.y) * alpha, fi = (p0.y - p1.x) * alpha;
+            const int base = ky * ty;
+#pragma unroll
+            for (int tx = 0; tx < K; ++tx) {
+                const int ph = (base + kx * tx) & 31;
+                acc[tx] += fr * kCos32[ph] - fi * kSin32[ph];
+            }
+        }
+    }
+#pragma unroll
+    for (int tx = 0; tx < K; ++tx) dw[((size_t)(ty * K + tx) * N + n) * C + c] = acc[tx] * (1.0f / 1024.0f);
+}
+
+// Data gradient, overlap-add: tile (ty, tx) of dy contributes a full 32x32 patch of dx at offset -pad.  The (at most two)
+// tile rows that reach an image row are summed in the frequency domain before the row transform; along x the patches of
+// even and odd tiles are written by two launches (parity): the first writer of a column stores (+ addsrc), the second adds.
+__global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __restrict__ S, float* __restrict__ dx, int lddx,
+                                                                const float* __restrict__ addsrc, int ld_add, FftGeom g,
+                                                                int parity) {
+    const int C = g.C, T = g.T;
+    const int ntx = (g.tiles_x + 1 - parity) / 2;         // tiles of this parity per row
+    const int64_t total = (int64_t)g.B * g.H * ntx * C;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int tx = (int)(r % ntx) * 2 + parity;
+        r /= ntx;
+        const int iy = (int)(r % g.H), b = (int)(r / g.H);
+        const int q = iy + g.pad;
+        const int ty_a = q / T, j_a = q - ty_a * T;
+        float re[32], im[32];
+#pragma unroll
+        for (int kx = 0; kx < FFT_NK; ++kx) { re[kx] = 0.f; im[kx] = 0.f; }
+        if (ty_a < g.tiles_y) {
+            const int t = (b * g.tiles_y + ty_a) * g.tiles_x + tx;
+            const float2* src = S + (((size_t)t * FFT_N + j_a) * FFT_NK) * C + c;
+#pragma unroll
+            for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = src[(size_t)kx * C]; re[kx] = v.x; im[kx] = v.y; }
+        }
+        if (ty_a >= 1 && j_a + T < FFT_N) {
+            const int t = (b * g.tiles_y + ty_a - 1) * g.tiles_x + tx;
+            const float2* src = S + (((size_t)t * FFT_N + j_a + T) * FFT_NK) * C + c;
+#pragma unroll
+            for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = src[(size_t)kx * C]; re[kx] += v.x; im[kx] += v.y; }
+        }
+#pragma unroll
+        for (int kx = FFT_NK; kx < 32; ++kx) { re[kx] = re[32 - kx]; im[kx] = -im[32 - kx]; }
+        fft32<1>(re, im);
+        float* dst = dx + ((size_t)(b * g.H + iy) * g.W) * lddx + c;
+        const float* ad = addsrc ? addsrc + ((size_t)(b * g.H + iy) * g.W) * ld_add + c : nullptr;
+        const bool has_next = tx + 1 < g.tiles_x;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int ix = tx * T - g.pad + j;
+            if (ix < 0 || ix >= g.W) continue;
+            const float val = re[j] * (1.0f / 1024.0f);
+            // odd tiles: columns shared with the even neighbours were stored by the first launch
+            const bool second = parity == 1 && (j < g.k - 1 || (j >= T && has_next));
+            if (second) dst[(size_t)ix * lddx] += val;
+            else dst[(size_t)ix * lddx] = ad ? val + ad[(size_t)ix * ld_add] : val;
+        }
+    }
+}
+
+bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
+    if (!g || g->transposed || g->stride != 1 || g->pad_mode != 0 || g->k < 3 || g->k > 15 || (g->k & 1) == 0) return false;
+    if (g->pad != g->k / 2) return false;
+    if ((g->Cin % 64) || (g->Cout % 64) || g->Cin > 256 || g->Cout > 256) return false;
+    f.B = g->B; f.H = g->H; f.W = g->W; f.C = g->Cin; f.N = g->Cout; f.k = g->k; f.pad = g->pad;
+    f.T = FFT_N - g->k + 1;
+    f.tiles_y = cdiv(g->H, f.T); f.tiles_x = cdiv(g->W, f.T);
+    f.M = g->B * f.tiles_y * f.tiles_x;
+    return true;
+}
+
+inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+// workspace: R/S intermediate (M*32*17*max(C,N) complex), Xf, Yf (M*544*C / N complex), Wf (544 * 2N * 2C floats)
+extern "C" size_t gdn_fftconv_fwd_workspace_bytes(const gdn_conv_geom* g) {
+    FftGeom f;
+    if (!fft_geom(g, f)) return 0;
+    const size_t cm = f.C > f.N ? f.C : f.N;
+    return al256((size_t)f.M * FFT_N * FFT_NK * cm * 8) + al256((size_t)f.M * FFT_BINS * f.C * 8) +
+           al256((size_t)f.M * FFT_BINS * f.N * 8) + al256((size_t)FFT_BINS * 4 * f.C * f.N * 4);
+}
+
+extern "C" int64_t gdn_fftconv_stats_slots(const gdn_conv_geom* g) {
+    FftGeom f;
+    if (!fft_geom(g, f)) return GDN_ERR_UNSUPPORTED;
+    return cdiv64((int64_t)f.M * f.T, 256 / f.N);
+}
+
+extern "C" size_t gdn_fftconv_spectrum_bytes(const gdn_conv_geom* g) {
+    FftGeom f;
+    if (!fft_geom(g, f)) return 0;
+    return al256((size_t)f.M * FFT_BINS * f.C * 8);
+}
+
+extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w, float* y, int32_t ldy,
+                               const float* addsrc, int32_t ld_add, float* stats, void* xf_out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    FftGeom f;
+    if (!fft_geom(g, f)) return GDN_ERR_UNSUPPORTED;
+    if (!x || !w || !y) return GDN_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gdn_fftconv_fwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t cm = f.C > f.N ? f.C : f.N;
+    char* p = (char*)workspace;
+    float2* R = (float2*)p; p += al256((size_t)f.M * FFT_N * FFT_NK * cm * 8);
+    float2* Xf = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.C * 8);
+    if (xf_out) Xf = (float2*)xf_out;
+    float2* Yf = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.N * 8);
+    float* Wf = (float*)p;
+    auto blocks = [](int64_t n) { const int64_t b = cdiv64(n, 256); return (unsigned)(b < 65536 * 8 ? b : 65536 * 8); };
+    hipLaunchKernelGGL(fft_rows_kernel, dim3(blocks((int64_t)f.M * FFT_N * f.C)), dim3(256), 0, st, x, ldx, R, f, 1);
+    hipLaunchKernelGGL(fft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.C)), dim3(256), 0, st, (const float2*)R, Xf, f.C, f.M);
+    hipLaunchKernelGGL(fft_weights_kernel, dim3(cdiv(f.N * f.C, 256), FFT_BINS), dim3(256), 0, st, w, Wf, f.N, f.C, f.k, 0);
+    hipLaunchKernelGGL(gemm_bins_kernel, dim3(cdiv(f.M, 64), cdiv(2 * f.N, 64), FFT_BINS), dim3(256), 0, st,
+                       (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, 2 * f.N, 2 * f.C);
+    hipLaunchKernelGGL(ifft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.N)), dim3(256), 0, st, (const float2*)Yf, R, f.N, f.M, f.T);
+    FftGeom fo = f;
+    hipLaunchKernelGGL(ifft_rows_kernel, dim3((unsigned)cdiv64((int64_t)f.M * f.T, 256 / f.N)), dim3(256), 0, st,
+                       (const float2*)R, y, ldy, addsrc, ld_add, stats, fo);
+    return gdn_launch_status();
+}
+
+// workspace: R/S intermediate, Df (spectrum of dy), Ef (spectrum of the dx patches), Wf / P (544 * 2N * 2C floats)
+extern "C" size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
+    FftGeom f;
+    if (!fft_geom(g, f)) return 0;
+    const size_t cm = f.C > f.N ? f.C : f.N;
+    return al256((size_t)f.M * FFT_N * FFT_NK * cm * 8) + al256((size_t)f.M * FFT_BINS * f.N * 8) +
+           al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)FFT_BINS * 4 * f.C * f.N * 4);
+}
+
+extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w, const void* xf,
+                               float* dx, int32_t ldx, const float* addsrc, int32_t ld_add, float* dw, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    FftGeom f;
+    if (!fft_geom(g, f)) return GDN_ERR_UNSUPPORTED;
+    if (!dy || (!dx && !dw) || (dx && !w) || (dw && !xf)) return GDN_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gdn_fftconv_bwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t cm = f.C > f.N ? f.C : f.N;
+    char* p = (char*)workspace;
+    float2* R = (float2*)p; p += al256((size_t)f.M * FFT_N * FFT_NK * cm * 8);
+    float2* Df = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.N * 8);
+    float2* Ef = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.C * 8);
+    float* Wf = (float*)p;
+    auto blocks = [](int64_t n) { const int64_t b = cdiv64(n, 256); return (unsigned)(b < 65536 * 8 ? b : 65536 * 8); };
+    // spectrum of the dy tiles (no halo: rows / columns >= T are the zero padding of the linear convolution)
+    FftGeom fd = f;
+    fd.C = f.N;
+    hipLaunchKernelGGL(fft_rows_kernel, dim3(blocks((int64_t)f.M * FFT_N * f.N)), dim3(256), 0, st, dy, ldy, R, fd, 0);
+    hipLaunchKernelGGL(fft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.N)), dim3(256), 0, st, (const float2*)R, Df, f.N, f.M);
+    if (dw) {
+        float* P = Wf;
+        hipLaunchKernelGGL(gemm_tn_bins_kernel, dim3(2 * f.N / 64, 2 * f.C / 64, FFT_BINS), dim3(256), 0, st,
+                           (const float*)Df, (const float*)xf, P, f.M, 2 * f.N, 2 * f.C);
+        const dim3 gr(cdiv(f.N * f.C, 256), f.k);
+#define GDN_TAPS(KK) case KK: hipLaunchKernelGGL(fft_wgrad_taps_kernel<KK>, gr, dim3(256), 0, st, (const float*)P, dw, f.N, f.C); break;
+        switch (f.k) {
+            GDN_TAPS(3) GDN_TAPS(5) GDN_TAPS(7) GDN_TAPS(9) GDN_TAPS(11) GDN_TAPS(13) GDN_TAPS(15)
+        }
+#undef GDN_TAPS
+    }
+    if (dx) {
+        hipLaunchKernelGGL(fft_weights_kernel, dim3(cdiv(f.N * f.C, 256), FFT_BINS), dim3(256), 0, st, w, Wf, f.N, f.C, f.k, 1);
+        hipLaunchKernelGGL(gemm_bins_kernel, dim3(cdiv(f.M, 64), cdiv(2 * f.C, 64), FFT_BINS), dim3(256), 0, st,
+                           (const float*)Df, (const float*)Wf, (float*)Ef, f.M, 2 * f.C, 2 * f.N);
+        hipLaunchKernelGGL(ifft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.C)), dim3(256), 0, st, (const float2*)Ef, R, f.C, f.M, FFT_N);
+        for (int parity = 0; parity < 2; ++parity) {
+            const int ntx = (f.tiles_x + 1 - parity) / 2;
+            if (ntx == 0) continue;
+            hipLaunchKernelGGL(ifft_rows_overlap_kernel, dim3(blocks((int64_t)f.B * f.H * ntx * f.C)), dim3(256), 0, st,
+                               (const float2*)R, dx, ldx, addsrc, ld_add, f, parity);
+        }
+    }
+    return gdn_launch_status();
+}

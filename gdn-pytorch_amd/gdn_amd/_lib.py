@@ -42,6 +42,12 @@ _SIGS = {
     "gdn_conv_wgrad": (c_int32, [_PG, _P, _i32, _i32, _P, _i32, _P, _i32, _i32, _P, _sz, _i32, _P]),
     "gdn_conv_wgrad_bf16_workspace_bytes": (_sz, [_PG, _i32, _i32]),
     "gdn_conv_wgrad_bf16": (c_int32, [_PG, _P, _i32, _i32, _P, _i32, _P, _i32, _i32, _P, _sz, _i32, _P]),
+    "gdn_fftconv_fwd_workspace_bytes": (_sz, [_PG]),
+    "gdn_fftconv_spectrum_bytes": (_sz, [_PG]),
+    "gdn_fftconv_stats_slots": (_i64, [_PG]),
+    "gdn_fftconv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _sz, _P]),
+    "gdn_fftconv_bwd_workspace_bytes": (_sz, [_PG]),
+    "gdn_fftconv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _P, _i32, _P, _i32, _P, _P, _sz, _P]),
     "gdn_transpose_taps": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P]),
     "gdn_cast": (c_int32, [_P, _P, _i64, _i32, _P]),
     "gdn_weight_to_tapmajor": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P]),

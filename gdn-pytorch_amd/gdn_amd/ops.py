@@ -165,6 +165,56 @@ class Conv:
                            0 if addsrc is None else _ld(addsrc), _p(ws), nb, tile_cfg, stream())
         return dx
 
+    # ---- FFT-domain path (csrc/conv_fft.hip): stride-1 zero-padded fp32 layers with 64..256 channels ----
+    def fft_ok(self, B, H, W):
+        """True when gdn_fftconv_* supports this layer at this input size."""
+        _, ref, _, _ = self.geom(B, H, W)
+        return int(lib.gdn_fftconv_spectrum_bytes(ref)) > 0
+
+    def fft_stats_slots(self, B, H, W):
+        _, ref, _, _ = self.geom(B, H, W)
+        return int(lib.gdn_fftconv_stats_slots(ref))
+
+    def fft_fwd(self, x, w_tap, stats=False, addsrc=None, spectrum=False, out=None, stats_out=None):
+        """y = conv(x) (+ addsrc) through the frequency domain; returns y, then the BatchNorm partials when `stats`,
+        then the input spectrum (opaque uint8 buffer for fft_bwd) when `spectrum`."""
+        _chk(x, "x"); _chk(w_tap, "w")
+        B, H, W, C1 = x.shape
+        _, ref, Ho, Wo = self.geom(B, H, W)
+        nb = int(lib.gdn_fftconv_fwd_workspace_bytes(ref))
+        if nb == 0 or C1 != self.cin:
+            raise GdnError("fftconv: unsupported layer k=%d stride=%d Cin=%d Cout=%d" % (self.k, self.stride, C1, self.cout))
+        y = out if out is not None else torch.empty((B, Ho, Wo, self.cout), dtype=torch.float32, device=x.device)
+        st = None
+        if stats:
+            st = stats_out if stats_out is not None else torch.empty(
+                (int(lib.gdn_fftconv_stats_slots(ref)), 2, self.cout), dtype=torch.float32, device=x.device)
+        xf = torch.empty(int(lib.gdn_fftconv_spectrum_bytes(ref)), dtype=torch.uint8, device=x.device) if spectrum else None
+        ws = workspace(nb, x.device, "fft")
+        lib.gdn_fftconv_fwd(ref, _p(x), _ld(x), _p(w_tap), _p(y), _ld(y), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
+                            _p(st), _p(xf), _p(ws), nb, stream())
+        res = (y,) + ((st,) if stats else ()) + ((xf,) if spectrum else ())
+        return res if len(res) > 1 else y
+
+    def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None):
+        """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's spectrum xf)
+        from one transform of dy.  w_tap is the FORWARD tap-major weight [k*k, Cout, Cin]."""
+        _chk(dy, "dy")
+        B = dy.shape[0]
+        H, W = in_hw
+        _, ref, Ho, Wo = self.geom(B, H, W)
+        nb = int(lib.gdn_fftconv_bwd_workspace_bytes(ref))
+        if nb == 0:
+            raise GdnError("fftconv: unsupported layer k=%d stride=%d" % (self.k, self.stride))
+        if tuple(dy.shape[1:]) != (Ho, Wo, self.cout):
+            raise GdnError("fft_bwd: dy shape %s does not match layer output" % (tuple(dy.shape),))
+        dx = torch.empty((B, H, W, self.cin), dtype=torch.float32, device=dy.device) if need_dx else None
+        ws = workspace(nb, dy.device, "fft")
+        lib.gdn_fftconv_bwd(ref, _p(dy), _ld(dy), _p(w_tap), _p(xf) if dw_tap is not None else None, _p(dx),
+                            0 if dx is None else _ld(dx), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
+                            _p(dw_tap), _p(ws), nb, stream())
+        return dx
+
     def wgrad(self, x, dy, dw_tap, ci_off=0, cfg=0):
         """dw_tap[tap][co][ci_off + ci] = wgrad over the channel slice x (Cx = x.shape[3]).
         bf16 x/dy take the bf16 MFMA kernel; dw_tap is fp32 either way."""

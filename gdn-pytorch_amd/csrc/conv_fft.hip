@@ -236,7 +236,8 @@ __global__ __launch_bounds__(256) void ifft_cols_kernel(const float2* __restrict
 // host passes rows_per_wg = 256 / C.
 __global__ __launch_bounds__(256) void ifft_rows_kernel(const float2* __restrict__ S, float* __restrict__ y, int ldy,
                                                         const float* __restrict__ addsrc, int ld_add,
-                                                        float* __restrict__ stats, FftGeom g) {
+                                                        float* __restrict__ stats, const float* __restrict__ ep_scale,
+                                                        const float* __restrict__ ep_shift, int act, FftGeom g) {
     __shared__ float red[256 * 2];
     const int C = g.N, T = g.T;
     const int rows_per_wg = 256 / C;
@@ -257,13 +258,18 @@ __global__ __launch_bounds__(256) void ifft_rows_kernel(const float2* __restrict
             fft32<1>(re, im);
             float* dst = y + ((size_t)(b * g.H + oy) * g.W) * ldy + c;
             const float* ad = addsrc ? addsrc + ((size_t)(b * g.H + oy) * g.W) * ld_add + c : nullptr;
+            const float es = ep_scale ? ep_scale[c] : 1.f, et = ep_shift ? ep_shift[c] : 0.f;
 #pragma unroll
             for (int v = 0; v < 32; ++v) {
                 const int ox = tx * T + v;
                 if (v < T && ox < g.W) {
-                    const float val = re[v] * (1.0f / 1024.0f);
+                    float val = re[v] * (1.0f / 1024.0f);
                     s1 += val; s2 += val * val;
-                    dst[(size_t)ox * ldy] = ad ? val + ad[(size_t)ox * ld_add] : val;
+                    if (ep_scale) val = val * es + et;
+                    if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
+                    if (ad) val += ad[(size_t)ox * ld_add];
+                    if (act & GDN_ACT_TANH) val = tanhf(val);
+                    dst[(size_t)ox * ldy] = val;
                 }
             }
         }
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __
 }
 
 bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
-    if (!g || g->transposed || g->stride != 1 || g->pad_mode != 0 || g->k < 3 || g->k > 15 || (g->k & 1) == 0) return false;
+    if (!g || g->transposed || g->stride != 1 || g->pad_mode != 0 || g->k < 3 || g->k > 9 || (g->k & 1) == 0) return false;
     if (g->pad != g->k / 2) return false;
     if ((g->Cin % 64) || (g->Cout % 64) || g->Cin > 256 || g->Cout > 256) return false;
     f.B = g->B; f.H = g->H; f.W = g->W; f.C = g->Cin; f.N = g->Cout; f.k = g->k; f.pad = g->pad;
@@ -454,12 +460,13 @@ extern "C" size_t gdn_fftconv_spectrum_bytes(const gdn_conv_geom* g) {
 }
 
 extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w, float* y, int32_t ldy,
-                               const float* addsrc, int32_t ld_add, float* stats, void* xf_out, void* workspace,
+                               const float* addsrc, int32_t ld_add, float* stats, const float* ep_scale,
+                               const float* ep_shift, int32_t act, void* xf_out, void* workspace,
                                size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     FftGeom f;
     if (!fft_geom(g, f)) return GDN_ERR_UNSUPPORTED;
-    if (!x || !w || !y) return GDN_ERR_BAD_ARG;
+    if (!x || !w || !y || (!ep_scale) != (!ep_shift)) return GDN_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gdn_fftconv_fwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const size_t cm = f.C > f.N ? f.C : f.N;
@@ -478,7 +485,7 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
     hipLaunchKernelGGL(ifft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.N)), dim3(256), 0, st, (const float2*)Yf, R, f.N, f.M, f.T);
     FftGeom fo = f;
     hipLaunchKernelGGL(ifft_rows_kernel, dim3((unsigned)cdiv64((int64_t)f.M * f.T, 256 / f.N)), dim3(256), 0, st,
-                       (const float2*)R, y, ldy, addsrc, ld_add, stats, fo);
+                       (const float2*)R, y, ldy, addsrc, ld_add, stats, ep_scale, ep_shift, act, fo);
     return gdn_launch_status();
 }
 
@@ -519,7 +526,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         const dim3 gr(cdiv(f.N * f.C, 256), f.k);
 #define GDN_TAPS(KK) case KK: hipLaunchKernelGGL(fft_wgrad_taps_kernel<KK>, gr, dim3(256), 0, st, (const float*)P, dw, f.N, f.C); break;
         switch (f.k) {
-            GDN_TAPS(3) GDN_TAPS(5) GDN_TAPS(7) GDN_TAPS(9) GDN_TAPS(11) GDN_TAPS(13) GDN_TAPS(15)
+            GDN_TAPS(3) GDN_TAPS(5) GDN_TAPS(7) GDN_TAPS(9)
         }
 #undef GDN_TAPS
     }

@@ -45,7 +45,7 @@ _SIGS = {
     "gdn_fftconv_fwd_workspace_bytes": (_sz, [_PG]),
     "gdn_fftconv_spectrum_bytes": (_sz, [_PG]),
     "gdn_fftconv_stats_slots": (_i64, [_PG]),
-    "gdn_fftconv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _sz, _P]),
+    "gdn_fftconv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _P, _P, _sz, _P]),
     "gdn_fftconv_bwd_workspace_bytes": (_sz, [_PG]),
     "gdn_fftconv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _P, _i32, _P, _i32, _P, _P, _sz, _P]),
     "gdn_transpose_taps": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P]),

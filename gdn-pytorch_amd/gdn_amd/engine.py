@@ -15,6 +15,9 @@ from ._lib import GdnError
 
 _ALIGN = 64  # floats
 _FUSE_EVAL_BN = os.environ.get("GDN_FUSE_EVAL_BN", "1") != "0"     # A/B switch for measurements
+# fp32 stride-1 zero-padded layers with a window of at least this size run in the frequency domain
+# (csrc/conv_fft.hip); 0 disables.  5x5 on 256 channels is the break-even neighbourhood.
+_FFT_MIN_K = int(os.environ.get("GDN_FFT_MIN_K", "5"))
 _GRAPH_EPOCH = 0
 
 
@@ -269,8 +272,17 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     if bn.training and isinstance(bn, torch.nn.InstanceNorm2d):
         raise NotImplementedError("train-mode InstanceNorm (per-instance statistics) is not implemented on the HIP path; "
                                   "model.eval() normalises with the tracked running statistics like the reference does")
+    use_fft = (_FFT_MIN_K > 0 and ldt == torch.float32 and x2 is None and not reflect and conv.kernel_size[0] >= _FFT_MIN_K
+               and conv.stride[0] == 1 and op.fft_ok(x.shape[0], x.shape[1], x.shape[2]))
+    xf = None
+    keep_xf = use_fft and ctx.record and conv.weight.requires_grad
     if bn.training:
-        y, st = op.fwd(x, w, x2=x2, stats=True)
+        if use_fft:
+            r = op.fft_fwd(x, w, stats=True, spectrum=keep_xf)
+            y, st = r[0], r[1]
+            xf = r[2] if keep_xf else None
+        else:
+            y, st = op.fwd(x, w, x2=x2, stats=True)
         count = y.shape[0] * y.shape[1] * y.shape[2]
         mom = 0.1 if bn.momentum is None else bn.momentum
         co = ops.bn_finalize_train(st, count, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, mom, bn.eps)
@@ -283,10 +295,13 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
              and (residual is None or residual.dtype == ldt) and conv.out_channels > 1)
     if fused:
         # eval-mode BN folded into the conv epilogue: conv + scale/shift + ReLU (+ residual) in one pass
-        y = a = op.fwd(x, w, x2=x2, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
+        if use_fft:
+            y = a = op.fft_fwd(x, w, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
+        else:
+            y = a = op.fwd(x, w, x2=x2, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
     else:
         if not bn.training:
-            y = op.fwd(x, w, x2=x2)
+            y = op.fft_fwd(x, w) if use_fft else op.fwd(x, w, x2=x2)
         a = ops.bn_apply(y, co[0], co[1], relu, residual, out_dtype=ctx.dtype)
     if ctx.record:
         in_hw = (x.shape[1], x.shape[2])
@@ -307,10 +322,26 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                                 bn.bias.grad if not frozen else None, out_dtype=ldt)
             else:
                 dy = ops.bn_eval_bwd(da, y, co, (2 if fused else 1) if relu else 0, out_dtype=ldt)
+            want_dx = need_dx and ctx.wants_dx(x)
+            if use_fft:
+                # one transform of dy feeds both gradients; the forward's input spectrum is reused for dw
+                gv = None
+                if not frozen:
+                    gv = tap_view(conv.weight.grad, False)
+                    if gv is None:
+                        raise GdnError("weight.grad is not tap-major")
+                if gv is not None or want_dx:
+                    dx = op.fft_bwd(dy, w, in_hw, xf=xf, dw_tap=gv, need_dx=want_dx,
+                                    addsrc=ctx.pop_grad_as(x, ldt) if want_dx else None)
+                    if want_dx:
+                        ctx.grads[id(x)] = (x, dx)
+                if not frozen:
+                    ctx.grads_done(bn.weight, bn.bias, conv.weight)
+                return
             if not frozen:
                 _wgrad_into(ctx, conv, x, dy, x2)
                 ctx.grads_done(bn.weight, bn.bias, conv.weight)
-            if need_dx and ctx.wants_dx(x):
+            if want_dx:
                 wt = ops.transpose_taps(_w_tap(conv)[0], dtype=ldt)
                 if x2 is None:
                     dx = op.dgrad(dy, wt, in_hw, addsrc=ctx.pop_grad_as(x, ldt))

@@ -175,7 +175,8 @@ class Conv:
         _, ref, _, _ = self.geom(B, H, W)
         return int(lib.gdn_fftconv_stats_slots(ref))
 
-    def fft_fwd(self, x, w_tap, stats=False, addsrc=None, spectrum=False, out=None, stats_out=None):
+    def fft_fwd(self, x, w_tap, stats=False, addsrc=None, spectrum=False, out=None, stats_out=None, affine=None,
+                act=ACT_NONE):
         """y = conv(x) (+ addsrc) through the frequency domain; returns y, then the BatchNorm partials when `stats`,
         then the input spectrum (opaque uint8 buffer for fft_bwd) when `spectrum`."""
         _chk(x, "x"); _chk(w_tap, "w")
@@ -192,7 +193,8 @@ class Conv:
         xf = torch.empty(int(lib.gdn_fftconv_spectrum_bytes(ref)), dtype=torch.uint8, device=x.device) if spectrum else None
         ws = workspace(nb, x.device, "fft")
         lib.gdn_fftconv_fwd(ref, _p(x), _ld(x), _p(w_tap), _p(y), _ld(y), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
-                            _p(st), _p(xf), _p(ws), nb, stream())
+                            _p(st), _p(affine[0]) if affine else None, _p(affine[1]) if affine else None, int(act),
+                            _p(xf), _p(ws), nb, stream())
         res = (y,) + ((st,) if stats else ()) + ((xf,) if spectrum else ())
         return res if len(res) > 1 else y
 

@@ -130,10 +130,11 @@ int gdn_conv_wgrad(const gdn_conv_geom* g, const void* x, int32_t ldx, int32_t C
                    void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream);
 
 /* FFT-domain convolution for the large-window residual layers (AE_model_unet.py ResidualBlock:
- * 9x9 on 64 channels, 7x7 on 128): stride 1, zero padding k/2, odd k in 3..15, Cin and Cout
+ * 9x9 on 64 channels, 7x7 on 128): stride 1, zero padding k/2, odd k in 3..9, Cin and Cout
  * multiples of 64 up to 256, fp32.  Overlap-save on 32x32 tiles: real FFT of the input patches,
  * one complex (real-embedded, MFMA) GEMM per frequency bin, inverse FFT of the valid outputs.
- * Same contract as gdn_conv_fwd for y / addsrc / stats (slots: gdn_fftconv_stats_slots).
+ * Same contract as gdn_conv_fwd for y / addsrc / stats / ep_scale / ep_shift / act (slots:
+ * gdn_fftconv_stats_slots).
  * xf_out (nullable, gdn_fftconv_spectrum_bytes) receives the input spectrum, which
  * gdn_fftconv_bwd reuses for the weight gradient.  GDN_ERR_UNSUPPORTED for other geometries. */
 size_t gdn_fftconv_fwd_workspace_bytes(const gdn_conv_geom* g);
@@ -141,6 +142,7 @@ size_t gdn_fftconv_spectrum_bytes(const gdn_conv_geom* g);
 int64_t gdn_fftconv_stats_slots(const gdn_conv_geom* g);
 int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w,
                     float* y, int32_t ldy, const float* addsrc, int32_t ld_add, float* stats,
+                    const float* ep_scale, const float* ep_shift, int32_t act,
                     void* xf_out, void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the same layer from one transform of dy: dx = dgrad (+ addsrc) when dx != NULL,
  * dw[tap][Cout][Cin] = wgrad when dw != NULL (needs xf, the spectrum saved by the forward). */

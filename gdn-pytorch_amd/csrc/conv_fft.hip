@@ -125,40 +125,59 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(const float2* __restrict_
     }
 }
 
-// weights: direct DFT of the k*k taps at every kept bin, written as the real embedding of the complex matrix.
-//   mode 0 (forward, correlation): Wc = conj(DFT(w[n][c]))       -> Bm[bin][2n+p][2c+q]
-//   mode 1 (data gradient, convolution with roles swapped): Wc = DFT(w[n][c]), output index c, reduction index n
-// Bm rows are output reals, columns reduction reals: out_re = sum in_re*Wr - in_im*Wi, out_im = sum in_re*Wi + in_im*Wr.
-__global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restrict__ w /* [k*k][N][C] */, float* __restrict__ Bm,
-                                                          int N, int C, int k, int mode) {
-    const int bin = blockIdx.y, ky = bin / FFT_NK, kx = bin % FFT_NK;
-    const int OUT = mode == 0 ? N : C, RED = mode == 0 ? C : N;
-    float* dst = Bm + (size_t)bin * (2 * OUT) * (2 * RED);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < N * C; i += gridDim.x * 256) {
-        const int c = i % C, n = i / C;
+// weights: DFT of the k*k taps at every kept bin, written as the real embedding of conj(DFT(w[n][c])) (correlation):
+//   Wf[bin][2n+p][2c+q]:  row 2n = [wr, wi], row 2n+1 = [-wi, wr]   (out_re = sum x_re*wr + x_im*wi, ...)
+// The forward GEMM reads it as B[n][k] (k contiguous); the data-gradient GEMM reads the SAME buffer as B[k][n] -- the
+// transpose of this embedding is exactly the embedding of the un-conjugated, role-swapped matrix the convolution needs.
+// thread = (n, c) with its K*K taps in registers; block = one ky; column transform first, then the 17 kx bins.
+template <int K>
+__global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restrict__ w /* [k*k][N][C] */, float* __restrict__ Wf,
+                                                          int N, int C) {
+    const int ky = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int c = i % C, n = i / C;
+    float ur[K], ui[K];
+#pragma unroll
+    for (int tx = 0; tx < K; ++tx) { ur[tx] = 0.f; ui[tx] = 0.f; }
+#pragma unroll
+    for (int ty = 0; ty < K; ++ty) {
+        const int ph = (ky * ty) & 31;
+        const float cs = kCos32[ph], sn = kSin32[ph];
+#pragma unroll
+        for (int tx = 0; tx < K; ++tx) {
+            const float v = w[((size_t)(ty * K + tx) * N + n) * C + c];
+            ur[tx] += v * cs;
+            ui[tx] -= v * sn;              // e^{-i phi}
+        }
+    }
+    const size_t rs = (size_t)2 * C;
+#pragma unroll
+    for (int kx = 0; kx < FFT_NK; ++kx) {
         float wr = 0.f, wi = 0.f;
-        for (int ty = 0; ty < k; ++ty)
-            for (int tx = 0; tx < k; ++tx) {
-                const int ph = (ky * ty + kx * tx) & 31;
-                const float v = w[((size_t)(ty * k + tx) * N + n) * C + c];
-                wr += v * kCos32[ph];
-                wi -= v * kSin32[ph];          // e^{-i phi}
-            }
-        if (mode == 0) wi = -wi;              // conjugate: correlation
-        const int o = mode == 0 ? n : c, r = mode == 0 ? c : n;
-        float* row_re = dst + (size_t)(2 * o) * (2 * RED) + 2 * r;
-        float* row_im = dst + (size_t)(2 * o + 1) * (2 * RED) + 2 * r;
-        row_re[0] = wr; row_re[1] = -wi;
-        row_im[0] = wi; row_im[1] = wr;
+#pragma unroll
+        for (int tx = 0; tx < K; ++tx) {
+            const int ph = (kx * tx) & 31;
+            const float cs = kCos32[ph], sn = kSin32[ph];
+            wr += ur[tx] * cs + ui[tx] * sn;       // (ur + i ui)(cs - i sn)
+            wi += ui[tx] * cs - ur[tx] * sn;
+        }
+        float* dst = Wf + (size_t)(ky * FFT_NK + kx) * (2 * N) * rs + (size_t)(2 * n) * rs + 2 * c;
+        *reinterpret_cast<float2*>(dst) = make_float2(wr, wi);            // conj: -(-wi)
+        *reinterpret_cast<float2*>(dst + rs) = make_float2(-wi, wr);
     }
 }
 
-// Per-bin real GEMM  Cm[bin][m][n] = sum_k A[bin][m][k] * Bm[bin][n][k]   (M x K times N x K, both K-contiguous).
-// 64x64 tile, 4 waves of one 32x32 MFMA tile, 32-wide k-steps, the LDS image / fragment scheme of conv_igemm_f32.
+// Per-bin real GEMM  Cm[bin][m][n] = sum_k A[bin][m][k] * B[bin](n, k).  A is M x K, K-contiguous.
+//   BKN = false: B stored [n][k] (k contiguous)  -- forward
+//   BKN = true : B stored [k][n] (n contiguous)  -- data gradient, reading the forward's weight spectrum transposed
+// 64x64 tile, 4 waves of one 32x32 MFMA tile, 32-wide k-steps; A (and the [n][k] B) use the pitch-36 LDS image and
+// b128 fragment reads of conv_igemm_f32 (lane half h owns k = 16h..16h+15 of the slab); the [k][n] B is read row-wise.
+template <bool BKN>
 __global__ __launch_bounds__(256) void gemm_bins_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                         float* __restrict__ Cm, int M, int N, int K) {
-    constexpr int LD = 36;
-    __shared__ __attribute__((aligned(16))) float As[64 * LD], Bs[64 * LD];
+    constexpr int LD = 36, LDB = BKN ? 64 : 36;
+    __shared__ __attribute__((aligned(16))) float As[64 * LD], Bs[BKN ? 32 * 64 : 64 * 36];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int bin = blockIdx.z, m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
     const float* Ab = A + (size_t)bin * M * K;
@@ -167,25 +186,32 @@ __global__ __launch_bounds__(256) void gemm_bins_kernel(const float* __restrict_
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int lr = tid >> 3, lc = (tid & 7) * 4;          // staging: 32 rows per pass, 8 lanes x 16 B per row
+    const int lr = tid >> 3, lc = (tid & 7) * 4;          // [row][k] staging: 32 rows per pass, 8 lanes x 16 B per row
+    const int kr = tid >> 4, kc = (tid & 15) * 4;         // [k][n] staging: 16 k-rows per pass, 16 lanes x 16 B per row
     f32x4 ra[2], rb[2];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-            const int m = m0 + ps * 32 + lr, n = n0 + ps * 32 + lr;
+            const int m = m0 + ps * 32 + lr;
             ra[ps] = m < M ? *reinterpret_cast<const f32x4*>(Ab + (size_t)m * K + k0 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rb[ps] = n < N ? *reinterpret_cast<const f32x4*>(Bb + (size_t)n * K + k0 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (BKN) {
+                rb[ps] = *reinterpret_cast<const f32x4*>(Bb + (size_t)(k0 + ps * 16 + kr) * N + n0 + kc);
+            } else {
+                const int n = n0 + ps * 32 + lr;
+                rb[ps] = n < N ? *reinterpret_cast<const f32x4*>(Bb + (size_t)n * K + k0 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
     auto lstore = [&]() {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
             *reinterpret_cast<f32x4*>(&As[(ps * 32 + lr) * LD + lc]) = ra[ps];
-            *reinterpret_cast<f32x4*>(&Bs[(ps * 32 + lr) * LD + lc]) = rb[ps];
+            if (BKN) *reinterpret_cast<f32x4*>(&Bs[(ps * 16 + kr) * LDB + kc]) = rb[ps];
+            else *reinterpret_cast<f32x4*>(&Bs[(ps * 32 + lr) * LDB + lc]) = rb[ps];
         }
     };
     const int a_off = (wm * 32 + (lane & 31)) * LD + (lane >> 5) * 16;
-    const int b_off = (wn * 32 + (lane & 31)) * LD + (lane >> 5) * 16;
+    const int b_off = BKN ? (lane >> 5) * 16 * LDB + wn * 32 + (lane & 31) : (wn * 32 + (lane & 31)) * LDB + (lane >> 5) * 16;
     gload(0);
     lstore();
     __syncthreads();
@@ -194,9 +220,15 @@ __global__ __launch_bounds__(256) void gemm_bins_kernel(const float* __restrict_
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(&As[a_off + g4 * 4]);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[b_off + g4 * 4]);
+            if (BKN) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+                for (int e = 0; e < 4; ++e)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], Bs[b_off + (g4 * 4 + e) * LDB], acc, 0, 0, 0);
+            } else {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[b_off + g4 * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+            }
         }
         __syncthreads();
         if (k0 + 32 < K) { lstore(); __syncthreads(); }
@@ -453,11 +485,24 @@ extern "C" int64_t gdn_fftconv_stats_slots(const gdn_conv_geom* g) {
     return cdiv64((int64_t)f.M * f.T, 256 / f.N);
 }
 
+// saved state of one forward for its backward: input spectrum Xf, then the weight spectrum Wf
 extern "C" size_t gdn_fftconv_spectrum_bytes(const gdn_conv_geom* g) {
     FftGeom f;
     if (!fft_geom(g, f)) return 0;
-    return al256((size_t)f.M * FFT_BINS * f.C * 8);
+    return al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)FFT_BINS * 4 * f.C * f.N * 4);
 }
+
+namespace {
+void launch_weights(const FftGeom& f, const float* w, float* Wf, hipStream_t st) {
+    const dim3 gr(cdiv(f.N * f.C, 256), FFT_N);
+    switch (f.k) {
+        case 3: hipLaunchKernelGGL(fft_weights_kernel<3>, gr, dim3(256), 0, st, w, Wf, f.N, f.C); break;
+        case 5: hipLaunchKernelGGL(fft_weights_kernel<5>, gr, dim3(256), 0, st, w, Wf, f.N, f.C); break;
+        case 7: hipLaunchKernelGGL(fft_weights_kernel<7>, gr, dim3(256), 0, st, w, Wf, f.N, f.C); break;
+        default: hipLaunchKernelGGL(fft_weights_kernel<9>, gr, dim3(256), 0, st, w, Wf, f.N, f.C); break;
+    }
+}
+}  // namespace
 
 extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w, float* y, int32_t ldy,
                                const float* addsrc, int32_t ld_add, float* stats, const float* ep_scale,
@@ -473,14 +518,17 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
     char* p = (char*)workspace;
     float2* R = (float2*)p; p += al256((size_t)f.M * FFT_N * FFT_NK * cm * 8);
     float2* Xf = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.C * 8);
-    if (xf_out) Xf = (float2*)xf_out;
     float2* Yf = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.N * 8);
     float* Wf = (float*)p;
+    if (xf_out) {
+        Xf = (float2*)xf_out;
+        Wf = (float*)((char*)xf_out + al256((size_t)f.M * FFT_BINS * f.C * 8));
+    }
     auto blocks = [](int64_t n) { const int64_t b = cdiv64(n, 256); return (unsigned)(b < 65536 * 8 ? b : 65536 * 8); };
     hipLaunchKernelGGL(fft_rows_kernel, dim3(blocks((int64_t)f.M * FFT_N * f.C)), dim3(256), 0, st, x, ldx, R, f, 1);
     hipLaunchKernelGGL(fft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.C)), dim3(256), 0, st, (const float2*)R, Xf, f.C, f.M);
-    hipLaunchKernelGGL(fft_weights_kernel, dim3(cdiv(f.N * f.C, 256), FFT_BINS), dim3(256), 0, st, w, Wf, f.N, f.C, f.k, 0);
-    hipLaunchKernelGGL(gemm_bins_kernel, dim3(cdiv(f.M, 64), cdiv(2 * f.N, 64), FFT_BINS), dim3(256), 0, st,
+    launch_weights(f, w, Wf, st);
+    hipLaunchKernelGGL(gemm_bins_kernel<false>, dim3(cdiv(f.M, 64), cdiv(2 * f.N, 64), FFT_BINS), dim3(256), 0, st,
                        (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, 2 * f.N, 2 * f.C);
     hipLaunchKernelGGL(ifft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.N)), dim3(256), 0, st, (const float2*)Yf, R, f.N, f.M, f.T);
     FftGeom fo = f;
@@ -504,7 +552,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     (void)hipGetLastError();
     FftGeom f;
     if (!fft_geom(g, f)) return GDN_ERR_UNSUPPORTED;
-    if (!dy || (!dx && !dw) || (dx && !w) || (dw && !xf)) return GDN_ERR_BAD_ARG;
+    if (!dy || (!dx && !dw) || (dx && !w && !xf) || (dw && !xf)) return GDN_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gdn_fftconv_bwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const size_t cm = f.C > f.N ? f.C : f.N;
@@ -512,7 +560,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     float2* R = (float2*)p; p += al256((size_t)f.M * FFT_N * FFT_NK * cm * 8);
     float2* Df = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.N * 8);
     float2* Ef = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.C * 8);
-    float* Wf = (float*)p;
+    float* Wf = (float*)p;           // weight-gradient products P, or the weight spectrum when the forward saved none
     auto blocks = [](int64_t n) { const int64_t b = cdiv64(n, 256); return (unsigned)(b < 65536 * 8 ? b : 65536 * 8); };
     // spectrum of the dy tiles (no halo: rows / columns >= T are the zero padding of the linear convolution)
     FftGeom fd = f;
@@ -531,9 +579,10 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
 #undef GDN_TAPS
     }
     if (dx) {
-        hipLaunchKernelGGL(fft_weights_kernel, dim3(cdiv(f.N * f.C, 256), FFT_BINS), dim3(256), 0, st, w, Wf, f.N, f.C, f.k, 1);
-        hipLaunchKernelGGL(gemm_bins_kernel, dim3(cdiv(f.M, 64), cdiv(2 * f.C, 64), FFT_BINS), dim3(256), 0, st,
-                           (const float*)Df, (const float*)Wf, (float*)Ef, f.M, 2 * f.C, 2 * f.N);
+        const float* Wsaved = xf ? (const float*)((const char*)xf + al256((size_t)f.M * FFT_BINS * f.C * 8)) : nullptr;
+        if (!Wsaved) launch_weights(f, w, Wf, st);
+        hipLaunchKernelGGL(gemm_bins_kernel<true>, dim3(cdiv(f.M, 64), cdiv(2 * f.C, 64), FFT_BINS), dim3(256), 0, st,
+                           (const float*)Df, Wsaved ? Wsaved : (const float*)Wf, (float*)Ef, f.M, 2 * f.C, 2 * f.N);
         hipLaunchKernelGGL(ifft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.C)), dim3(256), 0, st, (const float2*)Ef, R, f.C, f.M, FFT_N);
         for (int parity = 0; parity < 2; ++parity) {
             const int ntx = (f.tiles_x + 1 - parity) / 2;

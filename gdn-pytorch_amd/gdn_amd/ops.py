@@ -199,8 +199,9 @@ class Conv:
         return res if len(res) > 1 else y
 
     def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None):
-        """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's spectrum xf)
-        from one transform of dy.  w_tap is the FORWARD tap-major weight [k*k, Cout, Cin]."""
+        """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's saved state xf:
+        input + weight spectra) from one transform of dy.  w_tap is the FORWARD tap-major weight [k*k, Cout, Cin]; it is
+        only read when xf is None."""
         _chk(dy, "dy")
         B = dy.shape[0]
         H, W = in_hw
@@ -212,7 +213,7 @@ class Conv:
             raise GdnError("fft_bwd: dy shape %s does not match layer output" % (tuple(dy.shape),))
         dx = torch.empty((B, H, W, self.cin), dtype=torch.float32, device=dy.device) if need_dx else None
         ws = workspace(nb, dy.device, "fft")
-        lib.gdn_fftconv_bwd(ref, _p(dy), _ld(dy), _p(w_tap), _p(xf) if dw_tap is not None else None, _p(dx),
+        lib.gdn_fftconv_bwd(ref, _p(dy), _ld(dy), _p(w_tap), _p(xf), _p(dx),
                             0 if dx is None else _ld(dx), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
                             _p(dw_tap), _p(ws), nb, stream())
         return dx

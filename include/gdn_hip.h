@@ -135,8 +135,8 @@ int gdn_conv_wgrad(const gdn_conv_geom* g, const void* x, int32_t ldx, int32_t C
  * one complex (real-embedded, MFMA) GEMM per frequency bin, inverse FFT of the valid outputs.
  * Same contract as gdn_conv_fwd for y / addsrc / stats / ep_scale / ep_shift / act (slots:
  * gdn_fftconv_stats_slots).
- * xf_out (nullable, gdn_fftconv_spectrum_bytes) receives the input spectrum, which
- * gdn_fftconv_bwd reuses for the weight gradient.  GDN_ERR_UNSUPPORTED for other geometries. */
+ * xf_out (nullable, gdn_fftconv_spectrum_bytes) receives the input and weight spectra, which
+ * gdn_fftconv_bwd reuses (weight gradient; data gradient without a second weight transform).  GDN_ERR_UNSUPPORTED for other geometries. */
 size_t gdn_fftconv_fwd_workspace_bytes(const gdn_conv_geom* g);
 size_t gdn_fftconv_spectrum_bytes(const gdn_conv_geom* g);
 int64_t gdn_fftconv_stats_slots(const gdn_conv_geom* g);
@@ -145,7 +145,8 @@ int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const f
                     const float* ep_scale, const float* ep_shift, int32_t act,
                     void* xf_out, void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the same layer from one transform of dy: dx = dgrad (+ addsrc) when dx != NULL,
- * dw[tap][Cout][Cin] = wgrad when dw != NULL (needs xf, the spectrum saved by the forward). */
+ * dw[tap][Cout][Cin] = wgrad when dw != NULL (needs xf, the state saved by the forward; with
+ * xf == NULL the data gradient transforms w itself). */
 size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g);
 int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w,
                     const void* xf, float* dx, int32_t ldx, const float* addsrc, int32_t ld_add,

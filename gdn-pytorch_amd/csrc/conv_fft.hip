@@ -8,15 +8,19 @@
 // sums 64-128 products per bin instead of 5184-6272, and measured against an fp64 convolution the tiled fp32 FFT result is
 // closer than the direct fp32 sum (oracle experiment in DESIGN.md).
 //
-// Pipeline (all tensors NHWC, channels contiguous, so every global access is a full 256/512-byte line):
-//   rows   x  -> R   [tile][32 rows][17 kx][C] complex     real FFT32 along x of each patch row (zero padding = halo)
-//   cols   R  -> Xf  [bin = ky*17+kx][tile][C] complex      FFT32 along y
-//   wdft   w  -> Wf  [bin][2*Cout][2*Cin] real              direct DFT of the k*k taps, laid out as the REAL embedding of
-//                                                           the complex product (conjugated: correlation)
-//   gemm   Yf[bin] = Xf[bin] * Wf[bin]^T                    one real GEMM per bin, M = tiles, K = 2*Cin, N = 2*Cout (MFMA)
-//   icols  Yf -> S   [tile][T rows][17 kx][Cout] complex    inverse FFT32 along ky
-//   irows  S  -> y                                          Hermitian inverse FFT32 along kx, valid T x T outputs,
-//                                                           1/1024 scale, + residual, BatchNorm sum / sum-of-squares partials
+// Pipeline (all tensors NHWC, channels contiguous; spectra are [bin = ky*17+kx][tile][channel] complex):
+//   fft2d_fwd    x  -> Xf     real FFT32 along x then FFT32 along y of each 32x32 patch (zero padding = halo); one
+//                             workgroup = one tile x 16 channels, the two passes meet in LDS
+//   weights      w  -> Wf     [bin][2*Cout][2*Cin] real: DFT of the k*k taps laid out as the REAL embedding of the complex
+//                             product (conjugated: correlation)
+//   gemm_bins    Yf[bin] = Xf[bin] * Wf[bin]^T      one real GEMM per bin, M = tiles, K = 2*Cin, N = 2*Cout (MFMA)
+//   ifft2d_valid Yf -> y      inverse FFT32 along ky, Hermitian inverse along kx, valid T x T outputs, 1/1024 scale,
+//                             affine / ReLU / residual epilogue, BatchNorm sum / sum-of-squares partials (slot = tile)
+// Backward from ONE transform of dy (tile without halo, zero padded = the linear convolution fits the 32-point circle):
+//   data gradient    Ef[bin] = Df[bin] * Wf[bin] (the saved Wf read transposed), inverse along ky, then overlap-add of the
+//                    32x32 patches at offset -pad: vertical overlaps summed in the frequency domain, horizontal ones by two
+//                    ordered launches (even tiles store, odd tiles add) -- deterministic, no atomics
+//   weight gradient  P[bin] = Df[bin]^T * Xf[bin] (reduction over tiles, MFMA), inverse DFT at the k*k taps only
 #include "common.h"
 
 #define FFT_N 32
@@ -76,54 +80,6 @@ struct FftGeom {
     int B, H, W, C, N;           // input [B,H,W,C], output channels N
     int k, pad, T, tiles_y, tiles_x, M;      // M = B * tiles_y * tiles_x
 };
-
-// rows: thread = (tile, patch row a, channel c); c fastest -> every load / store of a wave is one contiguous line
-__global__ __launch_bounds__(256) void fft_rows_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ R,
-                                                       FftGeom g, int halo /* 1: patch = outputs - pad (overlap-save); 0: tile only */) {
-    const int C = g.C;
-    const int64_t total = (int64_t)g.M * FFT_N * C;
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        int64_t r = i / C;
-        const int a = (int)(r % FFT_N);
-        const int t = (int)(r / FFT_N);
-        const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
-        const int iy = ty * g.T + a - (halo ? g.pad : 0);
-        const int ix0 = tx * g.T - (halo ? g.pad : 0);
-        const int nvalid = halo ? FFT_N : g.T;          // tile-only mode: positions >= T (and rows >= T) are zero padding
-        float re[32], im[32];
-        const bool row_ok = iy >= 0 && iy < g.H && a < nvalid;
-        const float* src = x + ((size_t)(b * g.H + (row_ok ? iy : 0)) * g.W) * ldx + c;
-#pragma unroll
-        for (int bb = 0; bb < 32; ++bb) {
-            const int ix = ix0 + bb;
-            re[bb] = (row_ok && bb < nvalid && ix >= 0 && ix < g.W) ? src[(size_t)ix * ldx] : 0.f;
-            im[bb] = 0.f;
-        }
-        fft32<-1>(re, im);
-        float2* dst = R + (((size_t)t * FFT_N + a) * FFT_NK) * C + c;
-#pragma unroll
-        for (int kx = 0; kx < FFT_NK; ++kx) dst[(size_t)kx * C] = make_float2(re[kx], im[kx]);
-    }
-}
-
-// cols: thread = (tile, kx, channel): FFT32 along the patch rows; output bin-major for the per-bin GEMM
-__global__ __launch_bounds__(256) void fft_cols_kernel(const float2* __restrict__ R, float2* __restrict__ Xf, int C, int M) {
-    const int64_t total = (int64_t)M * FFT_NK * C;
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        int64_t r = i / C;
-        const int kx = (int)(r % FFT_NK);
-        const int t = (int)(r / FFT_NK);
-        float re[32], im[32];
-        const float2* src = R + (((size_t)t * FFT_N) * FFT_NK + kx) * C + c;
-#pragma unroll
-        for (int a = 0; a < 32; ++a) { const float2 v = src[(size_t)a * FFT_NK * C]; re[a] = v.x; im[a] = v.y; }
-        fft32<-1>(re, im);
-#pragma unroll
-        for (int ky = 0; ky < 32; ++ky) Xf[((size_t)(ky * FFT_NK + kx) * M + t) * C + c] = make_float2(re[ky], im[ky]);
-    }
-}
 
 // weights: DFT of the k*k taps at every kept bin, written as the real embedding of conj(DFT(w[n][c])) (correlation):
 //   Wf[bin][2n+p][2c+q]:  row 2n = [wr, wi], row 2n+1 = [-wi, wr]   (out_re = sum x_re*wr + x_im*wi, ...)
@@ -263,62 +219,6 @@ __global__ __launch_bounds__(256) void ifft_cols_kernel(const float2* __restrict
     }
 }
 
-// irows: thread = (tile, row u, channel n): Hermitian inverse along kx; writes the valid T outputs of the row into y
-// (+ addsrc), and per-workgroup BatchNorm partial sums.  grid.x = ceil(M*T / 4) workgroups of 4 rows x 64 channels ... the
-// host passes rows_per_wg = 256 / C.
-__global__ __launch_bounds__(256) void ifft_rows_kernel(const float2* __restrict__ S, float* __restrict__ y, int ldy,
-                                                        const float* __restrict__ addsrc, int ld_add,
-                                                        float* __restrict__ stats, const float* __restrict__ ep_scale,
-                                                        const float* __restrict__ ep_shift, int act, FftGeom g) {
-    __shared__ float red[256 * 2];
-    const int C = g.N, T = g.T;
-    const int rows_per_wg = 256 / C;
-    const int c = threadIdx.x % C, rl = threadIdx.x / C;
-    const int64_t row_id = (int64_t)blockIdx.x * rows_per_wg + rl;          // = t * T + u
-    float s1 = 0.f, s2 = 0.f;
-    if (rl < rows_per_wg && row_id < (int64_t)g.M * T) {
-        const int t = (int)(row_id / T), u = (int)(row_id % T);
-        const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
-        const int oy = ty * T + u;
-        if (oy < g.H) {
-            float re[32], im[32];
-            const float2* src = S + (((size_t)t * FFT_N + u) * FFT_NK) * C + c;
-#pragma unroll
-            for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = src[(size_t)kx * C]; re[kx] = v.x; im[kx] = v.y; }
-#pragma unroll
-            for (int kx = FFT_NK; kx < 32; ++kx) { re[kx] = re[32 - kx]; im[kx] = -im[32 - kx]; }
-            fft32<1>(re, im);
-            float* dst = y + ((size_t)(b * g.H + oy) * g.W) * ldy + c;
-            const float* ad = addsrc ? addsrc + ((size_t)(b * g.H + oy) * g.W) * ld_add + c : nullptr;
-            const float es = ep_scale ? ep_scale[c] : 1.f, et = ep_shift ? ep_shift[c] : 0.f;
-#pragma unroll
-            for (int v = 0; v < 32; ++v) {
-                const int ox = tx * T + v;
-                if (v < T && ox < g.W) {
-                    float val = re[v] * (1.0f / 1024.0f);
-                    s1 += val; s2 += val * val;
-                    if (ep_scale) val = val * es + et;
-                    if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
-                    if (ad) val += ad[(size_t)ox * ld_add];
-                    if (act & GDN_ACT_TANH) val = tanhf(val);
-                    dst[(size_t)ox * ldy] = val;
-                }
-            }
-        }
-    }
-    if (stats) {
-        red[threadIdx.x * 2] = s1; red[threadIdx.x * 2 + 1] = s2;
-        __syncthreads();
-        if (threadIdx.x < C) {
-            float a1 = 0.f, a2 = 0.f;
-            for (int j = 0; j < rows_per_wg; ++j) { a1 += red[(j * C + threadIdx.x) * 2]; a2 += red[(j * C + threadIdx.x) * 2 + 1]; }
-            stats[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = a1;
-            stats[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = a2;
-        }
-    }
-}
-
-
 // Reduction-over-tiles GEMM of the weight gradient:  P[bin][i][j] = sum_m A[bin][m][i] * Bm[bin][m][j]
 // (A = spectrum of dy [M][2N], Bm = spectrum of x [M][2C]; both operands are read as they lie, rows = tiles).
 // 64x64 output tile, 32 tiles of the reduction per step; every MFMA operand is one conflict-free ds_read_b32 row read.
@@ -374,9 +274,54 @@ __global__ __launch_bounds__(256) void gemm_tn_bins_kernel(const float* __restri
 
 // Inverse DFT of the weight-gradient spectrum at the k*k taps.  P[bin][2n+p][2c+q] = sum_m D_p X_q;
 // dWf = conj(D) X = (P00 + P11) + i (P01 - P10); Hermitian weights 1 (kx = 0, 16) / 2 over the 17 kept kx bins.
-// thread = (n, c); one tap row (fixed ty) per blockIdx.y so the accumulators stay in registers.
-template <int K>
+// block = 64 (n, c) pairs x 4 groups of 8 ky (one wave each, so every twiddle index is wave-uniform); the four partial
+// sums meet in LDS in a fixed order.  TYB tap rows per block (1: one tap row per blockIdx.y; reading all taps from one pass
+// over P measured slower -- the twiddle lookups, not the bytes, bound this kernel).
+template <int K, int TYB>
 __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C) {
+    __shared__ float red[3][TYB * K][64];
+    const int ty0 = blockIdx.y * TYB;
+    const int pl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + pl;             // N*C is a multiple of 64
+    const int c = i % C, n = i / C;
+    float acc[TYB * K];
+#pragma unroll
+    for (int t = 0; t < TYB * K; ++t) acc[t] = 0.f;
+    const size_t rs = (size_t)2 * C;
+    for (int ky = grp * 8; ky < grp * 8 + 8; ++ky) {
+        for (int kx = 0; kx < FFT_NK; ++kx) {
+            const float* pb = P + (size_t)(ky * FFT_NK + kx) * (2 * N) * rs + (size_t)(2 * n) * rs + 2 * c;
+            const float2 p0 = *reinterpret_cast<const float2*>(pb);
+            const float2 p1 = *reinterpret_cast<const float2*>(pb + rs);
+            const float alpha = (kx == 0 || kx == 16) ? 1.f : 2.f;
+            const float fr = (p0.x + p1.y) * alpha, fi = (p0.y - p1.x) * alpha;
+#pragma unroll
+            for (int tyl = 0; tyl < TYB; ++tyl) {
+                const int base = ky * (ty0 + tyl);
+#pragma unroll
+                for (int tx = 0; tx < K; ++tx) {
+                    const int ph = (base + kx * tx) & 31;
+                    acc[tyl * K + tx] += fr * kCos32[ph] - fi * kSin32[ph];
+                }
+            }
+        }
+    }
+    if (grp > 0) {
+#pragma unroll
+        for (int t = 0; t < TYB * K; ++t) red[grp - 1][t][pl] = acc[t];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int t = 0; t < TYB * K; ++t)
+            dw[((size_t)(ty0 * K + t) * N + n) * C + c] = (((acc[t] + red[0][t][pl]) + red[1][t][pl]) + red[2][t][pl]) * (1.0f / 1024.0f);
+    }
+}
+
+// Wide layers (128+ channels): thread = (n, c), one tap row per blockIdx.y, all 544 bins -- enough threads already, and the
+// plain streaming order measured faster there than the grouped kernel above.
+template <int K>
+__global__ __launch_bounds__(256) void fft_wgrad_taps_wide_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C) {
     const int ty = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N * C) return;
@@ -455,6 +400,117 @@ __global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __
     }
 }
 
+// ---- single-pass 2-D transforms: one workgroup = one tile x 16 channels, rows and columns meet in LDS (68 KB) ----
+#define FFT_CG 16
+#define FFT_LDS_ELEMS (FFT_N * FFT_NK * FFT_CG)
+
+// forward: patch (halo = 1: rows/cols start at -pad, full 32; halo = 0: the T x T tile, zero padded) -> Xf[bin][tile][C]
+__global__ __launch_bounds__(512, 4) void fft2d_fwd_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ Xf,
+                                                        FftGeom g, int halo) {
+    __shared__ float2 lds[FFT_LDS_ELEMS];
+    const int tid = threadIdx.x, c = tid & 15, cg = blockIdx.x * FFT_CG, t = blockIdx.y;
+    const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
+    float re[32], im[32];
+    {
+        const int a = tid >> 4;
+        const int iy = ty * g.T + a - (halo ? g.pad : 0);
+        const int ix0 = tx * g.T - (halo ? g.pad : 0);
+        const int nvalid = halo ? FFT_N : g.T;
+        const bool row_ok = iy >= 0 && iy < g.H && a < nvalid;
+        const float* src = x + ((size_t)(b * g.H + (row_ok ? iy : 0)) * g.W) * ldx + cg + c;
+#pragma unroll
+        for (int bb = 0; bb < 32; ++bb) {
+            const int ix = ix0 + bb;
+            re[bb] = (row_ok && bb < nvalid && ix >= 0 && ix < g.W) ? src[(size_t)ix * ldx] : 0.f;
+            im[bb] = 0.f;
+        }
+        fft32<-1>(re, im);
+#pragma unroll
+        for (int kx = 0; kx < FFT_NK; ++kx) lds[(a * FFT_NK + kx) * FFT_CG + c] = make_float2(re[kx], im[kx]);
+    }
+    __syncthreads();
+    if (tid < FFT_NK * FFT_CG) {
+        const int kx = tid >> 4;
+#pragma unroll
+        for (int a = 0; a < 32; ++a) { const float2 v = lds[(a * FFT_NK + kx) * FFT_CG + c]; re[a] = v.x; im[a] = v.y; }
+        fft32<-1>(re, im);
+        const int C = g.C;
+#pragma unroll
+        for (int ky = 0; ky < 32; ++ky) Xf[((size_t)(ky * FFT_NK + kx) * g.M + t) * C + cg + c] = make_float2(re[ky], im[ky]);
+    }
+}
+
+// inverse, first half shared by both consumers: Yf[bin][tile][C] -> lds[u][kx][c] (inverse along ky)
+__device__ __forceinline__ void ifft2d_cols_to_lds(const float2* __restrict__ Yf, float2* lds, int C, int M, int t, int cg,
+                                                   float (&re)[32], float (&im)[32]) {
+    const int tid = threadIdx.x, c = tid & 15;
+    if (tid < FFT_NK * FFT_CG) {
+        const int kx = tid >> 4;
+#pragma unroll
+        for (int ky = 0; ky < 32; ++ky) {
+            const float2 v = Yf[((size_t)(ky * FFT_NK + kx) * M + t) * C + cg + c];
+            re[ky] = v.x; im[ky] = v.y;
+        }
+        fft32<1>(re, im);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) lds[(u * FFT_NK + kx) * FFT_CG + c] = make_float2(re[u], im[u]);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void ifft_row_from_lds(const float2* lds, int u, int c, float (&re)[32], float (&im)[32]) {
+#pragma unroll
+    for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = lds[(u * FFT_NK + kx) * FFT_CG + c]; re[kx] = v.x; im[kx] = v.y; }
+#pragma unroll
+    for (int kx = FFT_NK; kx < 32; ++kx) { re[kx] = re[32 - kx]; im[kx] = -im[32 - kx]; }
+    fft32<1>(re, im);
+}
+
+// forward convolution output: valid T x T outputs of the tile, epilogue, BatchNorm partials (stats slot = tile)
+__global__ __launch_bounds__(512, 4) void ifft2d_valid_kernel(const float2* __restrict__ Yf, float* __restrict__ y, int ldy,
+                                                           const float* __restrict__ addsrc, int ld_add,
+                                                           float* __restrict__ stats, const float* __restrict__ ep_scale,
+                                                           const float* __restrict__ ep_shift, int act, FftGeom g) {
+    __shared__ float2 lds[FFT_LDS_ELEMS];
+    const int tid = threadIdx.x, c = tid & 15, cg = blockIdx.x * FFT_CG, t = blockIdx.y, T = g.T;
+    const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
+    float re[32], im[32];
+    ifft2d_cols_to_lds(Yf, lds, g.N, g.M, t, cg, re, im);
+    const int u = tid >> 4, oy = ty * T + u;
+    float s1 = 0.f, s2 = 0.f;
+    if (u < T && oy < g.H) {
+        ifft_row_from_lds(lds, u, c, re, im);
+        float* dst = y + ((size_t)(b * g.H + oy) * g.W) * ldy + cg + c;
+        const float* ad = addsrc ? addsrc + ((size_t)(b * g.H + oy) * g.W) * ld_add + cg + c : nullptr;
+        const float es = ep_scale ? ep_scale[cg + c] : 1.f, et = ep_shift ? ep_shift[cg + c] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 32; ++v) {
+            const int ox = tx * T + v;
+            if (v < T && ox < g.W) {
+                float val = re[v] * (1.0f / 1024.0f);
+                s1 += val; s2 += val * val;
+                if (ep_scale) val = val * es + et;
+                if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
+                if (ad) val += ad[(size_t)ox * ld_add];
+                if (act & GDN_ACT_TANH) val = tanhf(val);
+                dst[(size_t)ox * ldy] = val;
+            }
+        }
+    }
+    if (stats) {
+        __syncthreads();                       // everyone is done reading the spectrum rows
+        float* red = reinterpret_cast<float*>(lds);
+        red[tid * 2] = s1; red[tid * 2 + 1] = s2;
+        __syncthreads();
+        if (tid < FFT_CG) {
+            float a1 = 0.f, a2 = 0.f;
+            for (int j = 0; j < 32; ++j) { a1 += red[(j * FFT_CG + tid) * 2]; a2 += red[(j * FFT_CG + tid) * 2 + 1]; }
+            stats[((size_t)t * 2 + 0) * g.N + cg + tid] = a1;
+            stats[((size_t)t * 2 + 1) * g.N + cg + tid] = a2;
+        }
+    }
+}
+
 bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
     if (!g || g->transposed || g->stride != 1 || g->pad_mode != 0 || g->k < 3 || g->k > 9 || (g->k & 1) == 0) return false;
     if (g->pad != g->k / 2) return false;
@@ -470,19 +526,18 @@ inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
 
-// workspace: R/S intermediate (M*32*17*max(C,N) complex), Xf, Yf (M*544*C / N complex), Wf (544 * 2N * 2C floats)
+// workspace: Xf, Yf (M*544*C / N complex), Wf (544 * 2N * 2C floats)
 extern "C" size_t gdn_fftconv_fwd_workspace_bytes(const gdn_conv_geom* g) {
     FftGeom f;
     if (!fft_geom(g, f)) return 0;
-    const size_t cm = f.C > f.N ? f.C : f.N;
-    return al256((size_t)f.M * FFT_N * FFT_NK * cm * 8) + al256((size_t)f.M * FFT_BINS * f.C * 8) +
-           al256((size_t)f.M * FFT_BINS * f.N * 8) + al256((size_t)FFT_BINS * 4 * f.C * f.N * 4);
+    return al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)f.M * FFT_BINS * f.N * 8) +
+           al256((size_t)FFT_BINS * 4 * f.C * f.N * 4);
 }
 
 extern "C" int64_t gdn_fftconv_stats_slots(const gdn_conv_geom* g) {
     FftGeom f;
     if (!fft_geom(g, f)) return GDN_ERR_UNSUPPORTED;
-    return cdiv64((int64_t)f.M * f.T, 256 / f.N);
+    return f.M;          // one slot per tile
 }
 
 // saved state of one forward for its backward: input spectrum Xf, then the weight spectrum Wf
@@ -514,9 +569,7 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
     if (!x || !w || !y || (!ep_scale) != (!ep_shift)) return GDN_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gdn_fftconv_fwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const size_t cm = f.C > f.N ? f.C : f.N;
     char* p = (char*)workspace;
-    float2* R = (float2*)p; p += al256((size_t)f.M * FFT_N * FFT_NK * cm * 8);
     float2* Xf = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.C * 8);
     float2* Yf = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.N * 8);
     float* Wf = (float*)p;
@@ -524,16 +577,12 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
         Xf = (float2*)xf_out;
         Wf = (float*)((char*)xf_out + al256((size_t)f.M * FFT_BINS * f.C * 8));
     }
-    auto blocks = [](int64_t n) { const int64_t b = cdiv64(n, 256); return (unsigned)(b < 65536 * 8 ? b : 65536 * 8); };
-    hipLaunchKernelGGL(fft_rows_kernel, dim3(blocks((int64_t)f.M * FFT_N * f.C)), dim3(256), 0, st, x, ldx, R, f, 1);
-    hipLaunchKernelGGL(fft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.C)), dim3(256), 0, st, (const float2*)R, Xf, f.C, f.M);
+    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.C / FFT_CG, f.M), dim3(512), 0, st, x, ldx, Xf, f, 1);
     launch_weights(f, w, Wf, st);
     hipLaunchKernelGGL(gemm_bins_kernel<false>, dim3(cdiv(f.M, 64), cdiv(2 * f.N, 64), FFT_BINS), dim3(256), 0, st,
                        (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, 2 * f.N, 2 * f.C);
-    hipLaunchKernelGGL(ifft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.N)), dim3(256), 0, st, (const float2*)Yf, R, f.N, f.M, f.T);
-    FftGeom fo = f;
-    hipLaunchKernelGGL(ifft_rows_kernel, dim3((unsigned)cdiv64((int64_t)f.M * f.T, 256 / f.N)), dim3(256), 0, st,
-                       (const float2*)R, y, ldy, addsrc, ld_add, stats, ep_scale, ep_shift, act, fo);
+    hipLaunchKernelGGL(ifft2d_valid_kernel, dim3(f.N / FFT_CG, f.M), dim3(512), 0, st, (const float2*)Yf, y, ldy, addsrc,
+                       ld_add, stats, ep_scale, ep_shift, act, f);
     return gdn_launch_status();
 }
 
@@ -565,14 +614,16 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     // spectrum of the dy tiles (no halo: rows / columns >= T are the zero padding of the linear convolution)
     FftGeom fd = f;
     fd.C = f.N;
-    hipLaunchKernelGGL(fft_rows_kernel, dim3(blocks((int64_t)f.M * FFT_N * f.N)), dim3(256), 0, st, dy, ldy, R, fd, 0);
-    hipLaunchKernelGGL(fft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.N)), dim3(256), 0, st, (const float2*)R, Df, f.N, f.M);
+    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.N / FFT_CG, f.M), dim3(512), 0, st, dy, ldy, Df, fd, 0);
     if (dw) {
         float* P = Wf;
         hipLaunchKernelGGL(gemm_tn_bins_kernel, dim3(2 * f.N / 64, 2 * f.C / 64, FFT_BINS), dim3(256), 0, st,
                            (const float*)Df, (const float*)xf, P, f.M, 2 * f.N, 2 * f.C);
-        const dim3 gr(cdiv(f.N * f.C, 256), f.k);
-#define GDN_TAPS(KK) case KK: hipLaunchKernelGGL(fft_wgrad_taps_kernel<KK>, gr, dim3(256), 0, st, (const float*)P, dw, f.N, f.C); break;
+        const bool wide = f.N * f.C >= 128 * 128;
+#define GDN_TAPS(KK) case KK: \
+            if (wide) hipLaunchKernelGGL(fft_wgrad_taps_wide_kernel<KK>, dim3(cdiv(f.N * f.C, 256), KK), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
+            else hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 1>), dim3(f.N * f.C / 64, KK), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
+            break;
         switch (f.k) {
             GDN_TAPS(3) GDN_TAPS(5) GDN_TAPS(7) GDN_TAPS(9)
         }
@@ -583,6 +634,8 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         if (!Wsaved) launch_weights(f, w, Wf, st);
         hipLaunchKernelGGL(gemm_bins_kernel<true>, dim3(cdiv(f.M, 64), cdiv(2 * f.C, 64), FFT_BINS), dim3(256), 0, st,
                            (const float*)Df, Wsaved ? Wsaved : (const float*)Wf, (float*)Ef, f.M, 2 * f.C, 2 * f.N);
+        // inverse along ky into S, then rows: the tile rows that reach an image row are summed in the frequency domain
+        // (measured faster than the single-pass patch kernel with four parity launches, profiles/r01_fftconv_notes.txt)
         hipLaunchKernelGGL(ifft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.C)), dim3(256), 0, st, (const float2*)Ef, R, f.C, f.M, FFT_N);
         for (int parity = 0; parity < 2; ++parity) {
             const int ntx = (f.tiles_x + 1 - parity) / 2;

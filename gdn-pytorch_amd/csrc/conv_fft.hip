@@ -79,6 +79,8 @@ __device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
 struct FftGeom {
     int B, H, W, C, N;           // input [B,H,W,C], output channels N
     int k, pad, T, tiles_y, tiles_x, M;      // M = B * tiles_y * tiles_x
+    int reflect;                             // input border: 0 zeros, 1 reflection (ReflectionPad2d(pad) + conv)
+    int flip;                                // stride-1 ConvTranspose2d: correlation with the flipped taps
 };
 
 // weights: DFT of the k*k taps at every kept bin, written as the real embedding of conj(DFT(w[n][c])) (correlation):
@@ -88,7 +90,7 @@ struct FftGeom {
 // thread = (n, c) with its K*K taps in registers; block = one ky; column transform first, then the 17 kx bins.
 template <int K>
 __global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restrict__ w /* [k*k][N][C] */, float* __restrict__ Wf,
-                                                          int N, int C) {
+                                                          int N, int C, int flip) {
     const int ky = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N * C) return;
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restric
         const float cs = kCos32[ph], sn = kSin32[ph];
 #pragma unroll
         for (int tx = 0; tx < K; ++tx) {
-            const float v = w[((size_t)(ty * K + tx) * N + n) * C + c];
+            const int tap = flip ? (K - 1 - ty) * K + (K - 1 - tx) : ty * K + tx;
+            const float v = w[((size_t)tap * N + n) * C + c];
             ur[tx] += v * cs;
             ui[tx] -= v * sn;              // e^{-i phi}
         }
@@ -354,17 +357,19 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_wide_kernel(const float* _
 // even and odd tiles are written by two launches (parity): the first writer of a column stores (+ addsrc), the second adds.
 __global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __restrict__ S, float* __restrict__ dx, int lddx,
                                                                 const float* __restrict__ addsrc, int ld_add, FftGeom g,
-                                                                int parity) {
+                                                                int parity, int Ho, int Wo, int off) {
+    // output image Ho x Wo; patch row j of tile row ty lands on output row ty*T - off + j  (off = pad for a zero-padded
+    // layer: dx itself; off = 0 for a reflection-padded one: the padded-domain gradient, folded afterwards)
     const int C = g.C, T = g.T;
     const int ntx = (g.tiles_x + 1 - parity) / 2;         // tiles of this parity per row
-    const int64_t total = (int64_t)g.B * g.H * ntx * C;
+    const int64_t total = (int64_t)g.B * Ho * ntx * C;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         int64_t r = i / C;
         const int tx = (int)(r % ntx) * 2 + parity;
         r /= ntx;
-        const int iy = (int)(r % g.H), b = (int)(r / g.H);
-        const int q = iy + g.pad;
+        const int iy = (int)(r % Ho), b = (int)(r / Ho);
+        const int q = iy + off;
         const int ty_a = q / T, j_a = q - ty_a * T;
         float re[32], im[32];
 #pragma unroll
@@ -384,19 +389,47 @@ __global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __
 #pragma unroll
         for (int kx = FFT_NK; kx < 32; ++kx) { re[kx] = re[32 - kx]; im[kx] = -im[32 - kx]; }
         fft32<1>(re, im);
-        float* dst = dx + ((size_t)(b * g.H + iy) * g.W) * lddx + c;
-        const float* ad = addsrc ? addsrc + ((size_t)(b * g.H + iy) * g.W) * ld_add + c : nullptr;
+        float* dst = dx + ((size_t)(b * Ho + iy) * Wo) * lddx + c;
+        const float* ad = addsrc ? addsrc + ((size_t)(b * Ho + iy) * Wo) * ld_add + c : nullptr;
         const bool has_next = tx + 1 < g.tiles_x;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-            const int ix = tx * T - g.pad + j;
-            if (ix < 0 || ix >= g.W) continue;
+            const int ix = tx * T - off + j;
+            if (ix < 0 || ix >= Wo) continue;
             const float val = re[j] * (1.0f / 1024.0f);
             // odd tiles: columns shared with the even neighbours were stored by the first launch
             const bool second = parity == 1 && (j < g.k - 1 || (j >= T && has_next));
             if (second) dst[(size_t)ix * lddx] += val;
             else dst[(size_t)ix * lddx] = ad ? val + ad[(size_t)ix * ld_add] : val;
         }
+    }
+}
+
+// dx[y][x] = sum of the padded-domain gradient over the padded coordinates that reflect onto (y, x)  (+ addsrc)
+__global__ __launch_bounds__(256) void fft_reflect_fold_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int ldx,
+                                                               const float* __restrict__ addsrc, int ld_add,
+                                                               int B, int H, int W, int C, int p) {
+    const int Hp = H + 2 * p, Wp = W + 2 * p, c4n = C / 4;
+    const int64_t total = (int64_t)B * H * W * c4n;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H), b = (int)(t / H);
+        int qy[3], qx[3], ny = 0, nx = 0;
+        qy[ny++] = y + p;
+        if (y >= 1 && y <= p) qy[ny++] = p - y;
+        if (y <= H - 2 && y >= H - 1 - p) qy[ny++] = 2 * (H - 1) - y + p;
+        qx[nx++] = x + p;
+        if (x >= 1 && x <= p) qx[nx++] = p - x;
+        if (x <= W - 2 && x >= W - 1 - p) qx[nx++] = 2 * (W - 1) - x + p;
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a)
+            for (int e = 0; e < nx; ++e)
+                s4 += *reinterpret_cast<const f32x4*>(dxp + ((size_t)(b * Hp + qy[a]) * Wp + qx[e]) * C + c4 * 4);
+        const size_t op = (size_t)(b * H + y) * W + x;
+        if (addsrc) s4 += *reinterpret_cast<const f32x4*>(addsrc + op * ld_add + c4 * 4);
+        *reinterpret_cast<f32x4*>(dx + op * ldx + c4 * 4) = s4;
     }
 }
 
@@ -408,7 +441,8 @@ __global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __
 __global__ __launch_bounds__(512, 4) void fft2d_fwd_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ Xf,
                                                         FftGeom g, int halo) {
     __shared__ float2 lds[FFT_LDS_ELEMS];
-    const int tid = threadIdx.x, c = tid & 15, cg = blockIdx.x * FFT_CG, t = blockIdx.y;
+    const int ngrp = g.C / FFT_CG;
+    const int tid = threadIdx.x, c = tid & 15, cg = (blockIdx.x % ngrp) * FFT_CG, t = blockIdx.x / ngrp;
     const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
     float re[32], im[32];
     {
@@ -416,12 +450,17 @@ __global__ __launch_bounds__(512, 4) void fft2d_fwd_kernel(const float* __restri
         const int iy = ty * g.T + a - (halo ? g.pad : 0);
         const int ix0 = tx * g.T - (halo ? g.pad : 0);
         const int nvalid = halo ? FFT_N : g.T;
-        const bool row_ok = iy >= 0 && iy < g.H && a < nvalid;
-        const float* src = x + ((size_t)(b * g.H + (row_ok ? iy : 0)) * g.W) * ldx + cg + c;
+        // reflection border (halo patches only): rows / columns -pad..-1 and H..H+pad-1 mirror the image; anything
+        // further out only feeds outputs beyond the image and reads as zero
+        const int lim = (halo && g.reflect) ? g.pad : 0;
+        const bool row_ok = iy >= -lim && iy < g.H + lim && a < nvalid;
+        const int iyr = iy < 0 ? -iy : (iy >= g.H ? 2 * g.H - 2 - iy : iy);
+        const float* src = x + ((size_t)(b * g.H + (row_ok ? iyr : 0)) * g.W) * ldx + cg + c;
 #pragma unroll
         for (int bb = 0; bb < 32; ++bb) {
             const int ix = ix0 + bb;
-            re[bb] = (row_ok && bb < nvalid && ix >= 0 && ix < g.W) ? src[(size_t)ix * ldx] : 0.f;
+            const int ixr = ix < 0 ? -ix : (ix >= g.W ? 2 * g.W - 2 - ix : ix);
+            re[bb] = (row_ok && bb < nvalid && ix >= -lim && ix < g.W + lim) ? src[(size_t)ixr * ldx] : 0.f;
             im[bb] = 0.f;
         }
         fft32<-1>(re, im);
@@ -472,7 +511,8 @@ __global__ __launch_bounds__(512, 4) void ifft2d_valid_kernel(const float2* __re
                                                            float* __restrict__ stats, const float* __restrict__ ep_scale,
                                                            const float* __restrict__ ep_shift, int act, FftGeom g) {
     __shared__ float2 lds[FFT_LDS_ELEMS];
-    const int tid = threadIdx.x, c = tid & 15, cg = blockIdx.x * FFT_CG, t = blockIdx.y, T = g.T;
+    const int ngrp = g.N / FFT_CG;
+    const int tid = threadIdx.x, c = tid & 15, cg = (blockIdx.x % ngrp) * FFT_CG, t = blockIdx.x / ngrp, T = g.T;
     const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
     float re[32], im[32];
     ifft2d_cols_to_lds(Yf, lds, g.N, g.M, t, cg, re, im);
@@ -512,13 +552,16 @@ __global__ __launch_bounds__(512, 4) void ifft2d_valid_kernel(const float2* __re
 }
 
 bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
-    if (!g || g->transposed || g->stride != 1 || g->pad_mode != 0 || g->k < 3 || g->k > 9 || (g->k & 1) == 0) return false;
-    if (g->pad != g->k / 2) return false;
+    if (!g || g->stride != 1 || g->k < 3 || g->k > 9 || (g->k & 1) == 0) return false;
+    if (g->pad != g->k / 2 || (g->transposed && g->pad_mode != 0)) return false;
+    if (g->pad_mode == 1 && (g->pad >= g->H || g->pad >= g->W)) return false;
     if ((g->Cin % 64) || (g->Cout % 64) || g->Cin > 256 || g->Cout > 256) return false;
     f.B = g->B; f.H = g->H; f.W = g->W; f.C = g->Cin; f.N = g->Cout; f.k = g->k; f.pad = g->pad;
     f.T = FFT_N - g->k + 1;
     f.tiles_y = cdiv(g->H, f.T); f.tiles_x = cdiv(g->W, f.T);
     f.M = g->B * f.tiles_y * f.tiles_x;
+    f.reflect = g->pad_mode == 1;
+    f.flip = g->transposed ? 1 : 0;
     return true;
 }
 
@@ -551,10 +594,10 @@ namespace {
 void launch_weights(const FftGeom& f, const float* w, float* Wf, hipStream_t st) {
     const dim3 gr(cdiv(f.N * f.C, 256), FFT_N);
     switch (f.k) {
-        case 3: hipLaunchKernelGGL(fft_weights_kernel<3>, gr, dim3(256), 0, st, w, Wf, f.N, f.C); break;
-        case 5: hipLaunchKernelGGL(fft_weights_kernel<5>, gr, dim3(256), 0, st, w, Wf, f.N, f.C); break;
-        case 7: hipLaunchKernelGGL(fft_weights_kernel<7>, gr, dim3(256), 0, st, w, Wf, f.N, f.C); break;
-        default: hipLaunchKernelGGL(fft_weights_kernel<9>, gr, dim3(256), 0, st, w, Wf, f.N, f.C); break;
+        case 3: hipLaunchKernelGGL(fft_weights_kernel<3>, gr, dim3(256), 0, st, w, Wf, f.N, f.C, f.flip); break;
+        case 5: hipLaunchKernelGGL(fft_weights_kernel<5>, gr, dim3(256), 0, st, w, Wf, f.N, f.C, f.flip); break;
+        case 7: hipLaunchKernelGGL(fft_weights_kernel<7>, gr, dim3(256), 0, st, w, Wf, f.N, f.C, f.flip); break;
+        default: hipLaunchKernelGGL(fft_weights_kernel<9>, gr, dim3(256), 0, st, w, Wf, f.N, f.C, f.flip); break;
     }
 }
 }  // namespace
@@ -577,11 +620,11 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
         Xf = (float2*)xf_out;
         Wf = (float*)((char*)xf_out + al256((size_t)f.M * FFT_BINS * f.C * 8));
     }
-    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.C / FFT_CG, f.M), dim3(512), 0, st, x, ldx, Xf, f, 1);
+    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.C / FFT_CG * f.M), dim3(512), 0, st, x, ldx, Xf, f, 1);
     launch_weights(f, w, Wf, st);
     hipLaunchKernelGGL(gemm_bins_kernel<false>, dim3(cdiv(f.M, 64), cdiv(2 * f.N, 64), FFT_BINS), dim3(256), 0, st,
                        (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, 2 * f.N, 2 * f.C);
-    hipLaunchKernelGGL(ifft2d_valid_kernel, dim3(f.N / FFT_CG, f.M), dim3(512), 0, st, (const float2*)Yf, y, ldy, addsrc,
+    hipLaunchKernelGGL(ifft2d_valid_kernel, dim3(f.N / FFT_CG * f.M), dim3(512), 0, st, (const float2*)Yf, y, ldy, addsrc,
                        ld_add, stats, ep_scale, ep_shift, act, f);
     return gdn_launch_status();
 }
@@ -590,9 +633,11 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
 extern "C" size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     FftGeom f;
     if (!fft_geom(g, f)) return 0;
+    if (f.flip) return 0;                  // stride-1 ConvTranspose2d: forward (inference) only
     const size_t cm = f.C > f.N ? f.C : f.N;
+    const size_t padded = f.reflect ? al256((size_t)f.B * (f.H + 2 * f.pad) * (f.W + 2 * f.pad) * f.C * 4) : 0;
     return al256((size_t)f.M * FFT_N * FFT_NK * cm * 8) + al256((size_t)f.M * FFT_BINS * f.N * 8) +
-           al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)FFT_BINS * 4 * f.C * f.N * 4);
+           al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)FFT_BINS * 4 * f.C * f.N * 4) + padded;
 }
 
 extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w, const void* xf,
@@ -600,8 +645,9 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
                                size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
     FftGeom f;
-    if (!fft_geom(g, f)) return GDN_ERR_UNSUPPORTED;
+    if (!fft_geom(g, f) || f.flip) return GDN_ERR_UNSUPPORTED;
     if (!dy || (!dx && !dw) || (dx && !w && !xf) || (dw && !xf)) return GDN_ERR_BAD_ARG;
+    if (dx && f.reflect && ((ldx % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < gdn_fftconv_bwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const size_t cm = f.C > f.N ? f.C : f.N;
@@ -609,12 +655,14 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     float2* R = (float2*)p; p += al256((size_t)f.M * FFT_N * FFT_NK * cm * 8);
     float2* Df = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.N * 8);
     float2* Ef = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.C * 8);
-    float* Wf = (float*)p;           // weight-gradient products P, or the weight spectrum when the forward saved none
+    float* Wf = (float*)p; p += al256((size_t)FFT_BINS * 4 * f.C * f.N * 4);   // weight-gradient products P, or the weight spectrum when the forward saved none
+    float* dxp = (float*)p;          // reflection layers: gradient over the padded domain
     auto blocks = [](int64_t n) { const int64_t b = cdiv64(n, 256); return (unsigned)(b < 65536 * 8 ? b : 65536 * 8); };
     // spectrum of the dy tiles (no halo: rows / columns >= T are the zero padding of the linear convolution)
     FftGeom fd = f;
     fd.C = f.N;
-    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.N / FFT_CG, f.M), dim3(512), 0, st, dy, ldy, Df, fd, 0);
+    fd.reflect = 0;
+    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.N / FFT_CG * f.M), dim3(512), 0, st, dy, ldy, Df, fd, 0);
     if (dw) {
         float* P = Wf;
         hipLaunchKernelGGL(gemm_tn_bins_kernel, dim3(2 * f.N / 64, 2 * f.C / 64, FFT_BINS), dim3(256), 0, st,
@@ -637,12 +685,20 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         // inverse along ky into S, then rows: the tile rows that reach an image row are summed in the frequency domain
         // (measured faster than the single-pass patch kernel with four parity launches, profiles/r01_fftconv_notes.txt)
         hipLaunchKernelGGL(ifft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.C)), dim3(256), 0, st, (const float2*)Ef, R, f.C, f.M, FFT_N);
+        const int Ho = f.reflect ? f.H + 2 * f.pad : f.H, Wo = f.reflect ? f.W + 2 * f.pad : f.W;
         for (int parity = 0; parity < 2; ++parity) {
             const int ntx = (f.tiles_x + 1 - parity) / 2;
             if (ntx == 0) continue;
-            hipLaunchKernelGGL(ifft_rows_overlap_kernel, dim3(blocks((int64_t)f.B * f.H * ntx * f.C)), dim3(256), 0, st,
-                               (const float2*)R, dx, ldx, addsrc, ld_add, f, parity);
+            if (f.reflect)
+                hipLaunchKernelGGL(ifft_rows_overlap_kernel, dim3(blocks((int64_t)f.B * Ho * ntx * f.C)), dim3(256), 0, st,
+                                   (const float2*)R, dxp, f.C, (const float*)nullptr, 0, f, parity, Ho, Wo, 0);
+            else
+                hipLaunchKernelGGL(ifft_rows_overlap_kernel, dim3(blocks((int64_t)f.B * Ho * ntx * f.C)), dim3(256), 0, st,
+                                   (const float2*)R, dx, ldx, addsrc, ld_add, f, parity, Ho, Wo, f.pad);
         }
+        if (f.reflect)
+            hipLaunchKernelGGL(fft_reflect_fold_kernel, dim3(blocks((int64_t)f.B * f.H * f.W * (f.C / 4))), dim3(256), 0, st,
+                               (const float*)dxp, dx, ldx, addsrc, ld_add, f.B, f.H, f.W, f.C, f.pad);
     }
     return gdn_launch_status();
 }

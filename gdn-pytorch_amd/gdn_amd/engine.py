@@ -272,8 +272,8 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     if bn.training and isinstance(bn, torch.nn.InstanceNorm2d):
         raise NotImplementedError("train-mode InstanceNorm (per-instance statistics) is not implemented on the HIP path; "
                                   "model.eval() normalises with the tracked running statistics like the reference does")
-    use_fft = (_FFT_MIN_K > 0 and ldt == torch.float32 and x2 is None and not reflect and conv.kernel_size[0] >= _FFT_MIN_K
-               and conv.stride[0] == 1 and op.fft_ok(x.shape[0], x.shape[1], x.shape[2]))
+    use_fft = (_FFT_MIN_K > 0 and ldt == torch.float32 and x2 is None and conv.kernel_size[0] >= _FFT_MIN_K
+               and conv.stride[0] == 1 and op.fft_ok(x.shape[0], x.shape[1], x.shape[2], backward=ctx.record))
     xf = None
     keep_xf = use_fft and ctx.record and conv.weight.requires_grad
     if bn.training:

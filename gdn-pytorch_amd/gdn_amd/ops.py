@@ -166,9 +166,12 @@ class Conv:
         return dx
 
     # ---- FFT-domain path (csrc/conv_fft.hip): stride-1 zero-padded fp32 layers with 64..256 channels ----
-    def fft_ok(self, B, H, W):
-        """True when gdn_fftconv_* supports this layer at this input size."""
+    def fft_ok(self, B, H, W, backward=False):
+        """True when gdn_fftconv_fwd (and, with `backward`, gdn_fftconv_bwd) supports this layer at this input size.
+        Stride-1 ConvTranspose2d layers are forward-only."""
         _, ref, _, _ = self.geom(B, H, W)
+        if backward:
+            return int(lib.gdn_fftconv_bwd_workspace_bytes(ref)) > 0
         return int(lib.gdn_fftconv_spectrum_bytes(ref)) > 0
 
     def fft_stats_slots(self, B, H, W):

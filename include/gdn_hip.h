@@ -129,14 +129,17 @@ int gdn_conv_wgrad(const gdn_conv_geom* g, const void* x, int32_t ldx, int32_t C
                    float* dw, int32_t ld_dw, int32_t ci_off,
                    void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream);
 
-/* FFT-domain convolution for the large-window residual layers (AE_model_unet.py ResidualBlock:
- * 9x9 on 64 channels, 7x7 on 128): stride 1, zero padding k/2, odd k in 3..9, Cin and Cout
- * multiples of 64 up to 256, fp32.  Overlap-save on 32x32 tiles: real FFT of the input patches,
+/* FFT-domain convolution for the large-window stride-1 layers (AE_model_unet.py ResidualBlock: 9x9 on
+ * 64 channels, 7x7 on 128, 5x5 on 256; ConvBlock with ReflectionPad2d in R's decoder; the legacy
+ * network's stride-1 ConvTranspose2d): stride 1, pad k/2 (zeros or reflection), odd k in 3..9, Cin and
+ * Cout multiples of 64 up to 256, fp32.  Overlap-save on 32x32 tiles: real FFT of the input patches,
  * one complex (real-embedded, MFMA) GEMM per frequency bin, inverse FFT of the valid outputs.
  * Same contract as gdn_conv_fwd for y / addsrc / stats / ep_scale / ep_shift / act (slots:
  * gdn_fftconv_stats_slots).
  * xf_out (nullable, gdn_fftconv_spectrum_bytes) receives the input and weight spectra, which
- * gdn_fftconv_bwd reuses (weight gradient; data gradient without a second weight transform).  GDN_ERR_UNSUPPORTED for other geometries. */
+ * gdn_fftconv_bwd reuses (weight gradient; data gradient without a second weight transform).
+ * GDN_ERR_UNSUPPORTED for other geometries; transposed (stride-1) layers are forward-only
+ * (gdn_fftconv_bwd_workspace_bytes == 0). */
 size_t gdn_fftconv_fwd_workspace_bytes(const gdn_conv_geom* g);
 size_t gdn_fftconv_spectrum_bytes(const gdn_conv_geom* g);
 int64_t gdn_fftconv_stats_slots(const gdn_conv_geom* g);

@@ -64,15 +64,63 @@ def test_fftconv_matches_cpu_conv(gpu, case):
 def test_fftconv_rejects_other_geometries(gpu):
     from gdn_amd import ops
     from gdn_amd._lib import GdnError
-    for args in [(64, 64, 4, 2, 1), (64, 64, 9, 2, 4), (64, 1, 9, 1, 4), (512, 512, 3, 1, 1), (64, 64, 9, 1, 3)]:
+    for args in [(64, 64, 4, 2, 1), (64, 64, 9, 2, 4), (64, 1, 9, 1, 4), (512, 512, 3, 1, 1), (64, 64, 9, 1, 3)]:   # even k, stride 2, thin, wide, pad != k//2
         op = ops.Conv(*args)
         assert not op.fft_ok(2, 32, 32)
         x = torch.randn(2, 32, 32, args[0], device=gpu)
         w = torch.randn(args[2] ** 2, args[1], args[0], device=gpu)
         with pytest.raises(GdnError):
             op.fft_fwd(x, w)
-    assert not ops.Conv(64, 64, 9, 1, 4, reflect=True).fft_ok(2, 32, 32)
-    assert not ops.Conv(64, 64, 9, 1, 4, transposed=True).fft_ok(2, 32, 32)
+    assert not ops.Conv(64, 64, 9, 1, 4, transposed=True).fft_ok(2, 32, 32, backward=True)     # forward-only
+
+
+REFLECT_CASES = [(128, 64, 7, 2, 40, 70), (256, 128, 5, 1, 26, 52), (64, 64, 3, 2, 9, 31), (64, 128, 9, 1, 24, 48)]
+
+
+@pytest.mark.parametrize("case", REFLECT_CASES, ids=["c%d_%d_k%d_%dx%dx%d" % c for c in REFLECT_CASES])
+def test_fftconv_reflection_pad(gpu, case):
+    """ConvBlock of R's decoder: ReflectionPad2d(k//2) + Conv2d(pad 0) (AE_model_unet.py:60-77)."""
+    from gdn_amd import ops
+    ci, co, k, B, H, W = case
+    p = k // 2
+    g = torch.Generator().manual_seed(77 + k + W)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    gy = torch.randn(B, co, H, W, generator=g)
+    gres = torch.randn(B, ci, H, W, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(F.pad(xr, (p, p, p, p), mode="reflect"), wr)
+    y_ref.backward(gy)
+    op = ops.Conv(ci, co, k, 1, p, reflect=True)
+    assert op.fft_ok(B, H, W, backward=True)
+    xd, wd = nhwc(x).to(gpu), tapmajor(w, False).to(gpu)
+    y, st, xf = op.fft_fwd(xd, wd, stats=True, spectrum=True)
+    close(nchw(y), y_ref, what="fwd")
+    close(st[:, 1].sum(0), (y_ref.detach() ** 2).sum((0, 2, 3)), what="stats sumsq")
+    dw = torch.empty_like(wd)
+    dx = op.fft_bwd(nhwc(gy).to(gpu), wd, (H, W), xf=xf, dw_tap=dw, addsrc=nhwc(gres).to(gpu))
+    close(nchw(dx), xr.grad + gres, what="dgrad")
+    close(dw, tapmajor(wr.grad, False), what="wgrad")
+    close(nchw(op.fft_bwd(nhwc(gy).to(gpu), wd, (H, W))), xr.grad, what="dgrad without saved spectra")
+    close(y, op.fwd(xd, wd), what="fwd vs direct")
+
+
+@pytest.mark.parametrize("case", [(256, 128, 5, 2, 26, 52), (128, 64, 7, 1, 40, 70)], ids=["k5", "k7"])
+def test_fftconv_transposed_stride1_forward(gpu, case):
+    """Legacy AutoEncoder upconv1/2: ConvTranspose2d(stride 1, padding k//2) (AE_model_unet.py:96-261), inference only."""
+    from gdn_amd import ops
+    ci, co, k, B, H, W = case
+    g = torch.Generator().manual_seed(5 + k)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(ci, co, k, k, generator=g) / (ci * k * k) ** 0.5
+    y_ref = F.conv_transpose2d(x, w, None, 1, k // 2)
+    op = ops.Conv(ci, co, k, 1, k // 2, transposed=True)
+    assert op.fft_ok(B, H, W) and not op.fft_ok(B, H, W, backward=True)
+    xd, wd = nhwc(x).to(gpu), tapmajor(w, True).to(gpu)
+    sc, sh = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g)
+    y = op.fft_fwd(xd, wd, affine=(sc.to(gpu), sh.to(gpu)), act=ops.ACT_RELU)
+    close(nchw(y), torch.relu(y_ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), what="convT fwd + affine + relu")
+    close(op.fft_fwd(xd, wd), op.fwd(xd, wd), what="vs direct")
 
 
 def test_fftconv_is_deterministic(gpu):

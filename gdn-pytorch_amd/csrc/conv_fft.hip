@@ -46,10 +46,13 @@ __device__ __constant__ float kSin32[32] = {
     -0.83146961230254546f, -0.70710678118654768f, -0.55557023301960218f, -0.38268343236509039f, -0.19509032201612872f};
 
 // In-register radix-2 decimation-in-time FFT of 32 complex points.  SIGN = -1 forward, +1 inverse (unscaled).
-// The loops are fully unrolled, so every twiddle index is a compile-time constant.
+// The loops are fully unrolled and the twiddles are compile-time literals, so the trivial ones (1, -+i: 46 of the 80
+// butterflies) cost no multiplies and the (1 -+ i)/sqrt2 ones two.
 template <int SIGN>
 __device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
-    // bit reversal (5 bits)
+    constexpr float C32[9] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f,
+                              0.55557023301960229f, 0.38268343236508984f, 0.19509032201612833f, 0.0f};
+    // bit reversal (5 bits): pure register renaming after unrolling
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
         const int j = ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
@@ -66,9 +69,22 @@ __device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
         for (int k = 0; k < 32; k += span) {
 #pragma unroll
             for (int j = 0; j < half; ++j) {
-                const float wr = kCos32[j * tstep], wi = SIGN * kSin32[j * tstep];
+                const int q = j * tstep;                 // twiddle angle 2*pi*q/32, q in [0, 16)
                 const int a = k + j, b = a + half;
-                const float xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                float xr, xi;
+                if (q == 0) {
+                    xr = re[b]; xi = im[b];
+                } else if (q == 8) {                     // w = SIGN * i
+                    xr = -SIGN * im[b]; xi = SIGN * re[b];
+                } else if (q == 4) {                     // (1 + SIGN i) / sqrt2
+                    xr = (re[b] - SIGN * im[b]) * C32[4]; xi = (im[b] + SIGN * re[b]) * C32[4];
+                } else if (q == 12) {                    // (-1 + SIGN i) / sqrt2
+                    xr = (-re[b] - SIGN * im[b]) * C32[4]; xi = (SIGN * re[b] - im[b]) * C32[4];
+                } else {
+                    const float wr = q < 8 ? C32[q] : -C32[16 - q];
+                    const float wi = SIGN * (q < 8 ? C32[8 - q] : C32[q - 8]);
+                    xr = re[b] * wr - im[b] * wi; xi = re[b] * wi + im[b] * wr;
+                }
                 re[b] = re[a] - xr; im[b] = im[a] - xi;
                 re[a] += xr; im[a] += xi;
             }
@@ -438,7 +454,8 @@ __global__ __launch_bounds__(256) void fft_reflect_fold_kernel(const float* __re
 #define FFT_LDS_ELEMS (FFT_N * FFT_NK * FFT_CG)
 
 // forward: patch (halo = 1: rows/cols start at -pad, full 32; halo = 0: the T x T tile, zero padded) -> Xf[bin][tile][C]
-__global__ __launch_bounds__(512, 4) void fft2d_fwd_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ Xf,
+// two waves per SIMD: at four (128 VGPRs) the two 32-point transforms spill 44 dwords per lane and the kernel is 15 % slower
+__global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ Xf,
                                                         FftGeom g, int halo) {
     __shared__ float2 lds[FFT_LDS_ELEMS];
     const int ngrp = g.C / FFT_CG;
@@ -455,12 +472,15 @@ __global__ __launch_bounds__(512, 4) void fft2d_fwd_kernel(const float* __restri
         const int lim = (halo && g.reflect) ? g.pad : 0;
         const bool row_ok = iy >= -lim && iy < g.H + lim && a < nvalid;
         const int iyr = iy < 0 ? -iy : (iy >= g.H ? 2 * g.H - 2 - iy : iy);
-        const float* src = x + ((size_t)(b * g.H + (row_ok ? iyr : 0)) * g.W) * ldx + cg + c;
+        // wave-uniform image base + 32-bit per-lane offsets (one image is far below 2^31 elements): half the address registers
+        const float* img = x + (size_t)b * g.H * g.W * ldx + cg;
+        const int row_off = (row_ok ? iyr : 0) * g.W * ldx + c;
 #pragma unroll
         for (int bb = 0; bb < 32; ++bb) {
             const int ix = ix0 + bb;
             const int ixr = ix < 0 ? -ix : (ix >= g.W ? 2 * g.W - 2 - ix : ix);
-            re[bb] = (row_ok && bb < nvalid && ix >= -lim && ix < g.W + lim) ? src[(size_t)ixr * ldx] : 0.f;
+            const bool ok = row_ok && bb < nvalid && ix >= -lim && ix < g.W + lim;
+            re[bb] = ok ? img[row_off + ixr * ldx] : 0.f;
             im[bb] = 0.f;
         }
         fft32<-1>(re, im);

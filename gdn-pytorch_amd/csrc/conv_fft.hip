@@ -2,11 +2,12 @@
 //
 // A k x k stride-1 "same" convolution costs k*k MACs per (pixel, cin, cout); in the frequency domain it costs one
 // complex MAC (4 real) per (frequency bin, cin, cout) plus transforms that are linear in the tensor size.  With 32x32
-// tiles (overlap-save: T = 33 - k valid outputs per tile side, T = 24 for 9x9, 26 for 7x7) the multiply count drops
-// 81 -> 4*(32/24)^2*(17/32)*2 = 7.6 (9x9) and 49 -> 6.4 (7x7), and -- at fp32 MFMA speed, where the direct kernels
-// already sit at 0.82 of peak -- that is the only lever left that is worth a factor.  Accuracy is not traded: each output
-// sums 64-128 products per bin instead of 5184-6272, and measured against an fp64 convolution the tiled fp32 FFT result is
-// closer than the direct fp32 sum (oracle experiment in DESIGN.md).
+// tiles (overlap-save: T = 33 - k valid outputs per tile side, T = 24 for 9x9, 26 for 7x7) and the 17 x 32 bins a real
+// input needs, the multiply count per output drops 81 -> 544*4/24^2 = 3.8 (9x9) and 49 -> 3.2 (7x7), and -- at fp32
+// MFMA speed, where the direct kernels already sit at 0.7-0.8 of peak -- that is the only lever left that is worth a
+// factor.  Accuracy is not traded: each output sums 64-128 products per bin instead of 5184-6272, and measured against
+// an fp64 convolution the tiled fp32 FFT result is as close as the direct fp32 sum (DESIGN.md 2.4,
+// tests/test_fftconv_model_cpu.py).
 //
 // Pipeline (all tensors NHWC, channels contiguous; spectra are [bin = ky*17+kx][tile][channel] complex):
 //   fft2d_fwd    x  -> Xf     real FFT32 along x then FFT32 along y of each 32x32 patch (zero padding = halo); one

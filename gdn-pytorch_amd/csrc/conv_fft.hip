@@ -27,6 +27,7 @@
 #define FFT_N 32
 #define FFT_NK 17            // kx bins kept of a real row transform
 #define FFT_BINS (FFT_N * FFT_NK)
+static_assert(FFT_BINS % 8 == 0, "bins are dealt to the 8 XCDs");
 
 namespace {
 
@@ -155,7 +156,12 @@ __global__ __launch_bounds__(256) void gemm_bins_kernel(const float* __restrict_
     constexpr int LD = 36, LDB = BKN ? 64 : 36;
     __shared__ __attribute__((aligned(16))) float As[64 * LD], Bs[BKN ? 32 * 64 : 64 * 36];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int bin = blockIdx.z, m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    // XCD-aware order (workgroups go round-robin over the 8 XCDs, each with its own 4 MB L2): XCD j owns the bins
+    // = j (mod 8) and walks them bin-major with the N-tiles of one M-tile back to back, so a bin's weights and every A
+    // tile are fetched from the fabric once instead of once per N-tile / per XCD (PMC: profiles/r01_fft_pmc.txt)
+    const int NT = N / 64, MT = (M + 63) / 64;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int bin = (sq / (NT * MT)) * 8 + xcd, m0 = ((sq / NT) % MT) * 64, n0 = (sq % NT) * 64;
     const float* Ab = A + (size_t)bin * M * K;
     const float* Bb = Bm + (size_t)bin * N * K;
     float* Cb = Cm + (size_t)bin * M * N;
@@ -247,7 +253,11 @@ __global__ __launch_bounds__(256) void gemm_tn_bins_kernel(const float* __restri
     constexpr int LD = 64;
     __shared__ __attribute__((aligned(16))) float As[32 * LD], Bs[32 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wi = wave >> 1, wj = wave & 1;
-    const int bin = blockIdx.z, i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    // XCD-aware order as in gemm_bins_kernel: the (NI/64) x (NJ/64) output tiles of one bin run on one XCD back to back and
+    // share the bin's two operand streams through its L2
+    const int TI = NI / 64, TJ = NJ / 64;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int bin = (sq / (TI * TJ)) * 8 + xcd, i0 = ((sq / TJ) % TI) * 64, j0 = (sq % TJ) * 64;
     const float* Ab = A + (size_t)bin * M * NI + i0;
     const float* Bb = Bm + (size_t)bin * M * NJ + j0;
     f32x16 acc;
@@ -643,7 +653,7 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
     }
     hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.C / FFT_CG * f.M), dim3(512), 0, st, x, ldx, Xf, f, 1);
     launch_weights(f, w, Wf, st);
-    hipLaunchKernelGGL(gemm_bins_kernel<false>, dim3(cdiv(f.M, 64), cdiv(2 * f.N, 64), FFT_BINS), dim3(256), 0, st,
+    hipLaunchKernelGGL(gemm_bins_kernel<false>, dim3(cdiv(f.M, 64) * (2 * f.N / 64) * FFT_BINS), dim3(256), 0, st,
                        (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, 2 * f.N, 2 * f.C);
     hipLaunchKernelGGL(ifft2d_valid_kernel, dim3(f.N / FFT_CG * f.M), dim3(512), 0, st, (const float2*)Yf, y, ldy, addsrc,
                        ld_add, stats, ep_scale, ep_shift, act, f);
@@ -686,7 +696,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.N / FFT_CG * f.M), dim3(512), 0, st, dy, ldy, Df, fd, 0);
     if (dw) {
         float* P = Wf;
-        hipLaunchKernelGGL(gemm_tn_bins_kernel, dim3(2 * f.N / 64, 2 * f.C / 64, FFT_BINS), dim3(256), 0, st,
+        hipLaunchKernelGGL(gemm_tn_bins_kernel, dim3((2 * f.N / 64) * (2 * f.C / 64) * FFT_BINS), dim3(256), 0, st,
                            (const float*)Df, (const float*)xf, P, f.M, 2 * f.N, 2 * f.C);
         const bool wide = f.N * f.C >= 128 * 128;
 #define GDN_TAPS(KK) case KK: \
@@ -701,7 +711,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     if (dx) {
         const float* Wsaved = xf ? (const float*)((const char*)xf + al256((size_t)f.M * FFT_BINS * f.C * 8)) : nullptr;
         if (!Wsaved) launch_weights(f, w, Wf, st);
-        hipLaunchKernelGGL(gemm_bins_kernel<true>, dim3(cdiv(f.M, 64), cdiv(2 * f.C, 64), FFT_BINS), dim3(256), 0, st,
+        hipLaunchKernelGGL(gemm_bins_kernel<true>, dim3(cdiv(f.M, 64) * (2 * f.C / 64) * FFT_BINS), dim3(256), 0, st,
                            (const float*)Df, Wsaved ? Wsaved : (const float*)Wf, (float*)Ef, f.M, 2 * f.C, 2 * f.N);
         // inverse along ky into S, then rows: the tile rows that reach an image row are summed in the frequency domain
         // (measured faster than the single-pass patch kernel with four parity launches, profiles/r01_fftconv_notes.txt)

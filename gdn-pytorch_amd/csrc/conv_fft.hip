@@ -12,13 +12,13 @@
 // Pipeline (all tensors NHWC, channels contiguous; spectra are [bin = ky*17+kx][tile][channel] complex):
 //   fft2d_fwd    x  -> Xf     real FFT32 along x then FFT32 along y of each 32x32 patch (zero padding = halo); one
 //                             workgroup = one tile x 16 channels, the two passes meet in LDS
-//   weights      w  -> Wf     [bin][2*Cout][2*Cin] real: DFT of the k*k taps laid out as the REAL embedding of the complex
-//                             product (conjugated: correlation)
-//   gemm_bins    Yf[bin] = Xf[bin] * Wf[bin]^T      one real GEMM per bin, M = tiles, K = 2*Cin, N = 2*Cout (MFMA)
+//   weights      w  -> Wf     [bin][3][Cout][Cin] real: conj(DFT) of the k*k taps (correlation) as the three planes of the
+//                             3-multiplication complex product (Re, Im - Re, Re + Im)
+//   cgemm_bins   Yf[bin] = Xf[bin] * Wf[bin]^T      one complex GEMM per bin, M = tiles, three real MFMA products
 //   ifft2d_valid Yf -> y      inverse FFT32 along ky, Hermitian inverse along kx, valid T x T outputs, 1/1024 scale,
 //                             affine / ReLU / residual epilogue, BatchNorm sum / sum-of-squares partials (slot = tile)
 // Backward from ONE transform of dy (tile without halo, zero padded = the linear convolution fits the 32-point circle):
-//   data gradient    Ef[bin] = Df[bin] * Wf[bin] (the saved Wf read transposed), inverse along ky, then overlap-add of the
+//   data gradient    Ef[bin] = Df[bin] * conj(Wf[bin]) (the same saved planes, read row-wise), inverse along ky, then overlap-add of the
 //                    32x32 patches at offset -pad: vertical overlaps summed in the frequency domain, horizontal ones by two
 //                    ordered launches (even tiles store, odd tiles add) -- deterministic, no atomics
 //   weight gradient  P[bin] = Df[bin]^T * Xf[bin] (reduction over tiles, MFMA), inverse DFT at the k*k taps only
@@ -101,10 +101,11 @@ struct FftGeom {
     int flip;                                // stride-1 ConvTranspose2d: correlation with the flipped taps
 };
 
-// weights: DFT of the k*k taps at every kept bin, written as the real embedding of conj(DFT(w[n][c])) (correlation):
-//   Wf[bin][2n+p][2c+q]:  row 2n = [wr, wi], row 2n+1 = [-wi, wr]   (out_re = sum x_re*wr + x_im*wi, ...)
-// The forward GEMM reads it as B[n][k] (k contiguous); the data-gradient GEMM reads the SAME buffer as B[k][n] -- the
-// transpose of this embedding is exactly the embedding of the un-conjugated, role-swapped matrix the convolution needs.
+// weights: DFT of the k*k taps at every kept bin.  With Wc = conj(DFT(w[n][c])) (correlation) the three real planes of
+// the 3-multiplication complex product are stored:  Wf[bin][0][n][c] = Re Wc,  [1] = Im Wc - Re Wc,  [2] = Re Wc + Im Wc.
+//   forward        y = x * Wc        :  k1 = P0 (xr + xi), k2 = P1 xr, k3 = P2 xi;   yr = k1 - k3, yi = k1 + k2
+//   data gradient  e = d * conj(Wc)  :  m1 = P0 (dr + di), m2 = P1 di, m3 = P2 dr;   er = m1 + m2, ei = m1 - m3
+// so both directions read the same buffer and the weights are transformed once per step.
 // thread = (n, c) with its K*K taps in registers; block = one ky; column transform first, then the 17 kx bins.
 template <int K>
 __global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restrict__ w /* [k*k][N][C] */, float* __restrict__ Wf,
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restric
             ui[tx] -= v * sn;              // e^{-i phi}
         }
     }
-    const size_t rs = (size_t)2 * C;
+    const size_t plane = (size_t)N * C;
 #pragma unroll
     for (int kx = 0; kx < FFT_NK; ++kx) {
         float wr = 0.f, wi = 0.f;
@@ -139,87 +140,113 @@ __global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restric
             wr += ur[tx] * cs + ui[tx] * sn;       // (ur + i ui)(cs - i sn)
             wi += ui[tx] * cs - ur[tx] * sn;
         }
-        float* dst = Wf + (size_t)(ky * FFT_NK + kx) * (2 * N) * rs + (size_t)(2 * n) * rs + 2 * c;
-        *reinterpret_cast<float2*>(dst) = make_float2(wr, wi);            // conj: -(-wi)
-        *reinterpret_cast<float2*>(dst + rs) = make_float2(-wi, wr);
+        const float wci = -wi;                     // conjugate
+        float* dst = Wf + (size_t)(ky * FFT_NK + kx) * 3 * plane + (size_t)n * C + c;
+        dst[0] = wr;
+        dst[plane] = wci - wr;
+        dst[2 * plane] = wr + wci;
     }
 }
 
-// Per-bin real GEMM  Cm[bin][m][n] = sum_k A[bin][m][k] * B[bin](n, k).  A is M x K, K-contiguous.
-//   BKN = false: B stored [n][k] (k contiguous)  -- forward
-//   BKN = true : B stored [k][n] (n contiguous)  -- data gradient, reading the forward's weight spectrum transposed
-// 64x64 tile, 4 waves of one 32x32 MFMA tile, 32-wide k-steps; A (and the [n][k] B) use the pitch-36 LDS image and
-// b128 fragment reads of conv_igemm_f32 (lane half h owns k = 16h..16h+15 of the slab); the [k][n] B is read row-wise.
-template <bool BKN>
-__global__ __launch_bounds__(256) void gemm_bins_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                        float* __restrict__ Cm, int M, int N, int K) {
-    constexpr int LD = 36, LDB = BKN ? 64 : 36;
-    __shared__ __attribute__((aligned(16))) float As[64 * LD], Bs[BKN ? 32 * 64 : 64 * 36];
+// Per-bin complex GEMM with three real multiplications per complex product (Gauss), fp32 MFMA:
+//   DGRAD = false:  Y[bin][m][n] = sum_c X[bin][m][c] * Wc[bin][n][c]          (planes read as [n][c], c contiguous)
+//   DGRAD = true :  E[bin][m][c] = sum_n D[bin][m][n] * conj(Wc[bin][n][c])    (same planes, read as [n][c] rows, c = output)
+// A (spectrum of x or dy) is [bin][M][Kc] complex, interleaved.  Workgroup tile 64 tiles x 64 complex outputs, 4 waves of
+// 32 x 32, three accumulator tiles each; 16 complex reduction channels per step.  The A image keeps conv_igemm_f32's
+// pitch-36 layout (lane half h owns channels 8h..8h+7 of the slab, one b128 read = two complex values); the [n][c] planes use
+// pitch 20 (b128 = four channels of one plane), the data-gradient planes are read row-wise (b32, conflict-free).
+// Against the 4-multiplication real embedding this is 25 % fewer MFMAs; the rounding cost (k1 - k3 cancels) is 1.4x on
+// the product stage, still below a direct fp32 convolution (tests/test_fftconv_model_cpu.py).
+// Workgroups are dealt XCD-aware: XCD j owns the bins = j (mod 8) and walks them bin-major with the N-tiles of one M-tile
+// back to back, so a bin's weight planes stay in that XCD's L2 and an A tile is fetched from the fabric once.
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void cgemm_bins_kernel(const float* __restrict__ A, const float* __restrict__ Wf,
+                                                         float* __restrict__ Cm, int M, int Nc /* complex outputs */,
+                                                         int Kc /* complex reduction */) {
+    constexpr int LDA = 36, LDB = DGRAD ? 64 : 20;
+    __shared__ __attribute__((aligned(16))) float As[64 * LDA], Bs[3 * (DGRAD ? 16 * 64 : 64 * 20)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    // XCD-aware order (workgroups go round-robin over the 8 XCDs, each with its own 4 MB L2): XCD j owns the bins
-    // = j (mod 8) and walks them bin-major with the N-tiles of one M-tile back to back, so a bin's weights and every A
-    // tile are fetched from the fabric once instead of once per N-tile / per XCD (PMC: profiles/r01_fft_pmc.txt)
-    const int NT = N / 64, MT = (M + 63) / 64;
+    const int NT = Nc / 64, MT = (M + 63) / 64;
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
     const int bin = (sq / (NT * MT)) * 8 + xcd, m0 = ((sq / NT) % MT) * 64, n0 = (sq % NT) * 64;
-    const float* Ab = A + (size_t)bin * M * K;
-    const float* Bb = Bm + (size_t)bin * N * K;
-    float* Cb = Cm + (size_t)bin * M * N;
-    f32x16 acc;
+    const float* Ab = A + (size_t)bin * M * Kc * 2;
+    // planes: forward [p][n = output][c = reduction] (row length Kc); data gradient [p][n = reduction][c = output] (row length Nc)
+    const size_t plane = (size_t)Nc * Kc;
+    const float* Wb = Wf + (size_t)bin * 3 * plane;
+    f32x16 acc1, acc2, acc3;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int lr = tid >> 3, lc = (tid & 7) * 4;          // [row][k] staging: 32 rows per pass, 8 lanes x 16 B per row
-    const int kr = tid >> 4, kc = (tid & 15) * 4;         // [k][n] staging: 16 k-rows per pass, 16 lanes x 16 B per row
-    f32x4 ra[2], rb[2];
-    auto gload = [&](int k0) {
+    for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+    const int ar = tid >> 3, ac = (tid & 7) * 4;          // A: 32 rows per pass, 8 lanes x 16 B = 16 complex per row
+    f32x4 ra[2], rb[3];
+    auto gload = [&](int k0) {                            // k0: first complex reduction index of the slab
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-            const int m = m0 + ps * 32 + lr;
-            ra[ps] = m < M ? *reinterpret_cast<const f32x4*>(Ab + (size_t)m * K + k0 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (BKN) {
-                rb[ps] = *reinterpret_cast<const f32x4*>(Bb + (size_t)(k0 + ps * 16 + kr) * N + n0 + kc);
-            } else {
-                const int n = n0 + ps * 32 + lr;
-                rb[ps] = n < N ? *reinterpret_cast<const f32x4*>(Bb + (size_t)n * K + k0 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            const int m = m0 + ps * 32 + ar;
+            ra[ps] = m < M ? *reinterpret_cast<const f32x4*>(Ab + ((size_t)m * Kc + k0) * 2 + ac) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            if (DGRAD) rb[p] = *reinterpret_cast<const f32x4*>(Wb + p * plane + (size_t)(k0 + (tid >> 4)) * Nc + n0 + (tid & 15) * 4);
+            else rb[p] = *reinterpret_cast<const f32x4*>(Wb + p * plane + (size_t)(n0 + (tid >> 2)) * Kc + k0 + (tid & 3) * 4);
         }
     };
     auto lstore = [&]() {
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            *reinterpret_cast<f32x4*>(&As[(ps * 32 + lr) * LD + lc]) = ra[ps];
-            if (BKN) *reinterpret_cast<f32x4*>(&Bs[(ps * 16 + kr) * LDB + kc]) = rb[ps];
-            else *reinterpret_cast<f32x4*>(&Bs[(ps * 32 + lr) * LDB + lc]) = rb[ps];
+        for (int ps = 0; ps < 2; ++ps) *reinterpret_cast<f32x4*>(&As[(ps * 32 + ar) * LDA + ac]) = ra[ps];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            if (DGRAD) *reinterpret_cast<f32x4*>(&Bs[p * 16 * 64 + (tid >> 4) * 64 + (tid & 15) * 4]) = rb[p];
+            else *reinterpret_cast<f32x4*>(&Bs[p * 64 * 20 + (tid >> 2) * 20 + (tid & 3) * 4]) = rb[p];
         }
     };
-    const int a_off = (wm * 32 + (lane & 31)) * LD + (lane >> 5) * 16;
-    const int b_off = BKN ? (lane >> 5) * 16 * LDB + wn * 32 + (lane & 31) : (wn * 32 + (lane & 31)) * LDB + (lane >> 5) * 16;
+    const int h = lane >> 5, r32 = lane & 31;
+    const int a_off = (wm * 32 + r32) * LDA + h * 16;
+    const int b_off = DGRAD ? (h * 8) * 64 + wn * 32 + r32 : (wn * 32 + r32) * 20 + h * 8;
     gload(0);
     lstore();
     __syncthreads();
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        if (k0 + 32 < K) gload(k0 + 32);
+    for (int k0 = 0; k0 < Kc; k0 += 16) {
+        if (k0 + 16 < Kc) gload(k0 + 16);
+        f32x4 b4[3][2];
+        if (!DGRAD) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[a_off + g4 * 4]);
-            if (BKN) {
+            for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], Bs[b_off + (g4 * 4 + e) * LDB], acc, 0, 0, 0);
-            } else {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[b_off + g4 * 4]);
+                for (int q = 0; q < 2; ++q) b4[p][q] = *reinterpret_cast<const f32x4*>(&Bs[p * 64 * 20 + b_off + q * 4]);
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&As[a_off + g * 4]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float xr = a4[2 * e], xi = a4[2 * e + 1];
+                float b1, b2, b3;
+                if (DGRAD) {
+                    const int row = (2 * g + e) * 64;
+                    b1 = Bs[b_off + row]; b2 = Bs[16 * 64 + b_off + row]; b3 = Bs[2 * 16 * 64 + b_off + row];
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xr + xi, b1, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, b2, acc2, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(xr, b3, acc3, 0, 0, 0);
+                } else {
+                    const int q = g >> 1, idx = 2 * (g & 1) + e;
+                    b1 = b4[0][q][idx]; b2 = b4[1][q][idx]; b3 = b4[2][q][idx];
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xr + xi, b1, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xr, b2, acc2, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, b3, acc3, 0, 0, 0);
+                }
             }
         }
         __syncthreads();
-        if (k0 + 32 < K) { lstore(); __syncthreads(); }
+        if (k0 + 16 < Kc) { lstore(); __syncthreads(); }
     }
-    const int col = n0 + wn * 32 + (lane & 31);
+    float2* Cb = reinterpret_cast<float2*>(Cm) + (size_t)bin * M * Nc;
+    const int col = n0 + wn * 32 + r32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M && col < N) Cb[(size_t)m * N + col] = acc[r];
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < M)
+            Cb[(size_t)m * Nc + col] = DGRAD ? make_float2(acc1[r] + acc2[r], acc1[r] - acc3[r])
+                                             : make_float2(acc1[r] - acc3[r], acc1[r] + acc2[r]);
     }
 }
 
@@ -245,65 +272,69 @@ __global__ __launch_bounds__(256) void ifft_cols_kernel(const float2* __restrict
     }
 }
 
-// Reduction-over-tiles GEMM of the weight gradient:  P[bin][i][j] = sum_m A[bin][m][i] * Bm[bin][m][j]
-// (A = spectrum of dy [M][2N], Bm = spectrum of x [M][2C]; both operands are read as they lie, rows = tiles).
-// 64x64 output tile, 32 tiles of the reduction per step; every MFMA operand is one conflict-free ds_read_b32 row read.
-__global__ __launch_bounds__(256) void gemm_tn_bins_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                           float* __restrict__ P, int M, int NI, int NJ) {
-    constexpr int LD = 64;
-    __shared__ __attribute__((aligned(16))) float As[32 * LD], Bs[32 * LD];
+// Reduction-over-tiles complex GEMM of the weight gradient:  dWf[bin][n][c] = sum_m conj(D[bin][m][n]) * X[bin][m][c]
+// (D = spectrum of dy [M][N], X = spectrum of x [M][C]; both operands are read as they lie, rows = tiles), again with three
+// real products:  g1 = dr (xr + xi), g2 = (dr + di) xr, g3 = (dr - di) xi;  re = g1 - g3, im = g1 - g2.
+// 64 x 64 complex output tile, 16 tiles of the reduction per step; every MFMA operand pair is one conflict-free ds_read_b64.
+__global__ __launch_bounds__(256) void cgemm_tn_bins_kernel(const float* __restrict__ D, const float* __restrict__ X,
+                                                            float* __restrict__ dWf, int M, int N, int C) {
+    constexpr int LD = 128;                              // 64 complex per row
+    __shared__ __attribute__((aligned(16))) float Ds[16 * LD], Xs[16 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wi = wave >> 1, wj = wave & 1;
-    // XCD-aware order as in gemm_bins_kernel: the (NI/64) x (NJ/64) output tiles of one bin run on one XCD back to back and
-    // share the bin's two operand streams through its L2
-    const int TI = NI / 64, TJ = NJ / 64;
+    const int TI = N / 64, TJ = C / 64;
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
     const int bin = (sq / (TI * TJ)) * 8 + xcd, i0 = ((sq / TJ) % TI) * 64, j0 = (sq % TJ) * 64;
-    const float* Ab = A + (size_t)bin * M * NI + i0;
-    const float* Bb = Bm + (size_t)bin * M * NJ + j0;
-    f32x16 acc;
+    const float* Db = D + ((size_t)bin * M * N + i0) * 2;
+    const float* Xb = X + ((size_t)bin * M * C + j0) * 2;
+    f32x16 acc1, acc2, acc3;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int lr = tid >> 4, lc = (tid & 15) * 4;         // 16 rows per pass, 16 lanes x 16 B per row
-    f32x4 ra[2], rb[2];
+    for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+    const int lr = tid >> 5, lc = (tid & 31) * 4;         // 8 rows per pass, 32 lanes x 16 B per 512-byte row
+    f32x4 rd[2], rx[2];
     auto gload = [&](int m0) {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-            const int m = m0 + ps * 16 + lr;
-            ra[ps] = m < M ? *reinterpret_cast<const f32x4*>(Ab + (size_t)m * NI + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rb[ps] = m < M ? *reinterpret_cast<const f32x4*>(Bb + (size_t)m * NJ + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int m = m0 + ps * 8 + lr;
+            rd[ps] = m < M ? *reinterpret_cast<const f32x4*>(Db + (size_t)m * N * 2 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rx[ps] = m < M ? *reinterpret_cast<const f32x4*>(Xb + (size_t)m * C * 2 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto lstore = [&]() {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-            *reinterpret_cast<f32x4*>(&As[(ps * 16 + lr) * LD + lc]) = ra[ps];
-            *reinterpret_cast<f32x4*>(&Bs[(ps * 16 + lr) * LD + lc]) = rb[ps];
+            *reinterpret_cast<f32x4*>(&Ds[(ps * 8 + lr) * LD + lc]) = rd[ps];
+            *reinterpret_cast<f32x4*>(&Xs[(ps * 8 + lr) * LD + lc]) = rx[ps];
         }
     };
-    const int a_off = (lane >> 5) * LD + wi * 32 + (lane & 31);
-    const int b_off = (lane >> 5) * LD + wj * 32 + (lane & 31);
+    const int d_off = (lane >> 5) * LD + (wi * 32 + (lane & 31)) * 2;
+    const int x_off = (lane >> 5) * LD + (wj * 32 + (lane & 31)) * 2;
     gload(0);
     lstore();
     __syncthreads();
-    for (int m0 = 0; m0 < M; m0 += 32) {
-        if (m0 + 32 < M) gload(m0 + 32);
+    for (int m0 = 0; m0 < M; m0 += 16) {
+        if (m0 + 16 < M) gload(m0 + 16);
 #pragma unroll
-        for (int kk = 0; kk < 32; kk += 2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[a_off + kk * LD], Bs[b_off + kk * LD], acc, 0, 0, 0);
+        for (int kk = 0; kk < 16; kk += 2) {
+            const float2 d = *reinterpret_cast<const float2*>(&Ds[d_off + kk * LD]);
+            const float2 x = *reinterpret_cast<const float2*>(&Xs[x_off + kk * LD]);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d.x, x.x + x.y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(d.x + d.y, x.x, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(d.x - d.y, x.y, acc3, 0, 0, 0);
+        }
         __syncthreads();
-        if (m0 + 32 < M) { lstore(); __syncthreads(); }
+        if (m0 + 16 < M) { lstore(); __syncthreads(); }
     }
-    float* Pb = P + (size_t)bin * NI * NJ;
+    float2* Pb = reinterpret_cast<float2*>(dWf) + (size_t)bin * N * C;
     const int col = j0 + wj * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        Pb[(size_t)i * NJ + col] = acc[r];
+        Pb[(size_t)i * C + col] = make_float2(acc1[r] - acc3[r], acc1[r] - acc2[r]);
     }
 }
 
-// Inverse DFT of the weight-gradient spectrum at the k*k taps.  P[bin][2n+p][2c+q] = sum_m D_p X_q;
-// dWf = conj(D) X = (P00 + P11) + i (P01 - P10); Hermitian weights 1 (kx = 0, 16) / 2 over the 17 kept kx bins.
+// Inverse DFT of the weight-gradient spectrum dWf[bin][n][c] (complex) at the k*k taps; Hermitian weights 1 (kx = 0, 16) / 2
+// over the 17 kept kx bins.
 // block = 64 (n, c) pairs x 4 groups of 8 ky (one wave each, so every twiddle index is wave-uniform); the four partial
 // sums meet in LDS in a fixed order.  TYB tap rows per block (1: one tap row per blockIdx.y; reading all taps from one pass
 // over P measured slower -- the twiddle lookups, not the bytes, bound this kernel).
@@ -317,14 +348,11 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
     float acc[TYB * K];
 #pragma unroll
     for (int t = 0; t < TYB * K; ++t) acc[t] = 0.f;
-    const size_t rs = (size_t)2 * C;
     for (int ky = grp * 8; ky < grp * 8 + 8; ++ky) {
         for (int kx = 0; kx < FFT_NK; ++kx) {
-            const float* pb = P + (size_t)(ky * FFT_NK + kx) * (2 * N) * rs + (size_t)(2 * n) * rs + 2 * c;
-            const float2 p0 = *reinterpret_cast<const float2*>(pb);
-            const float2 p1 = *reinterpret_cast<const float2*>(pb + rs);
+            const float2 v = reinterpret_cast<const float2*>(P)[((size_t)(ky * FFT_NK + kx) * N + n) * C + c];
             const float alpha = (kx == 0 || kx == 16) ? 1.f : 2.f;
-            const float fr = (p0.x + p1.y) * alpha, fi = (p0.y - p1.x) * alpha;
+            const float fr = v.x * alpha, fi = v.y * alpha;
 #pragma unroll
             for (int tyl = 0; tyl < TYB; ++tyl) {
                 const int base = ky * (ty0 + tyl);
@@ -359,14 +387,11 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_wide_kernel(const float* _
     float acc[K];
 #pragma unroll
     for (int t = 0; t < K; ++t) acc[t] = 0.f;
-    const size_t rs = (size_t)2 * C;
     for (int ky = 0; ky < FFT_N; ++ky) {
         for (int kx = 0; kx < FFT_NK; ++kx) {
-            const float* pb = P + (size_t)(ky * FFT_NK + kx) * (2 * N) * rs + (size_t)(2 * n) * rs + 2 * c;
-            const float2 p0 = *reinterpret_cast<const float2*>(pb);
-            const float2 p1 = *reinterpret_cast<const float2*>(pb + rs);
+            const float2 v = reinterpret_cast<const float2*>(P)[((size_t)(ky * FFT_NK + kx) * N + n) * C + c];
             const float alpha = (kx == 0 || kx == 16) ? 1.f : 2.f;
-            const float fr = (p0.x + p1.y) * alpha, fi = (p0.y - p1.x) * alpha;
+            const float fr = v.x * alpha, fi = v.y * alpha;
             const int base = ky * ty;
 #pragma unroll
             for (int tx = 0; tx < K; ++tx) {
@@ -600,12 +625,12 @@ inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
 
-// workspace: Xf, Yf (M*544*C / N complex), Wf (544 * 2N * 2C floats)
+// workspace: Xf, Yf (M*544*C / N complex), Wf (544 * 3 * N * C floats)
 extern "C" size_t gdn_fftconv_fwd_workspace_bytes(const gdn_conv_geom* g) {
     FftGeom f;
     if (!fft_geom(g, f)) return 0;
     return al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)f.M * FFT_BINS * f.N * 8) +
-           al256((size_t)FFT_BINS * 4 * f.C * f.N * 4);
+           al256((size_t)FFT_BINS * 3 * f.C * f.N * 4);
 }
 
 extern "C" int64_t gdn_fftconv_stats_slots(const gdn_conv_geom* g) {
@@ -618,7 +643,7 @@ extern "C" int64_t gdn_fftconv_stats_slots(const gdn_conv_geom* g) {
 extern "C" size_t gdn_fftconv_spectrum_bytes(const gdn_conv_geom* g) {
     FftGeom f;
     if (!fft_geom(g, f)) return 0;
-    return al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)FFT_BINS * 4 * f.C * f.N * 4);
+    return al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)FFT_BINS * 3 * f.C * f.N * 4);
 }
 
 namespace {
@@ -653,14 +678,14 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
     }
     hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.C / FFT_CG * f.M), dim3(512), 0, st, x, ldx, Xf, f, 1);
     launch_weights(f, w, Wf, st);
-    hipLaunchKernelGGL(gemm_bins_kernel<false>, dim3(cdiv(f.M, 64) * (2 * f.N / 64) * FFT_BINS), dim3(256), 0, st,
-                       (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, 2 * f.N, 2 * f.C);
+    hipLaunchKernelGGL(cgemm_bins_kernel<false>, dim3(cdiv(f.M, 64) * (f.N / 64) * FFT_BINS), dim3(256), 0, st,
+                       (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, f.N, f.C);
     hipLaunchKernelGGL(ifft2d_valid_kernel, dim3(f.N / FFT_CG * f.M), dim3(512), 0, st, (const float2*)Yf, y, ldy, addsrc,
                        ld_add, stats, ep_scale, ep_shift, act, f);
     return gdn_launch_status();
 }
 
-// workspace: R/S intermediate, Df (spectrum of dy), Ef (spectrum of the dx patches), Wf / P (544 * 2N * 2C floats)
+// workspace: R/S intermediate, Df (spectrum of dy), Ef (spectrum of the dx patches), Wf / dWf (544 * 3 * N * C floats)
 extern "C" size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     FftGeom f;
     if (!fft_geom(g, f)) return 0;
@@ -668,7 +693,7 @@ extern "C" size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     const size_t cm = f.C > f.N ? f.C : f.N;
     const size_t padded = f.reflect ? al256((size_t)f.B * (f.H + 2 * f.pad) * (f.W + 2 * f.pad) * f.C * 4) : 0;
     return al256((size_t)f.M * FFT_N * FFT_NK * cm * 8) + al256((size_t)f.M * FFT_BINS * f.N * 8) +
-           al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)FFT_BINS * 4 * f.C * f.N * 4) + padded;
+           al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)FFT_BINS * 3 * f.C * f.N * 4) + padded;
 }
 
 extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w, const void* xf,
@@ -686,7 +711,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     float2* R = (float2*)p; p += al256((size_t)f.M * FFT_N * FFT_NK * cm * 8);
     float2* Df = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.N * 8);
     float2* Ef = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.C * 8);
-    float* Wf = (float*)p; p += al256((size_t)FFT_BINS * 4 * f.C * f.N * 4);   // weight-gradient products P, or the weight spectrum when the forward saved none
+    float* Wf = (float*)p; p += al256((size_t)FFT_BINS * 3 * f.C * f.N * 4);   // weight-gradient products P, or the weight spectrum when the forward saved none
     float* dxp = (float*)p;          // reflection layers: gradient over the padded domain
     auto blocks = [](int64_t n) { const int64_t b = cdiv64(n, 256); return (unsigned)(b < 65536 * 8 ? b : 65536 * 8); };
     // spectrum of the dy tiles (no halo: rows / columns >= T are the zero padding of the linear convolution)
@@ -696,8 +721,8 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.N / FFT_CG * f.M), dim3(512), 0, st, dy, ldy, Df, fd, 0);
     if (dw) {
         float* P = Wf;
-        hipLaunchKernelGGL(gemm_tn_bins_kernel, dim3((2 * f.N / 64) * (2 * f.C / 64) * FFT_BINS), dim3(256), 0, st,
-                           (const float*)Df, (const float*)xf, P, f.M, 2 * f.N, 2 * f.C);
+        hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * FFT_BINS), dim3(256), 0, st,
+                           (const float*)Df, (const float*)xf, P, f.M, f.N, f.C);
         const bool wide = f.N * f.C >= 128 * 128;
 #define GDN_TAPS(KK) case KK: \
             if (wide) hipLaunchKernelGGL(fft_wgrad_taps_wide_kernel<KK>, dim3(cdiv(f.N * f.C, 256), KK), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
@@ -711,8 +736,8 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     if (dx) {
         const float* Wsaved = xf ? (const float*)((const char*)xf + al256((size_t)f.M * FFT_BINS * f.C * 8)) : nullptr;
         if (!Wsaved) launch_weights(f, w, Wf, st);
-        hipLaunchKernelGGL(gemm_bins_kernel<true>, dim3(cdiv(f.M, 64) * (2 * f.C / 64) * FFT_BINS), dim3(256), 0, st,
-                           (const float*)Df, Wsaved ? Wsaved : (const float*)Wf, (float*)Ef, f.M, 2 * f.C, 2 * f.N);
+        hipLaunchKernelGGL(cgemm_bins_kernel<true>, dim3(cdiv(f.M, 64) * (f.C / 64) * FFT_BINS), dim3(256), 0, st,
+                           (const float*)Df, Wsaved ? Wsaved : (const float*)Wf, (float*)Ef, f.M, f.C, f.N);
         // inverse along ky into S, then rows: the tile rows that reach an image row are summed in the frequency domain
         // (measured faster than the single-pass patch kernel with four parity launches, profiles/r01_fftconv_notes.txt)
         hipLaunchKernelGGL(ifft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.C)), dim3(256), 0, st, (const float2*)Ef, R, f.C, f.M, FFT_N);

@@ -494,8 +494,13 @@ __global__ __launch_bounds__(256) void fft_reflect_fold_kernel(const float* __re
 __global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ Xf,
                                                         FftGeom g, int halo) {
     __shared__ float2 lds[FFT_LDS_ELEMS];
-    const int ngrp = g.C / FFT_CG;
-    const int tid = threadIdx.x, c = tid & 15, cg = (blockIdx.x % ngrp) * FFT_CG, t = blockIdx.x / ngrp;
+    // XCD-aware order: XCD j (= blockIdx & 7) owns the contiguous tile range [j, j+1) * ceil(M/8) and runs the channel
+    // groups of one tile back to back, so the half cache lines the groups share and the halo rows / columns neighbouring
+    // tiles share are served by that XCD's L2 instead of being fetched once per XCD
+    const int ngrp = g.C / FFT_CG, tpx = (g.M + 7) / 8;
+    const int tid = threadIdx.x, c = tid & 15, cg = ((blockIdx.x >> 3) % ngrp) * FFT_CG;
+    const int t = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3) / ngrp;
+    if (t >= g.M) return;
     const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
     float re[32], im[32];
     {
@@ -567,8 +572,10 @@ __global__ __launch_bounds__(512, 4) void ifft2d_valid_kernel(const float2* __re
                                                            float* __restrict__ stats, const float* __restrict__ ep_scale,
                                                            const float* __restrict__ ep_shift, int act, FftGeom g) {
     __shared__ float2 lds[FFT_LDS_ELEMS];
-    const int ngrp = g.N / FFT_CG;
-    const int tid = threadIdx.x, c = tid & 15, cg = (blockIdx.x % ngrp) * FFT_CG, t = blockIdx.x / ngrp, T = g.T;
+    const int ngrp = g.N / FFT_CG, tpx = (g.M + 7) / 8;          // XCD-aware order as in fft2d_fwd_kernel
+    const int tid = threadIdx.x, c = tid & 15, cg = ((blockIdx.x >> 3) % ngrp) * FFT_CG, T = g.T;
+    const int t = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3) / ngrp;
+    if (t >= g.M) return;
     const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
     float re[32], im[32];
     ifft2d_cols_to_lds(Yf, lds, g.N, g.M, t, cg, re, im);
@@ -676,11 +683,11 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
         Xf = (float2*)xf_out;
         Wf = (float*)((char*)xf_out + al256((size_t)f.M * FFT_BINS * f.C * 8));
     }
-    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.C / FFT_CG * f.M), dim3(512), 0, st, x, ldx, Xf, f, 1);
+    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.C / FFT_CG * 8 * cdiv(f.M, 8)), dim3(512), 0, st, x, ldx, Xf, f, 1);
     launch_weights(f, w, Wf, st);
     hipLaunchKernelGGL(cgemm_bins_kernel<false>, dim3(cdiv(f.M, 64) * (f.N / 64) * FFT_BINS), dim3(256), 0, st,
                        (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, f.N, f.C);
-    hipLaunchKernelGGL(ifft2d_valid_kernel, dim3(f.N / FFT_CG * f.M), dim3(512), 0, st, (const float2*)Yf, y, ldy, addsrc,
+    hipLaunchKernelGGL(ifft2d_valid_kernel, dim3(f.N / FFT_CG * 8 * cdiv(f.M, 8)), dim3(512), 0, st, (const float2*)Yf, y, ldy, addsrc,
                        ld_add, stats, ep_scale, ep_shift, act, f);
     return gdn_launch_status();
 }
@@ -718,7 +725,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     FftGeom fd = f;
     fd.C = f.N;
     fd.reflect = 0;
-    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.N / FFT_CG * f.M), dim3(512), 0, st, dy, ldy, Df, fd, 0);
+    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.N / FFT_CG * 8 * cdiv(f.M, 8)), dim3(512), 0, st, dy, ldy, Df, fd, 0);
     if (dw) {
         float* P = Wf;
         hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * FFT_BINS), dim3(256), 0, st,

@@ -58,6 +58,44 @@ def conv3x3_roofline(dev, B, level, reps=20):
     return ms, flop
 
 
+def fftconv_roofline(dev, B, reps=10):
+    """Frequency-domain 9x9 64->64 layer at level 0 (128x416): forward (+BN partials, spectra kept) and backward
+    (dgrad + wgrad) against the bytes the decomposition has to move (spectra written once and read once)."""
+    from gdn_amd import ops
+    H, W, C, k = 128, 416, 64, 9
+    op = ops.Conv(C, C, k, 1, k // 2)
+    x = torch.randn(B, H, W, C, device=dev)
+    w = torch.randn(k * k, C, C, device=dev) * 0.02
+    gy = torch.randn(B, H, W, C, device=dev)
+    dw = torch.empty_like(w)
+    y, st, xf = op.fft_fwd(x, w, stats=True, spectrum=True)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ms_f = timed(lambda: op.fft_fwd(x, w, stats=True, spectrum=True))
+    ms_b = timed(lambda: op.fft_bwd(gy, w, (H, W), xf=xf, dw_tap=dw))
+    T = 33 - k
+    tiles = B * (-(-H // T)) * (-(-W // T))
+    spec = tiles * 544 * C * 8                         # one spectrum, bytes
+    act = B * H * W * C * 4
+    by_f = act + 4 * spec + act                        # x -> Xf -> GEMM -> Yf -> y
+    by_b = 2 * act + 8 * spec                          # dy -> Df | Df -> Ef | Ef -> S | S -> dx | wgrad reads Df + Xf
+    return {"layer": "9x9 s1 64->64, B=%d 128x416 (level 0), 32x32 tiles" % B, "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+            "fwd_ms": round(ms_f, 4), "fwd_bytes": by_f, "fwd_achieved": round(by_f / ms_f / 1e6, 1),
+            "bwd_ms": round(ms_b, 4), "bwd_bytes": by_b, "bwd_achieved": round(by_b / ms_b / 1e6, 1),
+            "frac": round(by_f / ms_f / 1e6 / 8000.0, 4),
+            "direct_equiv_tflops_fwd": round(2.0 * B * H * W * k * k * C * C / ms_f / 1e9, 1)}
+
+
 def pmc_traffic():
     """L2->fabric bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None if the summary is absent."""
@@ -288,6 +326,8 @@ def main():
                                 "frac": round(fl4 / (ms4 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                 "gflop_per_launch": round(fl4 / 1e9, 2), "ms_per_launch": round(ms4, 4)},
             }
+            # second-largest share of the step: the frequency-domain layers, HBM-bound
+            rec["roofline_fftconv"] = fftconv_roofline(dev, B)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec), flush=True)

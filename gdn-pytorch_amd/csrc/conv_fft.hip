@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restric
 // Workgroups are dealt XCD-aware: XCD j owns the bins = j (mod 8) and walks them bin-major with the N-tiles of one M-tile
 // back to back, so a bin's weight planes stay in that XCD's L2 and an A tile is fetched from the fabric once.
 template <bool DGRAD>
-__global__ __launch_bounds__(256) void cgemm_bins_kernel(const float* __restrict__ A, const float* __restrict__ Wf,
+__global__ __launch_bounds__(256, 4) void cgemm_bins_kernel(const float* __restrict__ A, const float* __restrict__ Wf,
                                                          float* __restrict__ Cm, int M, int Nc /* complex outputs */,
                                                          int Kc /* complex reduction */) {
     constexpr int LDA = 36, LDB = DGRAD ? 64 : 20;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void ifft_cols_kernel(const float2* __restrict
 // (D = spectrum of dy [M][N], X = spectrum of x [M][C]; both operands are read as they lie, rows = tiles), again with three
 // real products:  g1 = dr (xr + xi), g2 = (dr + di) xr, g3 = (dr - di) xi;  re = g1 - g3, im = g1 - g2.
 // 64 x 64 complex output tile, 16 tiles of the reduction per step; every MFMA operand pair is one conflict-free ds_read_b64.
-__global__ __launch_bounds__(256) void cgemm_tn_bins_kernel(const float* __restrict__ D, const float* __restrict__ X,
+__global__ __launch_bounds__(256, 4) void cgemm_tn_bins_kernel(const float* __restrict__ D, const float* __restrict__ X,
                                                             float* __restrict__ dWf, int M, int N, int C) {
     constexpr int LD = 128;                              // 64 complex per row
     __shared__ __attribute__((aligned(16))) float Ds[16 * LD], Xs[16 * LD];
@@ -726,19 +726,37 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     fd.C = f.N;
     fd.reflect = 0;
     hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.N / FFT_CG * 8 * cdiv(f.M, 8)), dim3(512), 0, st, dy, ldy, Df, fd, 0);
+    // The weight-gradient chain (reduction GEMM + tap transform) and the data-gradient chain only share Df.  Each is
+    // HBM-latency-bound at ~3.3 of the ~6.3 TB/s a pure copy reaches, so with both wanted the first runs on a side stream
+    // next to the second (fork after the dy transform, join before returning: the workspace is free again for the caller).
+    static hipStream_t side = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    static const bool overlap_ok = getenv("GDN_FFT_NO_OVERLAP") == nullptr;
+    hipStream_t sw = st;
+    if (dw && dx && overlap_ok) {
+        if (!side) {
+            if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
+                return GDN_ERR_LAUNCH;
+        }
+        if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return GDN_ERR_LAUNCH;
+        sw = side;
+    }
     if (dw) {
         float* P = Wf;
-        hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * FFT_BINS), dim3(256), 0, st,
+        hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * FFT_BINS), dim3(256), 0, sw,
                            (const float*)Df, (const float*)xf, P, f.M, f.N, f.C);
         const bool wide = f.N * f.C >= 128 * 128;
 #define GDN_TAPS(KK) case KK: \
-            if (wide) hipLaunchKernelGGL(fft_wgrad_taps_wide_kernel<KK>, dim3(cdiv(f.N * f.C, 256), KK), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
-            else hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 1>), dim3(f.N * f.C / 64, KK), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
+            if (wide) hipLaunchKernelGGL(fft_wgrad_taps_wide_kernel<KK>, dim3(cdiv(f.N * f.C, 256), KK), dim3(256), 0, sw, (const float*)P, dw, f.N, f.C); \
+            else hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 1>), dim3(f.N * f.C / 64, KK), dim3(256), 0, sw, (const float*)P, dw, f.N, f.C); \
             break;
         switch (f.k) {
             GDN_TAPS(3) GDN_TAPS(5) GDN_TAPS(7) GDN_TAPS(9)
         }
 #undef GDN_TAPS
+        if (sw != st && hipEventRecord(ev_join, sw) != hipSuccess) return GDN_ERR_LAUNCH;
     }
     if (dx) {
         const float* Wsaved = xf ? (const float*)((const char*)xf + al256((size_t)f.M * FFT_BINS * f.C * 8)) : nullptr;
@@ -763,5 +781,6 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
             hipLaunchKernelGGL(fft_reflect_fold_kernel, dim3(blocks((int64_t)f.B * f.H * f.W * (f.C / 4))), dim3(256), 0, st,
                                (const float*)dxp, dx, ldx, addsrc, ld_add, f.B, f.H, f.W, f.C, f.pad);
     }
+    if (sw != st && hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return GDN_ERR_LAUNCH;
     return gdn_launch_status();
 }

@@ -18,7 +18,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         print(c, "no counter file"); continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(files[0])):
-        agg[(r["Kernel_Name"].split("(")[0][:60], r["Grid_Size"])].append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        agg[(name.split("(")[0][:40], r["Grid_Size"])].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         res[k][c] = sum(v) / len(v)
 print("kernel | grid | FETCH_SIZE KB (raw; x2 on gfx950 per the guide) | WRITE_SIZE KB")

@@ -157,3 +157,37 @@ def test_engine_fft_switch_matches_direct(gpu, monkeypatch):
     close(outs[5][1], outs[0][1], what="block dx")
     for a, b in zip(outs[5][2], outs[0][2]):
         close(a, b, what="block param grad")
+
+
+FULL_SIZE = [(64, 9, 128, 416), (128, 7, 64, 208), (256, 5, 32, 104)]      # G's residual levels 0-2 at BASELINE configs[1]
+
+
+@pytest.mark.parametrize("C,k,H,W", FULL_SIZE, ids=["k%d" % c[1] for c in FULL_SIZE])
+def test_fftconv_full_size_adjoint_and_direct(gpu, C, k, H, W):
+    """BASELINE batch 20 at 128x416: too large for the CPU oracle in a test, so use size-independent properties --
+    the three bilinear identities <conv(x, w), g> = <x, dgrad(g, w)> = <w, wgrad(x, g)> (each side accumulated in fp64),
+    linearity in x, and agreement with the direct MFMA kernels (themselves pinned to the oracle at small sizes)."""
+    from gdn_amd import ops
+    B = 20
+    gen = torch.Generator(device=gpu).manual_seed(k)
+    x = torch.randn(B, H, W, C, device=gpu, generator=gen)
+    x2 = torch.randn(B, H, W, C, device=gpu, generator=gen)
+    w = torch.randn(k * k, C, C, device=gpu, generator=gen) / (C * k * k) ** 0.5
+    g = torch.randn(B, H, W, C, device=gpu, generator=gen)
+    op = ops.Conv(C, C, k, 1, k // 2)
+    y, xf = op.fft_fwd(x, w, spectrum=True)
+    dw = torch.empty_like(w)
+    dx = op.fft_bwd(g, w, (H, W), xf=xf, dw_tap=dw)
+    a = float((y.double() * g.double()).sum())
+    b = float((x.double() * dx.double()).sum())
+    c = float((w.double() * dw.double()).sum())
+    scale = float(y.double().norm() * g.double().norm())
+    assert abs(a - b) <= 2e-6 * scale and abs(a - c) <= 2e-6 * scale, (a, b, c, scale)
+    y2 = op.fft_fwd(x2, w)
+    y12 = op.fft_fwd(x + 2.0 * x2, w)
+    close(y12, y + 2.0 * y2, rtol=1e-4, atol_scale=1e-5, what="linearity")
+    close(y, op.fwd(x, w), rtol=1e-4, atol_scale=1e-5, what="fwd vs direct, full size")
+    close(dx, op.dgrad(g, ops.transpose_taps(w), (H, W)), rtol=1e-4, atol_scale=1e-5, what="dgrad vs direct, full size")
+    dw_d = torch.empty_like(w)
+    op.wgrad(x, g, dw_d)
+    close(dw, dw_d, rtol=1e-4, atol_scale=2e-5, what="wgrad vs direct, full size")

@@ -333,75 +333,59 @@ __global__ __launch_bounds__(256, 4) void cgemm_tn_bins_kernel(const float* __re
     }
 }
 
-// Inverse DFT of the weight-gradient spectrum dWf[bin][n][c] (complex) at the k*k taps; Hermitian weights 1 (kx = 0, 16) / 2
-// over the 17 kept kx bins.
-// block = 64 (n, c) pairs x 4 groups of 8 ky (one wave each, so every twiddle index is wave-uniform); the four partial
-// sums meet in LDS in a fixed order.  TYB tap rows per block (1: one tap row per blockIdx.y; reading all taps from one pass
-// over P measured slower -- the twiddle lookups, not the bytes, bound this kernel).
-template <int K, int TYB>
+// Inverse DFT of the weight-gradient spectrum dWf[bin][n][c] (complex) at the k*k taps only, separably:
+//   g[ty] = sum_ky F[ky][kx] e^{+i 2 pi ky ty / 32}            (K complex values per kx)
+//   dw[ty][tx] += alpha_kx Re( g[ty] e^{+i 2 pi kx tx / 32} )   (Hermitian weights 1 for kx = 0, 16, else 2)
+// so the spectrum is read ONCE and a thread does 32*K + K*K complex MACs per kx instead of 32*K*K, with 32*K + K twiddle
+// lookups instead of 32*K*K (the lookups, wave-uniform scalar loads, bounded the earlier per-tap-row kernels).
+// block = 64 (n, c) pairs x 4 groups of kx (one wave each: every twiddle index is wave-uniform); the four partial tap sets
+// meet in LDS in a fixed order.
+template <int K>
 __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C) {
-    __shared__ float red[3][TYB * K][64];
-    const int ty0 = blockIdx.y * TYB;
+    __shared__ float red[3][K * K][64];
     const int pl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + pl;             // N*C is a multiple of 64
     const int c = i % C, n = i / C;
-    float acc[TYB * K];
+    const int kx0 = grp == 0 ? 0 : 1 + grp * 4, kx1 = grp == 3 ? FFT_NK : 5 + grp * 4;     // 0-4, 5-8, 9-12, 13-16
+    float acc[K * K];
 #pragma unroll
-    for (int t = 0; t < TYB * K; ++t) acc[t] = 0.f;
-    for (int ky = grp * 8; ky < grp * 8 + 8; ++ky) {
-        for (int kx = 0; kx < FFT_NK; ++kx) {
-            const float2 v = reinterpret_cast<const float2*>(P)[((size_t)(ky * FFT_NK + kx) * N + n) * C + c];
-            const float alpha = (kx == 0 || kx == 16) ? 1.f : 2.f;
-            const float fr = v.x * alpha, fi = v.y * alpha;
+    for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
+    const float2* F = reinterpret_cast<const float2*>(P) + (size_t)n * C + c;
+    const size_t bs = (size_t)N * C;
+    for (int kx = kx0; kx < kx1; ++kx) {
+        float gr[K], gi[K];
 #pragma unroll
-            for (int tyl = 0; tyl < TYB; ++tyl) {
-                const int base = ky * (ty0 + tyl);
+        for (int ty = 0; ty < K; ++ty) { gr[ty] = 0.f; gi[ty] = 0.f; }
+#pragma unroll 8
+        for (int ky = 0; ky < FFT_N; ++ky) {
+            const float2 v = F[(size_t)(ky * FFT_NK + kx) * bs];
 #pragma unroll
-                for (int tx = 0; tx < K; ++tx) {
-                    const int ph = (base + kx * tx) & 31;
-                    acc[tyl * K + tx] += fr * kCos32[ph] - fi * kSin32[ph];
-                }
+            for (int ty = 0; ty < K; ++ty) {
+                const int ph = (ky * ty) & 31;
+                const float cs = kCos32[ph], sn = kSin32[ph];
+                gr[ty] += v.x * cs - v.y * sn;
+                gi[ty] += v.x * sn + v.y * cs;
             }
+        }
+        const float alpha = (kx == 0 || kx == 16) ? 1.f : 2.f;
+#pragma unroll
+        for (int tx = 0; tx < K; ++tx) {
+            const int ph = (kx * tx) & 31;
+            const float cs = kCos32[ph] * alpha, sn = kSin32[ph] * alpha;
+#pragma unroll
+            for (int ty = 0; ty < K; ++ty) acc[ty * K + tx] += gr[ty] * cs - gi[ty] * sn;
         }
     }
     if (grp > 0) {
 #pragma unroll
-        for (int t = 0; t < TYB * K; ++t) red[grp - 1][t][pl] = acc[t];
+        for (int t = 0; t < K * K; ++t) red[grp - 1][t][pl] = acc[t];
     }
     __syncthreads();
     if (grp == 0) {
 #pragma unroll
-        for (int t = 0; t < TYB * K; ++t)
-            dw[((size_t)(ty0 * K + t) * N + n) * C + c] = (((acc[t] + red[0][t][pl]) + red[1][t][pl]) + red[2][t][pl]) * (1.0f / 1024.0f);
+        for (int t = 0; t < K * K; ++t)
+            dw[((size_t)t * N + n) * C + c] = (((acc[t] + red[0][t][pl]) + red[1][t][pl]) + red[2][t][pl]) * (1.0f / 1024.0f);
     }
-}
-
-// Wide layers (128+ channels): thread = (n, c), one tap row per blockIdx.y, all 544 bins -- enough threads already, and the
-// plain streaming order measured faster there than the grouped kernel above.
-template <int K>
-__global__ __launch_bounds__(256) void fft_wgrad_taps_wide_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C) {
-    const int ty = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N * C) return;
-    const int c = i % C, n = i / C;
-    float acc[K];
-#pragma unroll
-    for (int t = 0; t < K; ++t) acc[t] = 0.f;
-    for (int ky = 0; ky < FFT_N; ++ky) {
-        for (int kx = 0; kx < FFT_NK; ++kx) {
-            const float2 v = reinterpret_cast<const float2*>(P)[((size_t)(ky * FFT_NK + kx) * N + n) * C + c];
-            const float alpha = (kx == 0 || kx == 16) ? 1.f : 2.f;
-            const float fr = v.x * alpha, fi = v.y * alpha;
-            const int base = ky * ty;
-#pragma unroll
-            for (int tx = 0; tx < K; ++tx) {
-                const int ph = (base + kx * tx) & 31;
-                acc[tx] += fr * kCos32[ph] - fi * kSin32[ph];
-            }
-        }
-    }
-#pragma unroll
-    for (int tx = 0; tx < K; ++tx) dw[((size_t)(ty * K + tx) * N + n) * C + c] = acc[tx] * (1.0f / 1024.0f);
 }
 
 // Data gradient, overlap-add: tile (ty, tx) of dy contributes a full 32x32 patch of dx at offset -pad.  The (at most two)
@@ -747,10 +731,8 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         float* P = Wf;
         hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * FFT_BINS), dim3(256), 0, sw,
                            (const float*)Df, (const float*)xf, P, f.M, f.N, f.C);
-        const bool wide = f.N * f.C >= 128 * 128;
 #define GDN_TAPS(KK) case KK: \
-            if (wide) hipLaunchKernelGGL(fft_wgrad_taps_wide_kernel<KK>, dim3(cdiv(f.N * f.C, 256), KK), dim3(256), 0, sw, (const float*)P, dw, f.N, f.C); \
-            else hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 1>), dim3(f.N * f.C / 64, KK), dim3(256), 0, sw, (const float*)P, dw, f.N, f.C); \
+            hipLaunchKernelGGL(fft_wgrad_taps_kernel<KK>, dim3(f.N * f.C / 64), dim3(256), 0, sw, (const float*)P, dw, f.N, f.C); \
             break;
         switch (f.k) {
             GDN_TAPS(3) GDN_TAPS(5) GDN_TAPS(7) GDN_TAPS(9)

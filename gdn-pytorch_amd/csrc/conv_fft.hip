@@ -28,6 +28,11 @@
 #define FFT_NK 17            // kx bins kept of a real row transform
 #define FFT_BINS (FFT_N * FFT_NK)
 static_assert(FFT_BINS % 8 == 0, "bins are dealt to the 8 XCDs");
+// Index arithmetic is kept off the vector ALU (the transform kernels are VALU-bound; 64-bit divisions and per-element
+// 64-bit multiplies were most of their instructions): grids carry (channel chunk, tile), row and image instead of a
+// flat index, and every strided access walks a running pointer.  GDN_KEEP pins a running value so the unrolled loops do
+// not fold it back into multiplies.
+#define GDN_KEEP(v) asm volatile("" : "+v"(v))
 
 namespace {
 
@@ -250,25 +255,29 @@ __global__ __launch_bounds__(256, 4) void cgemm_bins_kernel(const float* __restr
     }
 }
 
-// icols: thread = (tile, kx, channel n): inverse FFT32 along ky, rows u < nrows kept
-__global__ __launch_bounds__(256) void ifft_cols_kernel(const float2* __restrict__ Yf, float2* __restrict__ S, int C, int M, int nrows) {
-    const int64_t total = (int64_t)M * FFT_NK * C;
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        int64_t r = i / C;
-        const int kx = (int)(r % FFT_NK);
-        const int t = (int)(r / FFT_NK);
-        float re[32], im[32];
+// icols: thread = (tile, kx, channel n): inverse FFT32 along ky, rows u < nrows kept.
+// grid: x = (tile / 4) * (C / 64) + channel chunk, y = kx; block = 4 tiles x 64 channels
+__global__ __launch_bounds__(256) void ifft_cols_kernel(const float2* __restrict__ Yf, float2* __restrict__ S, int C, int M, int nrows,
+                                                        int cq_shift) {
+    const int t = (blockIdx.x >> cq_shift) * 4 + (threadIdx.x >> 6);
+    if (t >= M) return;
+    const int c = (blockIdx.x & ((1 << cq_shift) - 1)) * 64 + (threadIdx.x & 63), kx = blockIdx.y;
+    float re[32], im[32];
+    const float2* src = Yf + ((size_t)kx * M + t) * C + c;
+    const size_t sk = (size_t)FFT_NK * M * C;
 #pragma unroll
-        for (int ky = 0; ky < 32; ++ky) {
-            const float2 v = Yf[((size_t)(ky * FFT_NK + kx) * M + t) * C + c];
-            re[ky] = v.x; im[ky] = v.y;
-        }
-        fft32<1>(re, im);
-        float2* dst = S + (((size_t)t * FFT_N) * FFT_NK + kx) * C + c;
+    for (int ky = 0; ky < 32; ++ky) {
+        const float2 v = *src;
+        re[ky] = v.x; im[ky] = v.y;
+        src += sk; GDN_KEEP(src);
+    }
+    fft32<1>(re, im);
+    float2* dst = S + (((size_t)t * FFT_N) * FFT_NK + kx) * C + c;
+    const int su = FFT_NK * C;
 #pragma unroll
-        for (int u = 0; u < 32; ++u)
-            if (u < nrows) dst[(size_t)u * FFT_NK * C] = make_float2(re[u], im[u]);
+    for (int u = 0; u < 32; ++u) {
+        if (u < nrows) *dst = make_float2(re[u], im[u]);
+        dst += su; GDN_KEEP(dst);
     }
 }
 
@@ -393,51 +402,53 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
 // even and odd tiles are written by two launches (parity): the first writer of a column stores (+ addsrc), the second adds.
 __global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __restrict__ S, float* __restrict__ dx, int lddx,
                                                                 const float* __restrict__ addsrc, int ld_add, FftGeom g,
-                                                                int parity, int Ho, int Wo, int off) {
+                                                                int parity, int Ho, int Wo, int off, int cq_shift) {
     // output image Ho x Wo; patch row j of tile row ty lands on output row ty*T - off + j  (off = pad for a zero-padded
     // layer: dx itself; off = 0 for a reflection-padded one: the padded-domain gradient, folded afterwards)
+    // grid: x = (tile-of-this-parity / 4) * (C / 64) + channel chunk, y = output row, z = image; block = 4 tiles x 64 channels
     const int C = g.C, T = g.T;
     const int ntx = (g.tiles_x + 1 - parity) / 2;         // tiles of this parity per row
-    const int64_t total = (int64_t)g.B * Ho * ntx * C;
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        int64_t r = i / C;
-        const int tx = (int)(r % ntx) * 2 + parity;
-        r /= ntx;
-        const int iy = (int)(r % Ho), b = (int)(r / Ho);
-        const int q = iy + off;
-        const int ty_a = q / T, j_a = q - ty_a * T;
-        float re[32], im[32];
+    const int txl = (blockIdx.x >> cq_shift) * 4 + (threadIdx.x >> 6);
+    if (txl >= ntx) return;
+    const int c = (blockIdx.x & ((1 << cq_shift) - 1)) * 64 + (threadIdx.x & 63);
+    const int tx = txl * 2 + parity, iy = blockIdx.y, b = blockIdx.z;
+    const int q = iy + off;
+    const int ty_a = q / T, j_a = q - ty_a * T;
+    float re[32], im[32];
 #pragma unroll
-        for (int kx = 0; kx < FFT_NK; ++kx) { re[kx] = 0.f; im[kx] = 0.f; }
-        if (ty_a < g.tiles_y) {
-            const int t = (b * g.tiles_y + ty_a) * g.tiles_x + tx;
-            const float2* src = S + (((size_t)t * FFT_N + j_a) * FFT_NK) * C + c;
+    for (int kx = 0; kx < FFT_NK; ++kx) { re[kx] = 0.f; im[kx] = 0.f; }
+    if (ty_a < g.tiles_y) {
+        const int t = (b * g.tiles_y + ty_a) * g.tiles_x + tx;
+        const float2* src = S + (((size_t)t * FFT_N + j_a) * FFT_NK) * C + c;
 #pragma unroll
-            for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = src[(size_t)kx * C]; re[kx] = v.x; im[kx] = v.y; }
-        }
-        if (ty_a >= 1 && j_a + T < FFT_N) {
-            const int t = (b * g.tiles_y + ty_a - 1) * g.tiles_x + tx;
-            const float2* src = S + (((size_t)t * FFT_N + j_a + T) * FFT_NK) * C + c;
+        for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = *src; re[kx] = v.x; im[kx] = v.y; src += C; GDN_KEEP(src); }
+    }
+    if (ty_a >= 1 && j_a + T < FFT_N) {
+        const int t = (b * g.tiles_y + ty_a - 1) * g.tiles_x + tx;
+        const float2* src = S + (((size_t)t * FFT_N + j_a + T) * FFT_NK) * C + c;
 #pragma unroll
-            for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = src[(size_t)kx * C]; re[kx] += v.x; im[kx] += v.y; }
-        }
+        for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = *src; re[kx] += v.x; im[kx] += v.y; src += C; GDN_KEEP(src); }
+    }
 #pragma unroll
-        for (int kx = FFT_NK; kx < 32; ++kx) { re[kx] = re[32 - kx]; im[kx] = -im[32 - kx]; }
-        fft32<1>(re, im);
-        float* dst = dx + ((size_t)(b * Ho + iy) * Wo) * lddx + c;
-        const float* ad = addsrc ? addsrc + ((size_t)(b * Ho + iy) * Wo) * ld_add + c : nullptr;
-        const bool has_next = tx + 1 < g.tiles_x;
+    for (int kx = FFT_NK; kx < 32; ++kx) { re[kx] = re[32 - kx]; im[kx] = -im[32 - kx]; }
+    fft32<1>(re, im);
+    const int ix0 = tx * T - off;
+    float* dst = dx + ((size_t)(b * Ho + iy) * Wo + ix0) * lddx + c;               // may point before the row: only
+    const float* ad = addsrc ? addsrc + ((size_t)(b * Ho + iy) * Wo + ix0) * ld_add + c : nullptr;   // dereferenced in range
+    const bool has_next = tx + 1 < g.tiles_x;
+    const int km1 = g.k - 1;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const int ix = tx * T - off + j;
-            if (ix < 0 || ix >= Wo) continue;
+    for (int j = 0; j < 32; ++j) {
+        const int ix = ix0 + j;
+        if (ix >= 0 && ix < Wo) {
             const float val = re[j] * (1.0f / 1024.0f);
             // odd tiles: columns shared with the even neighbours were stored by the first launch
-            const bool second = parity == 1 && (j < g.k - 1 || (j >= T && has_next));
-            if (second) dst[(size_t)ix * lddx] += val;
-            else dst[(size_t)ix * lddx] = ad ? val + ad[(size_t)ix * ld_add] : val;
+            const bool second = parity == 1 && (j < km1 || (j >= T && has_next));
+            if (second) *dst += val;
+            else *dst = ad ? val + *ad : val;
         }
+        dst += lddx; GDN_KEEP(dst);
+        if (ad) { ad += ld_add; GDN_KEEP(ad); }
     }
 }
 
@@ -500,13 +511,16 @@ __global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restri
         // wave-uniform image base + 32-bit per-lane offsets (one image is far below 2^31 elements): half the address registers
         const float* img = x + (size_t)b * g.H * g.W * ldx + cg;
         const int row_off = (row_ok ? iyr : 0) * g.W * ldx + c;
+        int off_x = ix0 * ldx;                             // running ix * ldx (interior columns: no multiply per element)
 #pragma unroll
         for (int bb = 0; bb < 32; ++bb) {
             const int ix = ix0 + bb;
-            const int ixr = ix < 0 ? -ix : (ix >= g.W ? 2 * g.W - 2 - ix : ix);
             const bool ok = row_ok && bb < nvalid && ix >= -lim && ix < g.W + lim;
-            re[bb] = ok ? img[row_off + ixr * ldx] : 0.f;
+            const bool inside = ix >= 0 && ix < g.W;
+            const int ixr = ix < 0 ? -ix : 2 * g.W - 2 - ix;         // mirrored column (border patches only)
+            re[bb] = ok ? img[row_off + (inside ? off_x : ixr * ldx)] : 0.f;
             im[bb] = 0.f;
+            off_x += ldx; GDN_KEEP(off_x);
         }
         fft32<-1>(re, im);
 #pragma unroll
@@ -518,9 +532,10 @@ __global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restri
 #pragma unroll
         for (int a = 0; a < 32; ++a) { const float2 v = lds[(a * FFT_NK + kx) * FFT_CG + c]; re[a] = v.x; im[a] = v.y; }
         fft32<-1>(re, im);
-        const int C = g.C;
+        float2* dst = Xf + ((size_t)kx * g.M + t) * g.C + cg + c;
+        const size_t sk = (size_t)FFT_NK * g.M * g.C;
 #pragma unroll
-        for (int ky = 0; ky < 32; ++ky) Xf[((size_t)(ky * FFT_NK + kx) * g.M + t) * C + cg + c] = make_float2(re[ky], im[ky]);
+        for (int ky = 0; ky < 32; ++ky) { *dst = make_float2(re[ky], im[ky]); dst += sk; GDN_KEEP(dst); }
     }
 }
 
@@ -530,10 +545,13 @@ __device__ __forceinline__ void ifft2d_cols_to_lds(const float2* __restrict__ Yf
     const int tid = threadIdx.x, c = tid & 15;
     if (tid < FFT_NK * FFT_CG) {
         const int kx = tid >> 4;
+        const float2* src = Yf + ((size_t)kx * M + t) * C + cg + c;
+        const size_t sk = (size_t)FFT_NK * M * C;
 #pragma unroll
         for (int ky = 0; ky < 32; ++ky) {
-            const float2 v = Yf[((size_t)(ky * FFT_NK + kx) * M + t) * C + cg + c];
+            const float2 v = *src;
             re[ky] = v.x; im[ky] = v.y;
+            src += sk; GDN_KEEP(src);
         }
         fft32<1>(re, im);
 #pragma unroll
@@ -567,21 +585,23 @@ __global__ __launch_bounds__(512, 4) void ifft2d_valid_kernel(const float2* __re
     float s1 = 0.f, s2 = 0.f;
     if (u < T && oy < g.H) {
         ifft_row_from_lds(lds, u, c, re, im);
-        float* dst = y + ((size_t)(b * g.H + oy) * g.W) * ldy + cg + c;
-        const float* ad = addsrc ? addsrc + ((size_t)(b * g.H + oy) * g.W) * ld_add + cg + c : nullptr;
+        const int ox0 = tx * T;
+        float* dst = y + ((size_t)(b * g.H + oy) * g.W + ox0) * ldy + cg + c;
+        const float* ad = addsrc ? addsrc + ((size_t)(b * g.H + oy) * g.W + ox0) * ld_add + cg + c : nullptr;
         const float es = ep_scale ? ep_scale[cg + c] : 1.f, et = ep_shift ? ep_shift[cg + c] : 0.f;
 #pragma unroll
         for (int v = 0; v < 32; ++v) {
-            const int ox = tx * T + v;
-            if (v < T && ox < g.W) {
+            if (v < T && ox0 + v < g.W) {
                 float val = re[v] * (1.0f / 1024.0f);
                 s1 += val; s2 += val * val;
                 if (ep_scale) val = val * es + et;
                 if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
-                if (ad) val += ad[(size_t)ox * ld_add];
+                if (ad) val += *ad;
                 if (act & GDN_ACT_TANH) val = tanhf(val);
-                dst[(size_t)ox * ldy] = val;
+                *dst = val;
             }
+            dst += ldy; GDN_KEEP(dst);
+            if (ad) { ad += ld_add; GDN_KEEP(ad); }
         }
     }
     if (stats) {
@@ -747,17 +767,21 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
                            (const float*)Df, Wsaved ? Wsaved : (const float*)Wf, (float*)Ef, f.M, f.C, f.N);
         // inverse along ky into S, then rows: the tile rows that reach an image row are summed in the frequency domain
         // (measured faster than the single-pass patch kernel with four parity launches, profiles/r01_fftconv_notes.txt)
-        hipLaunchKernelGGL(ifft_cols_kernel, dim3(blocks((int64_t)f.M * FFT_NK * f.C)), dim3(256), 0, st, (const float2*)Ef, R, f.C, f.M, FFT_N);
+        int cq_shift = 0;
+        while ((64 << cq_shift) < f.C) ++cq_shift;           // C / 64 is 1, 2 or 4
+        hipLaunchKernelGGL(ifft_cols_kernel, dim3(cdiv(f.M, 4) << cq_shift, FFT_NK), dim3(256), 0, st, (const float2*)Ef, R, f.C, f.M,
+                           FFT_N, cq_shift);
         const int Ho = f.reflect ? f.H + 2 * f.pad : f.H, Wo = f.reflect ? f.W + 2 * f.pad : f.W;
         for (int parity = 0; parity < 2; ++parity) {
             const int ntx = (f.tiles_x + 1 - parity) / 2;
             if (ntx == 0) continue;
+            const dim3 gr(cdiv(ntx, 4) << cq_shift, Ho, f.B);
             if (f.reflect)
-                hipLaunchKernelGGL(ifft_rows_overlap_kernel, dim3(blocks((int64_t)f.B * Ho * ntx * f.C)), dim3(256), 0, st,
-                                   (const float2*)R, dxp, f.C, (const float*)nullptr, 0, f, parity, Ho, Wo, 0);
+                hipLaunchKernelGGL(ifft_rows_overlap_kernel, gr, dim3(256), 0, st,
+                                   (const float2*)R, dxp, f.C, (const float*)nullptr, 0, f, parity, Ho, Wo, 0, cq_shift);
             else
-                hipLaunchKernelGGL(ifft_rows_overlap_kernel, dim3(blocks((int64_t)f.B * Ho * ntx * f.C)), dim3(256), 0, st,
-                                   (const float2*)R, dx, ldx, addsrc, ld_add, f, parity, Ho, Wo, f.pad);
+                hipLaunchKernelGGL(ifft_rows_overlap_kernel, gr, dim3(256), 0, st,
+                                   (const float2*)R, dx, ldx, addsrc, ld_add, f, parity, Ho, Wo, f.pad, cq_shift);
         }
         if (f.reflect)
             hipLaunchKernelGGL(fft_reflect_fold_kernel, dim3(blocks((int64_t)f.B * f.H * f.W * (f.C / 4))), dim3(256), 0, st,

@@ -588,20 +588,33 @@ __global__ __launch_bounds__(512, 4) void ifft2d_valid_kernel(const float2* __re
         const int ox0 = tx * T;
         float* dst = y + ((size_t)(b * g.H + oy) * g.W + ox0) * ldy + cg + c;
         const float* ad = addsrc ? addsrc + ((size_t)(b * g.H + oy) * g.W + ox0) * ld_add + cg + c : nullptr;
-        const float es = ep_scale ? ep_scale[cg + c] : 1.f, et = ep_shift ? ep_shift[cg + c] : 0.f;
+        if (!ep_scale && act == 0 && !ad) {
+            // training forward (raw conv output + BatchNorm partials): nothing but the scale, the sums and the store
 #pragma unroll
-        for (int v = 0; v < 32; ++v) {
-            if (v < T && ox0 + v < g.W) {
-                float val = re[v] * (1.0f / 1024.0f);
-                s1 += val; s2 += val * val;
-                if (ep_scale) val = val * es + et;
-                if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
-                if (ad) val += *ad;
-                if (act & GDN_ACT_TANH) val = tanhf(val);
-                *dst = val;
+            for (int v = 0; v < 32; ++v) {
+                if (v < T && ox0 + v < g.W) {
+                    const float val = re[v] * (1.0f / 1024.0f);
+                    s1 += val; s2 += val * val;
+                    *dst = val;
+                }
+                dst += ldy; GDN_KEEP(dst);
             }
-            dst += ldy; GDN_KEEP(dst);
-            if (ad) { ad += ld_add; GDN_KEEP(ad); }
+        } else {
+            const float es = ep_scale ? ep_scale[cg + c] : 1.f, et = ep_shift ? ep_shift[cg + c] : 0.f;
+#pragma unroll
+            for (int v = 0; v < 32; ++v) {
+                if (v < T && ox0 + v < g.W) {
+                    float val = re[v] * (1.0f / 1024.0f);
+                    s1 += val; s2 += val * val;
+                    if (ep_scale) val = val * es + et;
+                    if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
+                    if (ad) val += *ad;
+                    if (act & GDN_ACT_TANH) val = tanhf(val);
+                    *dst = val;
+                }
+                dst += ldy; GDN_KEEP(dst);
+                if (ad) { ad += ld_add; GDN_KEEP(ad); }
+            }
         }
     }
     if (stats) {

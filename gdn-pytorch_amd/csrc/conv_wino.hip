@@ -1,0 +1,431 @@
+// Winograd F(2x2, 3x3) convolution for the 512-channel 3x3 residual layers (levels 3 and 4 of G and R: after the
+// frequency-domain path took the large windows they are the biggest share of the fp32 step).
+//
+// A 3x3 stride-1 convolution costs 9 MACs per (pixel, cin, cout); F(2x2,3x3) costs 16 per 2x2 outputs = 4, a 2.25x
+// cut with transforms that only add and halve -- the fp32 error stays at the level of the direct sum (rms 1.6x,
+// DESIGN.md 2.5), unlike F(4x4,3x3).  The frequency-domain path of conv_fft.hip does not apply here: with 512 channels
+// its weight spectrum would be 1.7 GB per layer.
+//
+//   input     x  -> V [16][tile][Cin]     V = B^T d B of every 4x4 patch (stride 2, zero border)
+//   weights   w  -> U [16][Cout][Cin]     U = G g G^T   (data gradient: taps flipped, channel roles swapped)
+//   gemm      Mo[bin] = V[bin] * U[bin]^T           16 real GEMMs, M = tiles, K = Cin, N = Cout (fp32 MFMA)
+//   output    Mo -> y                                y = A^T m A (2x2 per tile) + the conv_igemm epilogue (BN partials,
+//                                                    affine / ReLU / residual)
+// Backward: the data gradient is the same pipeline on dy with the flipped / transposed weights; the weight gradient is
+// dW = G^T [ sum_tiles (B^T d B) (.) (A dy A^T) ] G: V is kept from the forward, dy gets the 2x2 -> 4x4 transform, the sum
+// over tiles is a reduction GEMM per bin on the MFMA, and a last small kernel folds the 16 bins into the 9 taps.
+#include "common.h"
+
+#define WINO_BINS 16
+#define GDN_KEEP(v) asm volatile("" : "+v"(v))
+
+namespace {
+
+struct WinoGeom {
+    int B, H, W, C, N;            // input [B,H,W,C] -> output [B,H,W,N]
+    int tiles_y, tiles_x, M;      // 2x2 output tiles; M = B * tiles_y * tiles_x
+    int cq_shift, nq_shift;       // log2(C / 64), log2(N / 64)
+};
+
+// thread = (tile, channel): block = 4 tiles x 64 channels, grid.x = (tile / 4) << q_shift | channel chunk
+__device__ __forceinline__ bool wino_decode(int M, int q_shift, int& t, int& c) {
+    t = (blockIdx.x >> q_shift) * 4 + (threadIdx.x >> 6);
+    c = (blockIdx.x & ((1 << q_shift) - 1)) * 64 + (threadIdx.x & 63);
+    return t < M;
+}
+
+// V = B^T d B of the 4x4 patch whose top-left corner is (2a - 1, 2b - 1)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V, WinoGeom g) {
+    int t, c;
+    if (!wino_decode(g.M, g.cq_shift, t, c)) return;
+    const int b2 = t % g.tiles_x, a2 = (t / g.tiles_x) % g.tiles_y, img = t / (g.tiles_x * g.tiles_y);
+    float d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int iy = 2 * a2 - 1 + i;
+        const bool row_ok = iy >= 0 && iy < g.H;
+        const float* row = x + ((size_t)(img * g.H + (row_ok ? iy : 0)) * g.W) * ldx + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ix = 2 * b2 - 1 + j;
+            d[i][j] = (row_ok && ix >= 0 && ix < g.W) ? row[(size_t)ix * ldx] : 0.f;
+        }
+    }
+    float r[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {          // B^T along rows
+        r[0][j] = d[0][j] - d[2][j];
+        r[1][j] = d[1][j] + d[2][j];
+        r[2][j] = d[2][j] - d[1][j];
+        r[3][j] = d[1][j] - d[3][j];
+    }
+    float* dst = V + (size_t)t * g.C + c;
+    const size_t bs = (size_t)g.M * g.C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // ... and along columns
+        dst[0] = r[i][0] - r[i][2]; dst += bs; GDN_KEEP(dst);
+        dst[0] = r[i][1] + r[i][2]; dst += bs; GDN_KEEP(dst);
+        dst[0] = r[i][2] - r[i][1]; dst += bs; GDN_KEEP(dst);
+        dst[0] = r[i][1] - r[i][3]; dst += bs; GDN_KEEP(dst);
+    }
+}
+
+// Dv = A dy A^T of the 2x2 output tile (weight gradient)
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, int ldy, float* __restrict__ Dv, WinoGeom g) {
+    int t, n;
+    if (!wino_decode(g.M, g.nq_shift, t, n)) return;
+    const int b2 = t % g.tiles_x, a2 = (t / g.tiles_x) % g.tiles_y, img = t / (g.tiles_x * g.tiles_y);
+    float y[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oy = 2 * a2 + i, ox = 2 * b2 + j;
+            y[i][j] = (oy < g.H && ox < g.W) ? dy[((size_t)(img * g.H + oy) * g.W + ox) * ldy + n] : 0.f;
+        }
+    float s[4][2];                          // A along rows: (y0, y0 + y1, y0 - y1, -y1)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { s[0][j] = y[0][j]; s[1][j] = y[0][j] + y[1][j]; s[2][j] = y[0][j] - y[1][j]; s[3][j] = -y[1][j]; }
+    float* dst = Dv + (size_t)t * g.N + n;
+    const size_t bs = (size_t)g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dst[0] = s[i][0]; dst += bs; GDN_KEEP(dst);
+        dst[0] = s[i][0] + s[i][1]; dst += bs; GDN_KEEP(dst);
+        dst[0] = s[i][0] - s[i][1]; dst += bs; GDN_KEEP(dst);
+        dst[0] = -s[i][1]; dst += bs; GDN_KEEP(dst);
+    }
+}
+
+// U = G g G^T.  swap = 0: U[bin][n][c] from w[tap][n][c] (forward);  swap = 1: U[bin][c][n] from the flipped taps
+// (data gradient: correlation of dy with w[n][c][2 - ty][2 - tx], output channel c)
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int N, int C, int swap) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int c = i % C, n = i / C;
+    float gk[3][3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+            const int tap = swap ? (2 - ty) * 3 + (2 - tx) : ty * 3 + tx;
+            gk[ty][tx] = w[((size_t)tap * N + n) * C + c];
+        }
+    float r[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        r[0][j] = gk[0][j];
+        r[1][j] = 0.5f * (gk[0][j] + gk[1][j] + gk[2][j]);
+        r[2][j] = 0.5f * (gk[0][j] - gk[1][j] + gk[2][j]);
+        r[3][j] = gk[2][j];
+    }
+    float* dst = U + (swap ? (size_t)c * N + n : (size_t)n * C + c);
+    const size_t bs = (size_t)N * C;
+#pragma unroll
+    for (int i2 = 0; i2 < 4; ++i2) {
+        dst[0] = r[i2][0]; dst += bs; GDN_KEEP(dst);
+        dst[0] = 0.5f * (r[i2][0] + r[i2][1] + r[i2][2]); dst += bs; GDN_KEEP(dst);
+        dst[0] = 0.5f * (r[i2][0] - r[i2][1] + r[i2][2]); dst += bs; GDN_KEEP(dst);
+        dst[0] = r[i2][2]; dst += bs; GDN_KEEP(dst);
+    }
+}
+
+// Per-bin real GEMM  Cm[bin][m][n] = sum_k A[bin][m][k] * Bm[bin][n][k]  (both K-contiguous), fp32 MFMA.
+// 64x64 tile, 4 waves of one 32x32 MFMA tile, 32-wide k-steps, the pitch-36 LDS image / b128 fragment scheme of
+// conv_igemm_f32.  XCD-aware order: XCD j owns bins j and j + 8 and walks them bin-major with the N-tiles of one M-tile
+// back to back (a bin's 1 MB weight matrix and every A tile stay in that XCD's L2).
+__global__ __launch_bounds__(256, 4) void wino_gemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                         float* __restrict__ Cm, int M, int N, int K) {
+    constexpr int LD = 36;
+    __shared__ __attribute__((aligned(16))) float As[64 * LD], Bs[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int NT = N / 64, MT = (M + 63) / 64;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int bin = (sq / (NT * MT)) * 8 + xcd, m0 = ((sq / NT) % MT) * 64, n0 = (sq % NT) * 64;
+    const float* Ab = A + (size_t)bin * M * K;
+    const float* Bb = Bm + (size_t)bin * N * K;
+    float* Cb = Cm + (size_t)bin * M * N;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int lr = tid >> 3, lc = (tid & 7) * 4;
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int m = m0 + ps * 32 + lr;
+            ra[ps] = m < M ? *reinterpret_cast<const f32x4*>(Ab + (size_t)m * K + k0 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[ps] = *reinterpret_cast<const f32x4*>(Bb + (size_t)(n0 + ps * 32 + lr) * K + k0 + lc);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            *reinterpret_cast<f32x4*>(&As[(ps * 32 + lr) * LD + lc]) = ra[ps];
+            *reinterpret_cast<f32x4*>(&Bs[(ps * 32 + lr) * LD + lc]) = rb[ps];
+        }
+    };
+    const int a_off = (wm * 32 + (lane & 31)) * LD + (lane >> 5) * 16;
+    const int b_off = (wn * 32 + (lane & 31)) * LD + (lane >> 5) * 16;
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        if (k0 + 32 < K) gload(k0 + 32);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[a_off + g4 * 4]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[b_off + g4 * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+        }
+        __syncthreads();
+        if (k0 + 32 < K) { lstore(); __syncthreads(); }
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M) Cb[(size_t)m * N + col] = acc[r];
+    }
+}
+
+// Reduction-over-tiles GEMM of the weight gradient:  P[bin][n][c] = sum_t Dv[bin][t][n] * V[bin][t][c]  (rows = tiles, both
+// operands read as they lie).  64x64 output tile, 32 tiles of the reduction per step, conflict-free ds_read_b32 row reads.
+__global__ __launch_bounds__(256, 4) void wino_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                            float* __restrict__ P, int M, int NI, int NJ) {
+    constexpr int LD = 64;
+    __shared__ __attribute__((aligned(16))) float As[32 * LD], Bs[32 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wi = wave >> 1, wj = wave & 1;
+    const int TI = NI / 64, TJ = NJ / 64;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int bin = (sq / (TI * TJ)) * 8 + xcd, i0 = ((sq / TJ) % TI) * 64, j0 = (sq % TJ) * 64;
+    const float* Ab = A + (size_t)bin * M * NI + i0;
+    const float* Bb = Bm + (size_t)bin * M * NJ + j0;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int lr = tid >> 4, lc = (tid & 15) * 4;
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int m0) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int m = m0 + ps * 16 + lr;
+            ra[ps] = m < M ? *reinterpret_cast<const f32x4*>(Ab + (size_t)m * NI + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[ps] = m < M ? *reinterpret_cast<const f32x4*>(Bb + (size_t)m * NJ + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            *reinterpret_cast<f32x4*>(&As[(ps * 16 + lr) * LD + lc]) = ra[ps];
+            *reinterpret_cast<f32x4*>(&Bs[(ps * 16 + lr) * LD + lc]) = rb[ps];
+        }
+    };
+    const int a_off = (lane >> 5) * LD + wi * 32 + (lane & 31);
+    const int b_off = (lane >> 5) * LD + wj * 32 + (lane & 31);
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int m0 = 0; m0 < M; m0 += 32) {
+        if (m0 + 32 < M) gload(m0 + 32);
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[a_off + kk * LD], Bs[b_off + kk * LD], acc, 0, 0, 0);
+        __syncthreads();
+        if (m0 + 32 < M) { lstore(); __syncthreads(); }
+    }
+    float* Pb = P + (size_t)bin * NI * NJ;
+    const int col = j0 + wj * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        Pb[(size_t)i * NJ + col] = acc[r];
+    }
+}
+
+// y = A^T m A (2x2 outputs per tile) with the conv_igemm epilogue; stats slot = group of 4 tiles
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mo, float* __restrict__ y, int ldy,
+                                                          const float* __restrict__ addsrc, int ld_add,
+                                                          float* __restrict__ stats, const float* __restrict__ ep_scale,
+                                                          const float* __restrict__ ep_shift, int act, WinoGeom g, int Nout,
+                                                          int q_shift) {
+    __shared__ float red[256 * 2];
+    int t, n;
+    const bool live = wino_decode(g.M, q_shift, t, n);
+    float s1 = 0.f, s2 = 0.f;
+    if (live) {
+        const int b2 = t % g.tiles_x, a2 = (t / g.tiles_x) % g.tiles_y, img = t / (g.tiles_x * g.tiles_y);
+        float m[4][4];
+        const float* src = Mo + (size_t)t * Nout + n;
+        const size_t bs = (size_t)g.M * Nout;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { m[i][j] = *src; src += bs; GDN_KEEP(src); }
+        float r[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { r[0][j] = m[0][j] + m[1][j] + m[2][j]; r[1][j] = m[1][j] - m[2][j] - m[3][j]; }
+        const float es = ep_scale ? ep_scale[n] : 1.f, et = ep_shift ? ep_shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float o[2] = {r[i][0] + r[i][1] + r[i][2], r[i][1] - r[i][2] - r[i][3]};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int oy = 2 * a2 + i, ox = 2 * b2 + j;
+                if (oy < g.H && ox < g.W) {
+                    float val = o[j];
+                    s1 += val; s2 += val * val;
+                    if (ep_scale) val = val * es + et;
+                    if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
+                    const size_t px = (size_t)(img * g.H + oy) * g.W + ox;
+                    if (addsrc) val += addsrc[px * ld_add + n];
+                    if (act & GDN_ACT_TANH) val = tanhf(val);
+                    y[px * ldy + n] = val;
+                }
+            }
+        }
+    }
+    if (stats) {
+        red[threadIdx.x * 2] = s1; red[threadIdx.x * 2 + 1] = s2;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float a1 = 0.f, a2s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a1 += red[(j * 64 + threadIdx.x) * 2]; a2s += red[(j * 64 + threadIdx.x) * 2 + 1]; }
+            const int slot = blockIdx.x >> q_shift;
+            const int ch = (blockIdx.x & ((1 << q_shift) - 1)) * 64 + threadIdx.x;
+            stats[((size_t)slot * 2 + 0) * Nout + ch] = a1;
+            stats[((size_t)slot * 2 + 1) * Nout + ch] = a2s;
+        }
+    }
+}
+
+// dW[tap][n][c] = (G^T P G)[ty][tx]
+__global__ __launch_bounds__(256) void wino_wgrad_output_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    float p[4][4];
+    const float* src = P + i;
+    const size_t bs = (size_t)N * C;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { p[a][b] = *src; src += bs; GDN_KEEP(src); }
+    float r[3][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        r[0][b] = p[0][b] + 0.5f * (p[1][b] + p[2][b]);
+        r[1][b] = 0.5f * (p[1][b] - p[2][b]);
+        r[2][b] = 0.5f * (p[1][b] + p[2][b]) + p[3][b];
+    }
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+        dw[(size_t)(ty * 3 + 0) * bs + i] = r[ty][0] + 0.5f * (r[ty][1] + r[ty][2]);
+        dw[(size_t)(ty * 3 + 1) * bs + i] = 0.5f * (r[ty][1] - r[ty][2]);
+        dw[(size_t)(ty * 3 + 2) * bs + i] = 0.5f * (r[ty][1] + r[ty][2]) + r[ty][3];
+    }
+}
+
+bool wino_geom(const gdn_conv_geom* g, WinoGeom& f) {
+    if (!g || g->transposed || g->stride != 1 || g->k != 3 || g->pad != 1 || g->pad_mode != 0) return false;
+    if ((g->Cin % 64) || (g->Cout % 64) || g->Cin > 512 || g->Cout > 512) return false;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (!pow2(g->Cin / 64) || !pow2(g->Cout / 64)) return false;
+    f.B = g->B; f.H = g->H; f.W = g->W; f.C = g->Cin; f.N = g->Cout;
+    f.tiles_y = cdiv(g->H, 2); f.tiles_x = cdiv(g->W, 2);
+    f.M = g->B * f.tiles_y * f.tiles_x;
+    f.cq_shift = 0; while ((64 << f.cq_shift) < f.C) ++f.cq_shift;
+    f.nq_shift = 0; while ((64 << f.nq_shift) < f.N) ++f.nq_shift;
+    return true;
+}
+
+inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+inline size_t v_bytes(const WinoGeom& f) { return al256((size_t)WINO_BINS * f.M * f.C * 4); }
+inline size_t u_bytes(const WinoGeom& f) { return al256((size_t)WINO_BINS * f.N * f.C * 4); }
+inline size_t m_bytes(const WinoGeom& f) { return al256((size_t)WINO_BINS * f.M * f.N * 4); }
+
+}  // namespace
+
+// saved state of one forward for its backward: the transformed input V
+extern "C" size_t gdn_winoconv_state_bytes(const gdn_conv_geom* g) {
+    WinoGeom f;
+    return wino_geom(g, f) ? v_bytes(f) : 0;
+}
+
+// workspace: V, U, Mo
+extern "C" size_t gdn_winoconv_fwd_workspace_bytes(const gdn_conv_geom* g) {
+    WinoGeom f;
+    return wino_geom(g, f) ? v_bytes(f) + u_bytes(f) + m_bytes(f) : 0;
+}
+
+extern "C" int64_t gdn_winoconv_stats_slots(const gdn_conv_geom* g) {
+    WinoGeom f;
+    if (!wino_geom(g, f)) return GDN_ERR_UNSUPPORTED;
+    return cdiv(f.M, 4);
+}
+
+extern "C" int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w, float* y, int32_t ldy,
+                                const float* addsrc, int32_t ld_add, float* stats, const float* ep_scale,
+                                const float* ep_shift, int32_t act, void* state_out, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    WinoGeom f;
+    if (!wino_geom(g, f)) return GDN_ERR_UNSUPPORTED;
+    if (!x || !w || !y || (!ep_scale) != (!ep_shift)) return GDN_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gdn_winoconv_fwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* p = (char*)workspace;
+    float* V = (float*)p; p += v_bytes(f);
+    float* U = (float*)p; p += u_bytes(f);
+    float* Mo = (float*)p;
+    if (state_out) V = (float*)state_out;
+    hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(f.M, 4) << f.cq_shift), dim3(256), 0, st, x, ldx, V, f);
+    hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 0);
+    hipLaunchKernelGGL(wino_gemm_kernel, dim3(cdiv(f.M, 64) * (f.N / 64) * WINO_BINS), dim3(256), 0, st, (const float*)V,
+                       (const float*)U, Mo, f.M, f.N, f.C);
+    hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, (const float*)Mo, y, ldy, addsrc,
+                       ld_add, stats, ep_scale, ep_shift, act, f, f.N, f.nq_shift);
+    return gdn_launch_status();
+}
+
+// workspace: Vd (transformed dy for the data gradient, [16][M][N]) / Dv (for the weight gradient, same size), U', Eo / P
+extern "C" size_t gdn_winoconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
+    WinoGeom f;
+    if (!wino_geom(g, f)) return 0;
+    const size_t eo = al256((size_t)WINO_BINS * f.M * f.C * 4);
+    return m_bytes(f) + u_bytes(f) + (eo > u_bytes(f) ? eo : u_bytes(f));
+}
+
+extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w, const void* state,
+                                float* dx, int32_t ldx, const float* addsrc, int32_t ld_add, float* dw, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    WinoGeom f;
+    if (!wino_geom(g, f)) return GDN_ERR_UNSUPPORTED;
+    if (!dy || (!dx && !dw) || (dx && !w) || (dw && !state)) return GDN_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < gdn_winoconv_bwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* p = (char*)workspace;
+    float* Vd = (float*)p; p += m_bytes(f);
+    float* U = (float*)p; p += u_bytes(f);
+    float* Eo = (float*)p;                       // data gradient: GEMM output [16][M][C]; weight gradient: P [16][N][C]
+    if (dw) {
+        hipLaunchKernelGGL(wino_dy_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, dy, ldy, Vd, f);
+        hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3((f.N / 64) * (f.C / 64) * WINO_BINS), dim3(256), 0, st, (const float*)Vd,
+                           (const float*)state, Eo, f.M, f.N, f.C);
+        hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, (const float*)Eo, dw, f.N, f.C);
+    }
+    if (dx) {
+        // the data gradient of a zero-padded 3x3 layer is the same convolution of dy with flipped, role-swapped taps
+        WinoGeom fd = f;
+        fd.C = f.N; fd.N = f.C; fd.cq_shift = f.nq_shift; fd.nq_shift = f.cq_shift;
+        hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(f.M, 4) << fd.cq_shift), dim3(256), 0, st, dy, ldy, Vd, fd);
+        hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 1);
+        hipLaunchKernelGGL(wino_gemm_kernel, dim3(cdiv(f.M, 64) * (f.C / 64) * WINO_BINS), dim3(256), 0, st, (const float*)Vd,
+                           (const float*)U, Eo, f.M, f.C, f.N);
+        hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(f.M, 4) << fd.nq_shift), dim3(256), 0, st, (const float*)Eo, dx, ldx, addsrc,
+                           ld_add, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, fd, f.C, fd.nq_shift);
+    }
+    return gdn_launch_status();
+}

@@ -18,6 +18,8 @@ _FUSE_EVAL_BN = os.environ.get("GDN_FUSE_EVAL_BN", "1") != "0"     # A/B switch 
 # fp32 stride-1 zero-padded layers with a window of at least this size run in the frequency domain
 # (csrc/conv_fft.hip); 0 disables.  5x5 on 256 channels is the break-even neighbourhood.
 _FFT_MIN_K = int(os.environ.get("GDN_FFT_MIN_K", "5"))
+# fp32 3x3 stride-1 zero-padded layers on 64..512 channels run as Winograd F(2x2,3x3) (csrc/conv_wino.hip)
+_WINOGRAD = os.environ.get("GDN_WINOGRAD", "1") != "0"
 _GRAPH_EPOCH = 0
 
 
@@ -274,11 +276,19 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                                   "model.eval() normalises with the tracked running statistics like the reference does")
     use_fft = (_FFT_MIN_K > 0 and ldt == torch.float32 and x2 is None and conv.kernel_size[0] >= _FFT_MIN_K
                and conv.stride[0] == 1 and op.fft_ok(x.shape[0], x.shape[1], x.shape[2], backward=ctx.record))
+    use_wino = (not use_fft and _WINOGRAD and ldt == torch.float32 and x2 is None and not reflect
+                and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and op.wino_ok(x.shape[0], x.shape[1], x.shape[2]))
+    # the two transform-domain paths share one call shape: forward (+ saved state), backward from that state
+    alt_fwd = op.fft_fwd if use_fft else op.wino_fwd if use_wino else None
+    alt_bwd = op.fft_bwd if use_fft else op.wino_bwd if use_wino else None
+    state_kw = "spectrum" if use_fft else "state"
+    bstate_kw = "xf" if use_fft else "state"
+    use_fft = use_fft or use_wino
     xf = None
     keep_xf = use_fft and ctx.record and conv.weight.requires_grad
     if bn.training:
         if use_fft:
-            r = op.fft_fwd(x, w, stats=True, spectrum=keep_xf)
+            r = alt_fwd(x, w, stats=True, **{state_kw: keep_xf})
             y, st = r[0], r[1]
             xf = r[2] if keep_xf else None
         else:
@@ -296,12 +306,12 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     if fused:
         # eval-mode BN folded into the conv epilogue: conv + scale/shift + ReLU (+ residual) in one pass
         if use_fft:
-            y = a = op.fft_fwd(x, w, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
+            y = a = alt_fwd(x, w, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
         else:
             y = a = op.fwd(x, w, x2=x2, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
     else:
         if not bn.training:
-            y = op.fft_fwd(x, w) if use_fft else op.fwd(x, w, x2=x2)
+            y = alt_fwd(x, w) if use_fft else op.fwd(x, w, x2=x2)
         a = ops.bn_apply(y, co[0], co[1], relu, residual, out_dtype=ctx.dtype)
     if ctx.record:
         in_hw = (x.shape[1], x.shape[2])
@@ -331,7 +341,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                     if gv is None:
                         raise GdnError("weight.grad is not tap-major")
                 if gv is not None or want_dx:
-                    dx = op.fft_bwd(dy, w, in_hw, xf=xf, dw_tap=gv, need_dx=want_dx,
+                    dx = alt_bwd(dy, w, in_hw, dw_tap=gv, need_dx=want_dx, **{bstate_kw: xf},
                                     addsrc=ctx.pop_grad_as(x, ldt) if want_dx else None)
                     if want_dx:
                         ctx.grads[id(x)] = (x, dx)

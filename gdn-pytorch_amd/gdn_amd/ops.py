@@ -221,6 +221,49 @@ class Conv:
                             _p(dw_tap), _p(ws), nb, stream())
         return dx
 
+    # ---- Winograd F(2x2,3x3) path (csrc/conv_wino.hip): 3x3 stride-1 zero-padded fp32 layers with 64..512 channels ----
+    def wino_ok(self, B, H, W):
+        _, ref, _, _ = self.geom(B, H, W)
+        return int(lib.gdn_winoconv_state_bytes(ref)) > 0
+
+    def wino_fwd(self, x, w_tap, stats=False, addsrc=None, state=False, affine=None, act=ACT_NONE):
+        """y = conv3x3(x) (+ epilogue) by Winograd F(2x2,3x3); returns y, then the BatchNorm partials when `stats`, then
+        the transformed input (opaque buffer for wino_bwd) when `state`."""
+        _chk(x, "x"); _chk(w_tap, "w")
+        B, H, W, C1 = x.shape
+        _, ref, Ho, Wo = self.geom(B, H, W)
+        nb = int(lib.gdn_winoconv_fwd_workspace_bytes(ref))
+        if nb == 0 or C1 != self.cin:
+            raise GdnError("winoconv: unsupported layer k=%d stride=%d Cin=%d Cout=%d" % (self.k, self.stride, C1, self.cout))
+        y = torch.empty((B, Ho, Wo, self.cout), dtype=torch.float32, device=x.device)
+        st = torch.empty((int(lib.gdn_winoconv_stats_slots(ref)), 2, self.cout), dtype=torch.float32,
+                         device=x.device) if stats else None
+        sv = torch.empty(int(lib.gdn_winoconv_state_bytes(ref)), dtype=torch.uint8, device=x.device) if state else None
+        ws = workspace(nb, x.device, "fft")
+        lib.gdn_winoconv_fwd(ref, _p(x), _ld(x), _p(w_tap), _p(y), _ld(y), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
+                             _p(st), _p(affine[0]) if affine else None, _p(affine[1]) if affine else None, int(act),
+                             _p(sv), _p(ws), nb, stream())
+        res = (y,) + ((st,) if stats else ()) + ((sv,) if state else ())
+        return res if len(res) > 1 else y
+
+    def wino_bwd(self, dy, w_tap, in_hw, state=None, dw_tap=None, need_dx=True, addsrc=None):
+        """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's `state`).
+        w_tap is the FORWARD tap-major weight [9, Cout, Cin]."""
+        _chk(dy, "dy")
+        B = dy.shape[0]
+        H, W = in_hw
+        _, ref, Ho, Wo = self.geom(B, H, W)
+        nb = int(lib.gdn_winoconv_bwd_workspace_bytes(ref))
+        if nb == 0:
+            raise GdnError("winoconv: unsupported layer k=%d stride=%d" % (self.k, self.stride))
+        if tuple(dy.shape[1:]) != (Ho, Wo, self.cout):
+            raise GdnError("wino_bwd: dy shape %s does not match layer output" % (tuple(dy.shape),))
+        dx = torch.empty((B, H, W, self.cin), dtype=torch.float32, device=dy.device) if need_dx else None
+        ws = workspace(nb, dy.device, "fft")
+        lib.gdn_winoconv_bwd(ref, _p(dy), _ld(dy), _p(w_tap), _p(state), _p(dx), 0 if dx is None else _ld(dx), _p(addsrc),
+                             0 if addsrc is None else _ld(addsrc), _p(dw_tap), _p(ws), nb, stream())
+        return dx
+
     def wgrad(self, x, dy, dw_tap, ci_off=0, cfg=0):
         """dw_tap[tap][co][ci_off + ci] = wgrad over the channel slice x (Cx = x.shape[3]).
         bf16 x/dy take the bf16 MFMA kernel; dw_tap is fp32 either way."""

@@ -155,6 +155,26 @@ int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const 
                     const void* xf, float* dx, int32_t ldx, const float* addsrc, int32_t ld_add,
                     float* dw, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Winograd F(2x2,3x3) convolution for the 3x3 stride-1 zero-padded layers on 64..512 channels (the
+ * 512-channel ResidualBlocks of levels 3 and 4, AE_model_unet.py:45-57), fp32: 2.25x fewer
+ * multiplies than the direct kernel, transforms that only add and halve.  Same contract as
+ * gdn_conv_fwd for y / addsrc / stats / ep_scale / ep_shift / act (slots: gdn_winoconv_stats_slots).
+ * state_out (nullable, gdn_winoconv_state_bytes) receives the transformed input, which
+ * gdn_winoconv_bwd needs for the weight gradient.  Cin/64 and Cout/64 must be powers of two. */
+size_t gdn_winoconv_fwd_workspace_bytes(const gdn_conv_geom* g);
+size_t gdn_winoconv_state_bytes(const gdn_conv_geom* g);
+int64_t gdn_winoconv_stats_slots(const gdn_conv_geom* g);
+int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w,
+                     float* y, int32_t ldy, const float* addsrc, int32_t ld_add, float* stats,
+                     const float* ep_scale, const float* ep_shift, int32_t act,
+                     void* state_out, void* workspace, size_t workspace_bytes, void* stream);
+/* dx = dgrad (+ addsrc) when dx != NULL (needs w), dw[tap][Cout][Cin] = wgrad when dw != NULL
+ * (needs state). */
+size_t gdn_winoconv_bwd_workspace_bytes(const gdn_conv_geom* g);
+int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w,
+                     const void* state, float* dx, int32_t ldx, const float* addsrc, int32_t ld_add,
+                     float* dw, void* workspace, size_t workspace_bytes, void* stream);
+
 /* bf16 weight gradient (BASELINE configs[2]): x and dy hold bfloat16, dw is fp32 (the master
  * gradient arena).  Same contract as gdn_conv_wgrad otherwise.  Needs Cx and Cout multiples of
  * 64, pixel pitches multiples of 8 and 16-byte aligned bases.  cfg: 0 automatic, 1/2 force the

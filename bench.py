@@ -58,6 +58,36 @@ def conv3x3_roofline(dev, B, level, reps=20):
     return ms, flop
 
 
+def wino_roofline(dev, B, reps=20):
+    """The 512->512 3x3 layer at level 3 (16x52) as it now runs: Winograd F(2x2,3x3).  Times the dominant kernel (the 16
+    per-bin fp32 MFMA GEMMs) alone, and the whole forward (input / weight transforms + GEMMs + output transform with the
+    BatchNorm partials)."""
+    from gdn_amd import ops
+    H, W, C = 16, 52, 512
+    op = ops.Conv(C, C, 3, 1, 1)
+    tiles = B * (H // 2) * (W // 2)
+    V = torch.randn(16, tiles, C, device=dev)
+    U = torch.randn(16, C, C, device=dev) * 0.02
+    Mo = torch.empty(16, tiles, C, device=dev)
+    x = torch.randn(B, H, W, C, device=dev)
+    w = torch.randn(9, C, C, device=dev) * 0.02
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ms_g = timed(lambda: op.wino_gemm_only(V, U, Mo, B, H, W))
+    ms_l = timed(lambda: op.wino_fwd(x, w, stats=True, state=True))
+    return ms_g, 2.0 * 16 * tiles * C * C, ms_l, 2.0 * B * H * W * 9 * C * C
+
+
 def fftconv_roofline(dev, B, reps=10):
     """Frequency-domain 9x9 64->64 layer at level 0 (128x416): forward (+BN partials, spectra kept) and backward
     (dgrad + wgrad) against the bytes the decomposition has to move (spectra written once and read once)."""
@@ -96,10 +126,10 @@ def fftconv_roofline(dev, B, reps=10):
             "direct_equiv_tflops_fwd": round(2.0 * B * H * W * k * k * C * C / ms_f / 1e9, 1)}
 
 
-def pmc_traffic():
+def pmc_traffic(name="r01_conv3x3_pmc.json"):
     """L2->fabric bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None if the summary is absent."""
-    f = ROOT / "profiles" / "r01_conv3x3_pmc.json"
+    f = ROOT / "profiles" / name
     try:
         return json.loads(f.read_text())["traffic_bytes_per_launch"]
     except Exception:  # noqa: BLE001
@@ -317,8 +347,9 @@ def main():
             ms3, fl3 = conv3x3_roofline(dev, B, 3)
             ms4, fl4 = conv3x3_roofline(dev, B, 4)
             a3 = fl3 / (ms3 * 1e-3) / 1e12
-            rec["roofline"] = {
-                "kernel": "conv_igemm_f32 3x3 s1 512->512 + BN-stats epilogue, B=%d 16x52 (level 3)" % B,
+            direct = {
+                "kernel": "conv_igemm_f32 3x3 s1 512->512 + BN-stats epilogue, B=%d 16x52 (level 3): the direct fused kernel "
+                          "(GDN_WINOGRAD=0, stride-2 / reflection layers, bf16 twin)" % B,
                 "bound": "mfma", "achieved": round(a3, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(a3 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
                 "gflop_per_launch": round(fl3 / 1e9, 2), "ms_per_launch": round(ms3, 4),
@@ -326,6 +357,21 @@ def main():
                                 "frac": round(fl4 / (ms4 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                 "gflop_per_launch": round(fl4 / 1e9, 2), "ms_per_launch": round(ms4, 4)},
             }
+            # dominant kernel of the step since the 3x3 512-channel layers run as Winograd F(2x2,3x3): its per-bin GEMMs
+            ms_g, fl_g, ms_l, fl_l = wino_roofline(dev, B)
+            ag = fl_g / (ms_g * 1e-3) / 1e12
+            rec["roofline"] = {
+                "kernel": "wino_gemm_kernel: the 16 per-bin fp32 MFMA GEMMs [%d x 512] x [512 x 512] of the Winograd F(2x2,3x3) "
+                          "3x3 s1 512->512 layer, B=%d 16x52 (level 3)" % (B * 8 * 26, B),
+                "bound": "mfma", "achieved": round(ag, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ag / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("r01_wino_gemm_pmc.json"),
+                "gflop_per_launch": round(fl_g / 1e9, 2), "ms_per_launch": round(ms_g, 4),
+                "layer_forward": {"ms": round(ms_l, 4), "direct_conv_gflop": round(fl_l / 1e9, 2),
+                                  "direct_equiv_tflops": round(fl_l / (ms_l * 1e-3) / 1e12, 2),
+                                  "note": "whole layer forward (transforms + GEMMs + BN-stats epilogue) counted in the direct "
+                                          "convolution's FLOPs (SURVEY 8d unit, 78.5 GFLOP): 2.25x fewer multiplies are executed"},
+            }
+            rec["roofline_direct3x3"] = direct
             # second-largest share of the step: the frequency-domain layers, HBM-bound
             rec["roofline_fftconv"] = fftconv_roofline(dev, B)
         if world == 1 and not args.no_cpu_baseline:

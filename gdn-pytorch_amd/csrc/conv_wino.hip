@@ -17,6 +17,9 @@
 #include "common.h"
 
 #define WINO_BINS 16
+#ifndef WINO_KC
+#define WINO_KC 64
+#endif
 #define GDN_KEEP(v) asm volatile("" : "+v"(v))
 
 namespace {
@@ -131,63 +134,83 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 }
 
 // Per-bin real GEMM  Cm[bin][m][n] = sum_k A[bin][m][k] * Bm[bin][n][k]  (both K-contiguous), fp32 MFMA.
-// 64x64 tile, 4 waves of one 32x32 MFMA tile, 32-wide k-steps, the pitch-36 LDS image / b128 fragment scheme of
+// 64x64 tile, 4 waves of one 32x32 MFMA tile, 64-wide k-steps (8 per GEMM at K = 512), the padded-pitch LDS image / b128 fragment scheme of
 // conv_igemm_f32.  XCD-aware order: XCD j owns bins j and j + 8 and walks them bin-major with the N-tiles of one M-tile
 // back to back (a bin's 1 MB weight matrix and every A tile stay in that XCD's L2).
-__global__ __launch_bounds__(256, 4) void wino_gemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                         float* __restrict__ Cm, int M, int N, int K) {
-    constexpr int LD = 36;
-    __shared__ __attribute__((aligned(16))) float As[64 * LD], Bs[64 * LD];
+template <int KC, int BM>      // KC reduction channels per step (32 / 64); BM rows per workgroup (64: one 32x32 MFMA tile
+                               // per wave; 128: two, sharing the B fragment)
+__global__ __launch_bounds__(256, BM == 64 ? 4 : 3) void wino_gemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                                          float* __restrict__ Cm, int M, int N, int K) {
+    constexpr int LD = KC + 4, NV = KC / 32, RM = BM / 64;  // NV float4 per thread, row pass and operand; RM row tiles per wave
+    __shared__ __attribute__((aligned(16))) float As[BM * LD], Bs[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int NT = N / 64, MT = (M + 63) / 64;
+    const int NT = N / 64, MT = (M + BM - 1) / BM;
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int bin = (sq / (NT * MT)) * 8 + xcd, m0 = ((sq / NT) % MT) * 64, n0 = (sq % NT) * 64;
+    const int bin = (sq / (NT * MT)) * 8 + xcd, m0 = ((sq / NT) % MT) * BM, n0 = (sq % NT) * 64;
     const float* Ab = A + (size_t)bin * M * K;
     const float* Bb = Bm + (size_t)bin * N * K;
     float* Cb = Cm + (size_t)bin * M * N;
-    f32x16 acc;
+    f32x16 acc[RM];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int lr = tid >> 3, lc = (tid & 7) * 4;
-    f32x4 ra[2], rb[2];
+    for (int t = 0; t < RM; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int lr = tid >> 3, lc = (tid & 7) * 4;          // 32 rows per pass, 8 lanes x 16 B = one 32-float chunk per row
+    f32x4 ra[2 * RM][NV], rb[2][NV];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
+        for (int ps = 0; ps < 2 * RM; ++ps) {
             const int m = m0 + ps * 32 + lr;
-            ra[ps] = m < M ? *reinterpret_cast<const f32x4*>(Ab + (size_t)m * K + k0 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rb[ps] = *reinterpret_cast<const f32x4*>(Bb + (size_t)(n0 + ps * 32 + lr) * K + k0 + lc);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                ra[ps][v] = m < M ? *reinterpret_cast<const f32x4*>(Ab + (size_t)m * K + k0 + v * 32 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                rb[ps][v] = *reinterpret_cast<const f32x4*>(Bb + (size_t)(n0 + ps * 32 + lr) * K + k0 + v * 32 + lc);
     };
     auto lstore = [&]() {
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            *reinterpret_cast<f32x4*>(&As[(ps * 32 + lr) * LD + lc]) = ra[ps];
-            *reinterpret_cast<f32x4*>(&Bs[(ps * 32 + lr) * LD + lc]) = rb[ps];
-        }
+        for (int ps = 0; ps < 2 * RM; ++ps)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) *reinterpret_cast<f32x4*>(&As[(ps * 32 + lr) * LD + v * 32 + lc]) = ra[ps][v];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) *reinterpret_cast<f32x4*>(&Bs[(ps * 32 + lr) * LD + v * 32 + lc]) = rb[ps][v];
     };
-    const int a_off = (wm * 32 + (lane & 31)) * LD + (lane >> 5) * 16;
+    const int a_off = (wm * 32 * RM + (lane & 31)) * LD + (lane >> 5) * 16;     // wave rows: wm * 32 * RM + t * 32 + r
     const int b_off = (wn * 32 + (lane & 31)) * LD + (lane >> 5) * 16;
     gload(0);
     lstore();
     __syncthreads();
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        if (k0 + 32 < K) gload(k0 + 32);
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        if (k0 + KC < K) gload(k0 + KC);
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[a_off + g4 * 4]);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[b_off + g4 * 4]);
+        for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
-        }
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[b_off + v * 32 + g4 * 4]);
+#pragma unroll
+                for (int t = 0; t < RM; ++t) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(&As[a_off + t * 32 * LD + v * 32 + g4 * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[t], 0, 0, 0);
+                }
+            }
         __syncthreads();
-        if (k0 + 32 < K) { lstore(); __syncthreads(); }
+        if (k0 + KC < K) { lstore(); __syncthreads(); }
     }
     const int col = n0 + wn * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M) Cb[(size_t)m * N + col] = acc[r];
-    }
+    for (int t = 0; t < RM; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 * RM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < M) Cb[(size_t)m * N + col] = acc[t][r];
+        }
 }
 
 // Reduction-over-tiles GEMM of the weight gradient:  P[bin][n][c] = sum_t Dv[bin][t][n] * V[bin][t][c]  (rows = tiles, both
@@ -327,6 +350,12 @@ __global__ __launch_bounds__(256) void wino_wgrad_output_kernel(const float* __r
     }
 }
 
+// 64-row tiles: the 128-row instantiation (two MFMA tiles per wave sharing the B fragment, 3 workgroups per CU) measured
+// the same at level 3 (0.392 vs 0.397 ms per forward) and 8 % slower at level 4
+void launch_wino_gemm(const float* A, const float* Bm, float* Cm, int M, int N, int K, hipStream_t st) {
+    hipLaunchKernelGGL((wino_gemm_kernel<WINO_KC, 64>), dim3(cdiv(M, 64) * (N / 64) * WINO_BINS), dim3(256), 0, st, A, Bm, Cm, M, N, K);
+}
+
 bool wino_geom(const gdn_conv_geom* g, WinoGeom& f) {
     if (!g || g->transposed || g->stride != 1 || g->k != 3 || g->pad != 1 || g->pad_mode != 0) return false;
     if ((g->Cin % 64) || (g->Cout % 64) || g->Cin > 512 || g->Cout > 512) return false;
@@ -382,8 +411,7 @@ extern "C" int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t 
     if (state_out) V = (float*)state_out;
     hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(f.M, 4) << f.cq_shift), dim3(256), 0, st, x, ldx, V, f);
     hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 0);
-    hipLaunchKernelGGL(wino_gemm_kernel, dim3(cdiv(f.M, 64) * (f.N / 64) * WINO_BINS), dim3(256), 0, st, (const float*)V,
-                       (const float*)U, Mo, f.M, f.N, f.C);
+    launch_wino_gemm((const float*)V, (const float*)U, Mo, f.M, f.N, f.C, st);
     hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, (const float*)Mo, y, ldy, addsrc,
                        ld_add, stats, ep_scale, ep_shift, act, f, f.N, f.nq_shift);
     return gdn_launch_status();
@@ -422,10 +450,20 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
         fd.C = f.N; fd.N = f.C; fd.cq_shift = f.nq_shift; fd.nq_shift = f.cq_shift;
         hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(f.M, 4) << fd.cq_shift), dim3(256), 0, st, dy, ldy, Vd, fd);
         hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 1);
-        hipLaunchKernelGGL(wino_gemm_kernel, dim3(cdiv(f.M, 64) * (f.C / 64) * WINO_BINS), dim3(256), 0, st, (const float*)Vd,
-                           (const float*)U, Eo, f.M, f.C, f.N);
+        launch_wino_gemm((const float*)Vd, (const float*)U, Eo, f.M, f.C, f.N, st);
         hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(f.M, 4) << fd.nq_shift), dim3(256), 0, st, (const float*)Eo, dx, ldx, addsrc,
                            ld_add, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, fd, f.C, fd.nq_shift);
     }
+    return gdn_launch_status();
+}
+
+// Measurement hook (bench.py roofline, tools/): the 16 per-bin GEMMs of one forward alone, on already transformed operands
+// V [16][M][Cin] and U [16][Cout][Cin]  ->  Mo [16][M][Cout].
+extern "C" int gdn_winoconv_gemm(const gdn_conv_geom* g, const float* V, const float* U, float* Mo, void* stream) {
+    (void)hipGetLastError();
+    WinoGeom f;
+    if (!wino_geom(g, f)) return GDN_ERR_UNSUPPORTED;
+    if (!V || !U || !Mo) return GDN_ERR_BAD_ARG;
+    launch_wino_gemm(V, U, Mo, f.M, f.N, f.C, (hipStream_t)stream);
     return gdn_launch_status();
 }

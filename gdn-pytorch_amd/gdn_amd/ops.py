@@ -246,6 +246,11 @@ class Conv:
         res = (y,) + ((st,) if stats else ()) + ((sv,) if state else ())
         return res if len(res) > 1 else y
 
+    def wino_gemm_only(self, V, U, Mo, B, H, W):
+        """Measurement hook: the 16 per-bin GEMMs of one forward on already transformed operands."""
+        _, ref, _, _ = self.geom(B, H, W)
+        lib.gdn_winoconv_gemm(ref, _p(V), _p(U), _p(Mo), stream())
+
     def wino_bwd(self, dy, w_tap, in_hw, state=None, dw_tap=None, need_dx=True, addsrc=None):
         """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's `state`).
         w_tap is the FORWARD tap-major weight [9, Cout, Cin]."""

@@ -171,6 +171,9 @@ int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const 
 /* dx = dgrad (+ addsrc) when dx != NULL (needs w), dw[tap][Cout][Cin] = wgrad when dw != NULL
  * (needs state). */
 size_t gdn_winoconv_bwd_workspace_bytes(const gdn_conv_geom* g);
+/* Measurement hook: only the 16 per-bin MFMA GEMMs of one forward, V [16][tiles][Cin] x U [16][Cout][Cin]
+ * -> Mo [16][tiles][Cout] (tiles = B * ceil(H/2) * ceil(W/2)). */
+int gdn_winoconv_gemm(const gdn_conv_geom* g, const float* V, const float* U, float* Mo, void* stream);
 int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w,
                      const void* state, float* dx, int32_t ldx, const float* addsrc, int32_t ld_add,
                      float* dw, void* workspace, size_t workspace_bytes, void* stream);

@@ -1,0 +1,43 @@
+#!/bin/bash
+# GPU box: PMC passes (separate runs, kernel-trace only) of the Winograd kernels at level 3 / level 4, B=20 -> JSON summary
+cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+out=$R/gpurun_out/pmc_wino
+mkdir -p $out
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 $R/tests/diag/wino_time.py > $out/$c.log 2>&1
+done
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/SQ -- python3 $R/tests/diag/wino_time.py > $out/SQ.log 2>&1
+cd $R
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections, json, os
+out = sys.argv[1]
+res = collections.defaultdict(dict)
+dur = collections.defaultdict(list)
+for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
+    files = sorted(glob.glob(out + "/" + c + "/*/*counter_collection.csv"), key=os.path.getmtime)
+    if not files:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(files[-1])):
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:34]
+        k = (name, int(r["Grid_Size"]))
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if c == "SQ" and r["Counter_Name"] == "SQ_WAVES":
+            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for k, d in agg.items():
+        for cn, v in d.items():
+            res[k][cn] = sum(v) / len(v)
+rows = {}
+for k, d in sorted(res.items()):
+    if "wino" not in k[0]:
+        continue
+    fe, wr = d.get("FETCH_SIZE", 0), d.get("WRITE_SIZE", 0)
+    rows["%s grid %d" % k] = {"FETCH_SIZE_KB": round(fe, 1), "WRITE_SIZE_KB": round(wr, 1),
+                              "traffic_bytes_per_launch": int((2 * fe + wr) * 1024),
+                              "SQ_INSTS_MFMA": d.get("SQ_INSTS_MFMA"), "SQ_INSTS_VALU": d.get("SQ_INSTS_VALU"),
+                              "SQ_VALU_MFMA_BUSY_CYCLES": d.get("SQ_VALU_MFMA_BUSY_CYCLES"), "SQ_BUSY_CYCLES": d.get("SQ_BUSY_CYCLES"),
+                              "GRBM_GUI_ACTIVE": d.get("GRBM_GUI_ACTIVE"),
+                              "mean_duration_us_profiled": round(sum(dur[k]) / max(len(dur[k]), 1), 1)}
+print(json.dumps(rows, indent=1))
+PY

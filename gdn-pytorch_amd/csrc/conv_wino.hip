@@ -25,7 +25,10 @@
 namespace {
 
 struct WinoGeom {
-    int B, H, W, C, N;            // input [B,H,W,C] -> output [B,H,W,N]
+    int B, H, W, C, N;            // input [B,H,W,C] -> output [B,Ho,Wo,N]
+    int Ho, Wo;                   // output extent (= H, W except for the padded-domain data gradient of a reflection layer)
+    int pad_off;                  // output (oy, ox) reads input rows oy - pad_off .. oy - pad_off + 2
+    int reflect;                  // input border: 0 zeros, 1 mirror (ReflectionPad2d(1) + conv)
     int tiles_y, tiles_x, M;      // 2x2 output tiles; M = B * tiles_y * tiles_x
     int cq_shift, nq_shift;       // log2(C / 64), log2(N / 64)
 };
@@ -37,21 +40,24 @@ __device__ __forceinline__ bool wino_decode(int M, int q_shift, int& t, int& c) 
     return t < M;
 }
 
-// V = B^T d B of the 4x4 patch whose top-left corner is (2a - 1, 2b - 1)
+// V = B^T d B of the 4x4 patch whose top-left corner is (2a - pad_off, 2b - pad_off)
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V, WinoGeom g) {
     int t, c;
     if (!wino_decode(g.M, g.cq_shift, t, c)) return;
     const int b2 = t % g.tiles_x, a2 = (t / g.tiles_x) % g.tiles_y, img = t / (g.tiles_x * g.tiles_y);
     float d[4][4];
+    const int lim = g.reflect ? 1 : 0;      // mirrored border rows / columns -1 and H (W); anything further out reads zero
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int iy = 2 * a2 - 1 + i;
-        const bool row_ok = iy >= 0 && iy < g.H;
-        const float* row = x + ((size_t)(img * g.H + (row_ok ? iy : 0)) * g.W) * ldx + c;
+        const int iy = 2 * a2 - g.pad_off + i;
+        const bool row_ok = iy >= -lim && iy < g.H + lim;
+        const int iyr = iy < 0 ? -iy : (iy >= g.H ? 2 * g.H - 2 - iy : iy);
+        const float* row = x + ((size_t)(img * g.H + (row_ok ? iyr : 0)) * g.W) * ldx + c;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ix = 2 * b2 - 1 + j;
-            d[i][j] = (row_ok && ix >= 0 && ix < g.W) ? row[(size_t)ix * ldx] : 0.f;
+            const int ix = 2 * b2 - g.pad_off + j;
+            const int ixr = ix < 0 ? -ix : (ix >= g.W ? 2 * g.W - 2 - ix : ix);
+            d[i][j] = (row_ok && ix >= -lim && ix < g.W + lim) ? row[(size_t)ixr * ldx] : 0.f;
         }
     }
     float r[4][4];
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int oy = 2 * a2 + i, ox = 2 * b2 + j;
-            y[i][j] = (oy < g.H && ox < g.W) ? dy[((size_t)(img * g.H + oy) * g.W + ox) * ldy + n] : 0.f;
+            y[i][j] = (oy < g.Ho && ox < g.Wo) ? dy[((size_t)(img * g.Ho + oy) * g.Wo + ox) * ldy + n] : 0.f;
         }
     float s[4][2];                          // A along rows: (y0, y0 + y1, y0 - y1, -y1)
 #pragma unroll
@@ -296,12 +302,12 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int oy = 2 * a2 + i, ox = 2 * b2 + j;
-                if (oy < g.H && ox < g.W) {
+                if (oy < g.Ho && ox < g.Wo) {
                     float val = o[j];
                     s1 += val; s2 += val * val;
                     if (ep_scale) val = val * es + et;
                     if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
-                    const size_t px = (size_t)(img * g.H + oy) * g.W + ox;
+                    const size_t px = (size_t)(img * g.Ho + oy) * g.Wo + ox;
                     if (addsrc) val += addsrc[px * ld_add + n];
                     if (act & GDN_ACT_TANH) val = tanhf(val);
                     y[px * ldy + n] = val;
@@ -356,12 +362,42 @@ void launch_wino_gemm(const float* A, const float* Bm, float* Cm, int M, int N, 
     hipLaunchKernelGGL((wino_gemm_kernel<WINO_KC, 64>), dim3(cdiv(M, 64) * (N / 64) * WINO_BINS), dim3(256), 0, st, A, Bm, Cm, M, N, K);
 }
 
+// dx[y][x] = sum of the padded-domain gradient over the padded coordinates that reflect onto (y, x)  (+ addsrc), pad 1
+__global__ __launch_bounds__(256) void wino_reflect_fold_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int ldx,
+                                                                const float* __restrict__ addsrc, int ld_add,
+                                                                int B, int H, int W, int C) {
+    const int Hp = H + 2, Wp = W + 2, c4n = C / 4;
+    const int64_t total = (int64_t)B * H * W * c4n;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H), b = (int)(t / H);
+        int qy[3], qx[3], ny = 0, nx = 0;
+        qy[ny++] = y + 1;
+        if (y == 1) qy[ny++] = 0;                  // padded row 0 mirrors row 1
+        if (y == H - 2) qy[ny++] = H + 1;          // padded row H + 1 mirrors row H - 2
+        qx[nx++] = x + 1;
+        if (x == 1) qx[nx++] = 0;
+        if (x == W - 2) qx[nx++] = W + 1;
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a)
+            for (int e = 0; e < nx; ++e)
+                s4 += *reinterpret_cast<const f32x4*>(dxp + ((size_t)(b * Hp + qy[a]) * Wp + qx[e]) * C + c4 * 4);
+        const size_t op = (size_t)(b * H + y) * W + x;
+        if (addsrc) s4 += *reinterpret_cast<const f32x4*>(addsrc + op * ld_add + c4 * 4);
+        *reinterpret_cast<f32x4*>(dx + op * ldx + c4 * 4) = s4;
+    }
+}
+
 bool wino_geom(const gdn_conv_geom* g, WinoGeom& f) {
-    if (!g || g->transposed || g->stride != 1 || g->k != 3 || g->pad != 1 || g->pad_mode != 0) return false;
+    if (!g || g->transposed || g->stride != 1 || g->k != 3 || g->pad != 1) return false;
+    if (g->pad_mode == 1 && (g->H < 4 || g->W < 4)) return false;        // mirrored rows 1 and H-2 must be distinct interior rows
     if ((g->Cin % 64) || (g->Cout % 64) || g->Cin > 512 || g->Cout > 512) return false;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     if (!pow2(g->Cin / 64) || !pow2(g->Cout / 64)) return false;
     f.B = g->B; f.H = g->H; f.W = g->W; f.C = g->Cin; f.N = g->Cout;
+    f.Ho = g->H; f.Wo = g->W; f.pad_off = 1; f.reflect = g->pad_mode == 1;
     f.tiles_y = cdiv(g->H, 2); f.tiles_x = cdiv(g->W, 2);
     f.M = g->B * f.tiles_y * f.tiles_x;
     f.cq_shift = 0; while ((64 << f.cq_shift) < f.C) ++f.cq_shift;
@@ -421,8 +457,11 @@ extern "C" int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t 
 extern "C" size_t gdn_winoconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     WinoGeom f;
     if (!wino_geom(g, f)) return 0;
-    const size_t eo = al256((size_t)WINO_BINS * f.M * f.C * 4);
-    return m_bytes(f) + u_bytes(f) + (eo > u_bytes(f) ? eo : u_bytes(f));
+    // reflection layers run the data gradient over the padded domain: more tiles, plus the padded gradient itself
+    const size_t Md = f.reflect ? (size_t)f.B * cdiv(f.H + 2, 2) * cdiv(f.W + 2, 2) : (size_t)f.M;
+    const size_t vd = al256((size_t)WINO_BINS * Md * f.N * 4), eo = al256((size_t)WINO_BINS * Md * f.C * 4);
+    const size_t padded = f.reflect ? al256((size_t)f.B * (f.H + 2) * (f.W + 2) * f.C * 4) : 0;
+    return (vd > m_bytes(f) ? vd : m_bytes(f)) + u_bytes(f) + (eo > u_bytes(f) ? eo : u_bytes(f)) + padded;
 }
 
 extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w, const void* state,
@@ -432,12 +471,15 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
     WinoGeom f;
     if (!wino_geom(g, f)) return GDN_ERR_UNSUPPORTED;
     if (!dy || (!dx && !dw) || (dx && !w) || (dw && !state)) return GDN_ERR_BAD_ARG;
+    if (dx && f.reflect && ((ldx % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < gdn_winoconv_bwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* p = (char*)workspace;
-    float* Vd = (float*)p; p += m_bytes(f);
+    const size_t Md = f.reflect ? (size_t)f.B * cdiv(f.H + 2, 2) * cdiv(f.W + 2, 2) : (size_t)f.M;
+    const size_t vd = al256((size_t)WINO_BINS * Md * f.N * 4);
+    float* Vd = (float*)p; p += (vd > m_bytes(f) ? vd : m_bytes(f));
     float* U = (float*)p; p += u_bytes(f);
-    float* Eo = (float*)p;                       // data gradient: GEMM output [16][M][C]; weight gradient: P [16][N][C]
+    float* Eo = (float*)p;                       // data gradient: GEMM output [16][Md][C] (+ padded gradient); weight gradient: P
     if (dw) {
         hipLaunchKernelGGL(wino_dy_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, dy, ldy, Vd, f);
         hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3((f.N / 64) * (f.C / 64) * WINO_BINS), dim3(256), 0, st, (const float*)Vd,
@@ -445,14 +487,30 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
         hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, (const float*)Eo, dw, f.N, f.C);
     }
     if (dx) {
-        // the data gradient of a zero-padded 3x3 layer is the same convolution of dy with flipped, role-swapped taps
+        // the data gradient of a 3x3 layer is the same kind of convolution of dy with flipped, role-swapped taps: pad 1 onto
+        // the H x W input for a zero-padded layer; pad 2 onto the (H+2) x (W+2) padded domain for a reflection-padded one,
+        // whose border rows / columns are then folded back onto the rows they mirror
         WinoGeom fd = f;
-        fd.C = f.N; fd.N = f.C; fd.cq_shift = f.nq_shift; fd.nq_shift = f.cq_shift;
-        hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(f.M, 4) << fd.cq_shift), dim3(256), 0, st, dy, ldy, Vd, fd);
+        fd.C = f.N; fd.N = f.C; fd.cq_shift = f.nq_shift; fd.nq_shift = f.cq_shift; fd.reflect = 0;
+        float* out = dx;
+        int ld_out = ldx;
+        if (f.reflect) {
+            fd.Ho = f.H + 2; fd.Wo = f.W + 2; fd.pad_off = 2;
+            fd.tiles_y = cdiv(fd.Ho, 2); fd.tiles_x = cdiv(fd.Wo, 2); fd.M = f.B * fd.tiles_y * fd.tiles_x;
+            out = Eo + (size_t)WINO_BINS * fd.M * f.C;                 // padded-domain gradient, behind the GEMM output
+            ld_out = f.C;
+        }
+        hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(fd.M, 4) << fd.cq_shift), dim3(256), 0, st, dy, ldy, Vd, fd);
         hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 1);
-        launch_wino_gemm((const float*)Vd, (const float*)U, Eo, f.M, f.C, f.N, st);
-        hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(f.M, 4) << fd.nq_shift), dim3(256), 0, st, (const float*)Eo, dx, ldx, addsrc,
-                           ld_add, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, fd, f.C, fd.nq_shift);
+        launch_wino_gemm((const float*)Vd, (const float*)U, Eo, fd.M, f.C, f.N, st);
+        hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(fd.M, 4) << fd.nq_shift), dim3(256), 0, st, (const float*)Eo, out, ld_out,
+                           f.reflect ? (const float*)nullptr : addsrc, ld_add, (float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, 0, fd, f.C, fd.nq_shift);
+        if (f.reflect) {
+            const int64_t nb = cdiv64((int64_t)f.B * f.H * f.W * (f.C / 4), 256);
+            hipLaunchKernelGGL(wino_reflect_fold_kernel, dim3((unsigned)(nb < 65536 * 8 ? nb : 65536 * 8)), dim3(256), 0, st,
+                               (const float*)out, dx, ldx, addsrc, ld_add, f.B, f.H, f.W, f.C);
+        }
     }
     return gdn_launch_status();
 }

@@ -276,7 +276,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                                   "model.eval() normalises with the tracked running statistics like the reference does")
     use_fft = (_FFT_MIN_K > 0 and ldt == torch.float32 and x2 is None and conv.kernel_size[0] >= _FFT_MIN_K
                and conv.stride[0] == 1 and op.fft_ok(x.shape[0], x.shape[1], x.shape[2], backward=ctx.record))
-    use_wino = (not use_fft and _WINOGRAD and ldt == torch.float32 and x2 is None and not reflect
+    use_wino = (not use_fft and _WINOGRAD and ldt == torch.float32 and x2 is None
                 and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and op.wino_ok(x.shape[0], x.shape[1], x.shape[2]))
     # the two transform-domain paths share one call shape: forward (+ saved state), backward from that state
     alt_fwd = op.fft_fwd if use_fft else op.wino_fwd if use_wino else None

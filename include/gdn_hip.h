@@ -155,8 +155,9 @@ int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const 
                     const void* xf, float* dx, int32_t ldx, const float* addsrc, int32_t ld_add,
                     float* dw, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Winograd F(2x2,3x3) convolution for the 3x3 stride-1 zero-padded layers on 64..512 channels (the
- * 512-channel ResidualBlocks of levels 3 and 4, AE_model_unet.py:45-57), fp32: 2.25x fewer
+/* Winograd F(2x2,3x3) convolution for the 3x3 stride-1 layers (zero or reflection padding 1) on
+ * 64..512 channels (the 512-channel ResidualBlocks of levels 3 and 4, AE_model_unet.py:45-57; R's
+ * decoder ConvBlocks upconv0 / upconv1, :60-77), fp32: 2.25x fewer
  * multiplies than the direct kernel, transforms that only add and halve.  Same contract as
  * gdn_conv_fwd for y / addsrc / stats / ep_scale / ep_shift / act (slots: gdn_winoconv_stats_slots).
  * state_out (nullable, gdn_winoconv_state_bytes) receives the transformed input, which

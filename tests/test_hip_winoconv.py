@@ -53,7 +53,7 @@ def test_winoconv_rejects_other_geometries(gpu):
     from gdn_amd import ops
     for args in [(512, 512, 3, 2, 1), (512, 512, 5, 1, 2), (512, 1, 3, 1, 1), (192, 192, 3, 1, 1), (1024, 512, 3, 1, 1)]:
         assert not ops.Conv(*args).wino_ok(2, 16, 16)
-    assert not ops.Conv(512, 512, 3, 1, 1, reflect=True).wino_ok(2, 16, 16)
+    assert not ops.Conv(512, 512, 3, 1, 1, reflect=True).wino_ok(2, 3, 16)          # mirrored rows must be interior
     assert not ops.Conv(512, 512, 3, 1, 1, transposed=True).wino_ok(2, 16, 16)
 
 
@@ -99,3 +99,33 @@ def test_engine_winograd_switch_matches_direct(gpu, monkeypatch):
     close(outs[True][1], outs[False][1], what="block dx")
     for a, b in zip(outs[True][2], outs[False][2]):
         close(a, b, what="block param grad")
+
+
+REFLECT_CASES = [(512, 256, 1, 32, 104), (128, 64, 2, 9, 13), (64, 64, 2, 4, 4), (256, 512, 1, 16, 52)]
+
+
+@pytest.mark.parametrize("case", REFLECT_CASES, ids=["c%d_%d_%dx%dx%d" % c for c in REFLECT_CASES])
+def test_winoconv_reflection_pad(gpu, case):
+    """ConvBlock of R's decoder: ReflectionPad2d(1) + Conv2d(3x3, pad 0) (AE_model_unet.py:60-77, upconv0 / upconv1)."""
+    from gdn_amd import ops
+    ci, co, B, H, W = case
+    g = torch.Generator().manual_seed(31 + H + W)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
+    gy = torch.randn(B, co, H, W, generator=g)
+    gres = torch.randn(B, ci, H, W, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wr)
+    y_ref.backward(gy)
+    op = ops.Conv(ci, co, 3, 1, 1, reflect=True)
+    assert op.wino_ok(B, H, W)
+    xd, wd = nhwc(x).to(gpu), tapmajor(w, False).to(gpu)
+    y, st, sv = op.wino_fwd(xd, wd, stats=True, state=True)
+    close(nchw(y), y_ref, what="fwd")
+    close(st[:, 1].sum(0), (y_ref.detach() ** 2).sum((0, 2, 3)), what="stats sumsq")
+    dw = torch.empty_like(wd)
+    dx = op.wino_bwd(nhwc(gy).to(gpu), wd, (H, W), state=sv, dw_tap=dw, addsrc=nhwc(gres).to(gpu))
+    close(nchw(dx), xr.grad + gres, what="dgrad")
+    close(dw, tapmajor(wr.grad, False), what="wgrad")
+    close(nchw(op.wino_bwd(nhwc(gy).to(gpu), wd, (H, W))), xr.grad, what="dgrad only")
+    close(y, op.fwd(xd, wd), what="fwd vs direct")

@@ -599,6 +599,22 @@ __global__ __launch_bounds__(512, 4) void ifft2d_valid_kernel(const float2* __re
                 }
                 dst += ldy; GDN_KEEP(dst);
             }
+        } else if (ep_scale && !(act & GDN_ACT_TANH)) {
+            // eval-mode layer (frozen guide, inference): folded BatchNorm, optional ReLU, optional residual
+            const float es = ep_scale[cg + c], et = ep_shift[cg + c];
+            const float lo = (act & GDN_ACT_RELU) ? 0.f : -3.402823466e38f;
+#pragma unroll
+            for (int v = 0; v < 32; ++v) {
+                if (v < T && ox0 + v < g.W) {
+                    const float raw = re[v] * (1.0f / 1024.0f);
+                    s1 += raw; s2 += raw * raw;
+                    float val = fmaxf(raw * es + et, lo);
+                    if (ad) val += *ad;
+                    *dst = val;
+                }
+                dst += ldy; GDN_KEEP(dst);
+                if (ad) { ad += ld_add; GDN_KEEP(ad); }
+            }
         } else {
             const float es = ep_scale ? ep_scale[cg + c] : 1.f, et = ep_shift ? ep_shift[cg + c] : 0.f;
 #pragma unroll

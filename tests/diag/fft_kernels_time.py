@@ -26,5 +26,9 @@ for (C, k, H, W, B) in [(64, 9, 128, 416, 20), (128, 7, 64, 208, 20), (256, 5, 3
     gy = torch.randn(B, H, W, C, device=dev)
     y, st, xf = op.fft_fwd(x, w, stats=True, spectrum=True)
     dw = torch.empty_like(w)
-    print("C=%d k=%d: fwd %.3f ms  bwd %.3f ms" % (C, k, timeit(lambda: op.fft_fwd(x, w, stats=True, spectrum=True)),
-                                                  timeit(lambda: op.fft_bwd(gy, w, (H, W), xf=xf, dw_tap=dw))))
+    sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+    print("C=%d k=%d: fwd %.3f ms  bwd %.3f ms | eval fwd (affine+relu) %.3f, (affine+residual) %.3f" % (
+        C, k, timeit(lambda: op.fft_fwd(x, w, stats=True, spectrum=True)),
+        timeit(lambda: op.fft_bwd(gy, w, (H, W), xf=xf, dw_tap=dw)),
+        timeit(lambda: op.fft_fwd(x, w, affine=(sc, sh), act=ops.ACT_RELU)),
+        timeit(lambda: op.fft_fwd(x, w, affine=(sc, sh), addsrc=gy))))

@@ -18,6 +18,7 @@ The same line carries
                   bounded sample, N=1 rank 0 only.
 """
 import argparse
+import contextlib
 import json
 import os
 import pathlib
@@ -169,7 +170,8 @@ def infer_main(args):
     torch.manual_seed(0)
     B = args.batch if args.batch != 20 else 64
     H, W = 256, 832
-    model = M.AutoEncoder(height=H, width=W).to(dev).eval().compute_dtype(args.dtype)
+    with contextlib.redirect_stdout(sys.stderr):          # the ctor prints '- norm : Batch' like the reference's
+        model = M.AutoEncoder(height=H, width=W).to(dev).eval().compute_dtype(args.dtype)
     x = (torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(rank)) * 2 - 1).to(dev)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -265,12 +267,13 @@ def main():
     depth, rgb, sparse = synthetic_batch(B, 128, 416, seed=rank, device=dev)
 
     G = None
-    if args.mode == "DtoD":
-        model = M.AutoEncoder_DtoD(input_dim=1).to(dev)
-    else:
-        model = M.AutoEncoder_2(input_dim=3).to(dev)
-        torch.manual_seed(1)
-        G = M.AutoEncoder_DtoD(input_dim=1).to(dev).eval()
+    with contextlib.redirect_stdout(sys.stderr):          # the ctors print '- norm : Batch' like the reference's: keep stdout
+        if args.mode == "DtoD":                           # to the one JSON line
+            model = M.AutoEncoder_DtoD(input_dim=1).to(dev)
+        else:
+            model = M.AutoEncoder_2(input_dim=3).to(dev)
+            torch.manual_seed(1)
+            G = M.AutoEncoder_DtoD(input_dim=1).to(dev).eval()
     model.train().compute_dtype(args.dtype)
     if G is not None:
         G.compute_dtype(args.dtype)

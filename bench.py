@@ -123,7 +123,8 @@ def fftconv_roofline(dev, B, reps=10):
     return {"layer": "9x9 s1 64->64, B=%d 128x416 (level 0), 32x32 tiles" % B, "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
             "fwd_ms": round(ms_f, 4), "fwd_bytes": by_f, "fwd_achieved": round(by_f / ms_f / 1e6, 1),
             "bwd_ms": round(ms_b, 4), "bwd_bytes": by_b, "bwd_achieved": round(by_b / ms_b / 1e6, 1),
-            "frac": round(by_f / ms_f / 1e6 / 8000.0, 4),
+            "achieved": round(by_f / ms_f / 1e6, 1), "frac": round(by_f / ms_f / 1e6 / 8000.0, 4),
+            "traffic": 2924000000,      # forward kernels' L2->fabric bytes, PMC (profiles/r01_fft_pmc.txt: 874 + 27 + 1173 + 849 MB)
             "direct_equiv_tflops_fwd": round(2.0 * B * H * W * k * k * C * C / ms_f / 1e9, 1)}
 
 

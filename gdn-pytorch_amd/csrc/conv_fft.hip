@@ -168,7 +168,7 @@ template <bool DGRAD>
 __global__ __launch_bounds__(256, 4) void cgemm_bins_kernel(const float* __restrict__ A, const float* __restrict__ Wf,
                                                          float* __restrict__ Cm, int M, int Nc /* complex outputs */,
                                                          int Kc /* complex reduction */) {
-    constexpr int LDA = 36, LDB = DGRAD ? 64 : 20;
+    constexpr int LDA = 36;                                 // plane images: pitch 20 ([n][c]) or 64 ([n][c] rows, DGRAD)
     __shared__ __attribute__((aligned(16))) float As[64 * LDA], Bs[3 * (DGRAD ? 16 * 64 : 64 * 20)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int NT = Nc / 64, MT = (M + 63) / 64;

@@ -402,53 +402,103 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
 // even and odd tiles are written by two launches (parity): the first writer of a column stores (+ addsrc), the second adds.
 __global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __restrict__ S, float* __restrict__ dx, int lddx,
                                                                 const float* __restrict__ addsrc, int ld_add, FftGeom g,
-                                                                int parity, int Ho, int Wo, int off, int cq_shift) {
+                                                                int parity, int Ho, int Wo, int off, int cq_shift,
+                                                                const float* __restrict__ bnb_y, int ld_bnb,
+                                                                const float* __restrict__ bnb_co, int bnb_relu,
+                                                                float* __restrict__ bnb_partial) {
     // output image Ho x Wo; patch row j of tile row ty lands on output row ty*T - off + j  (off = pad for a zero-padded
     // layer: dx itself; off = 0 for a reflection-padded one: the padded-domain gradient, folded afterwards)
     // grid: x = (tile-of-this-parity / 4) * (C / 64) + channel chunk, y = output row, z = image; block = 4 tiles x 64 channels
+    // bnb_y != NULL: dx is the gradient of a train-mode BatchNorm's output z = [relu](BN(bnb_y)); every element whose value
+    // is final after this launch also feeds that layer's backward reduction (sum dz, sum dz*xhat; slot = workgroup), so
+    // the stand-alone reduce pass over (dx, y) disappears.  Both parity launches then use the parity-0 grid.
+    __shared__ float red[256 * 2];
     const int C = g.C, T = g.T;
     const int ntx = (g.tiles_x + 1 - parity) / 2;         // tiles of this parity per row
     const int txl = (blockIdx.x >> cq_shift) * 4 + (threadIdx.x >> 6);
-    if (txl >= ntx) return;
+    const bool live = txl < ntx;
+    if (!live && !bnb_y) return;
     const int c = (blockIdx.x & ((1 << cq_shift) - 1)) * 64 + (threadIdx.x & 63);
     const int tx = txl * 2 + parity, iy = blockIdx.y, b = blockIdx.z;
-    const int q = iy + off;
-    const int ty_a = q / T, j_a = q - ty_a * T;
-    float re[32], im[32];
+    float s1 = 0.f, s2 = 0.f;
+    if (live) {
+        const int q = iy + off;
+        const int ty_a = q / T, j_a = q - ty_a * T;
+        float re[32], im[32];
 #pragma unroll
-    for (int kx = 0; kx < FFT_NK; ++kx) { re[kx] = 0.f; im[kx] = 0.f; }
-    if (ty_a < g.tiles_y) {
-        const int t = (b * g.tiles_y + ty_a) * g.tiles_x + tx;
-        const float2* src = S + (((size_t)t * FFT_N + j_a) * FFT_NK) * C + c;
+        for (int kx = 0; kx < FFT_NK; ++kx) { re[kx] = 0.f; im[kx] = 0.f; }
+        if (ty_a < g.tiles_y) {
+            const int t = (b * g.tiles_y + ty_a) * g.tiles_x + tx;
+            const float2* src = S + (((size_t)t * FFT_N + j_a) * FFT_NK) * C + c;
 #pragma unroll
-        for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = *src; re[kx] = v.x; im[kx] = v.y; src += C; GDN_KEEP(src); }
-    }
-    if (ty_a >= 1 && j_a + T < FFT_N) {
-        const int t = (b * g.tiles_y + ty_a - 1) * g.tiles_x + tx;
-        const float2* src = S + (((size_t)t * FFT_N + j_a + T) * FFT_NK) * C + c;
-#pragma unroll
-        for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = *src; re[kx] += v.x; im[kx] += v.y; src += C; GDN_KEEP(src); }
-    }
-#pragma unroll
-    for (int kx = FFT_NK; kx < 32; ++kx) { re[kx] = re[32 - kx]; im[kx] = -im[32 - kx]; }
-    fft32<1>(re, im);
-    const int ix0 = tx * T - off;
-    float* dst = dx + ((size_t)(b * Ho + iy) * Wo + ix0) * lddx + c;               // may point before the row: only
-    const float* ad = addsrc ? addsrc + ((size_t)(b * Ho + iy) * Wo + ix0) * ld_add + c : nullptr;   // dereferenced in range
-    const bool has_next = tx + 1 < g.tiles_x;
-    const int km1 = g.k - 1;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const int ix = ix0 + j;
-        if (ix >= 0 && ix < Wo) {
-            const float val = re[j] * (1.0f / 1024.0f);
-            // odd tiles: columns shared with the even neighbours were stored by the first launch
-            const bool second = parity == 1 && (j < km1 || (j >= T && has_next));
-            if (second) *dst += val;
-            else *dst = ad ? val + *ad : val;
+            for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = *src; re[kx] = v.x; im[kx] = v.y; src += C; GDN_KEEP(src); }
         }
-        dst += lddx; GDN_KEEP(dst);
-        if (ad) { ad += ld_add; GDN_KEEP(ad); }
+        if (ty_a >= 1 && j_a + T < FFT_N) {
+            const int t = (b * g.tiles_y + ty_a - 1) * g.tiles_x + tx;
+            const float2* src = S + (((size_t)t * FFT_N + j_a + T) * FFT_NK) * C + c;
+#pragma unroll
+            for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = *src; re[kx] += v.x; im[kx] += v.y; src += C; GDN_KEEP(src); }
+        }
+#pragma unroll
+        for (int kx = FFT_NK; kx < 32; ++kx) { re[kx] = re[32 - kx]; im[kx] = -im[32 - kx]; }
+        fft32<1>(re, im);
+        const int ix0 = tx * T - off;
+        float* dst = dx + ((size_t)(b * Ho + iy) * Wo + ix0) * lddx + c;               // may point before the row: only
+        const float* ad = addsrc ? addsrc + ((size_t)(b * Ho + iy) * Wo + ix0) * ld_add + c : nullptr;   // dereferenced in range
+        const bool has_next = tx + 1 < g.tiles_x;
+        const int km1 = g.k - 1;
+        if (!bnb_y) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int ix = ix0 + j;
+                if (ix >= 0 && ix < Wo) {
+                    const float val = re[j] * (1.0f / 1024.0f);
+                    // odd tiles: columns shared with the even neighbours were stored by the first launch
+                    const bool second = parity == 1 && (j < km1 || (j >= T && has_next));
+                    if (second) *dst += val;
+                    else *dst = ad ? val + *ad : val;
+                }
+                dst += lddx; GDN_KEEP(dst);
+                if (ad) { ad += ld_add; GDN_KEEP(ad); }
+            }
+        } else {
+            const float* yb = bnb_y + ((size_t)(b * Ho + iy) * Wo + ix0) * ld_bnb + c;
+            const float bs = bnb_co[c], bt = bnb_co[C + c], bmu = bnb_co[2 * C + c], bis = bnb_co[3 * C + c];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int ix = ix0 + j;
+                if (ix >= 0 && ix < Wo) {
+                    float val = re[j] * (1.0f / 1024.0f);
+                    const bool shared = (j < km1 && tx >= 1) || (j >= T && has_next);     // a neighbour tile of the other parity also lands here
+                    if (parity == 1 && shared) val += *dst;
+                    else if (ad) val += *ad;
+                    *dst = val;
+                    if (parity == 1 || !shared) {                                       // final value of this element
+                        const float yv = *yb;
+                        float dz = val;
+                        if (bnb_relu && !(yv * bs + bt > 0.f)) dz = 0.f;
+                        s1 += dz; s2 += dz * ((yv - bmu) * bis);
+                    }
+                }
+                dst += lddx; GDN_KEEP(dst);
+                yb += ld_bnb; GDN_KEEP(yb);
+                if (ad) { ad += ld_add; GDN_KEEP(ad); }
+            }
+        }
+    }
+    if (bnb_y) {
+        red[threadIdx.x * 2] = s1; red[threadIdx.x * 2 + 1] = s2;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a1 += red[(j * 64 + threadIdx.x) * 2]; a2 += red[(j * 64 + threadIdx.x) * 2 + 1]; }
+            const int nbx = gridDim.x >> cq_shift;
+            const size_t slot = (((size_t)parity * gridDim.z + b) * gridDim.y + iy) * nbx + (blockIdx.x >> cq_shift);
+            const int ch = (blockIdx.x & ((1 << cq_shift) - 1)) * 64 + threadIdx.x;
+            bnb_partial[(slot * 2 + 0) * C + ch] = a1;
+            bnb_partial[(slot * 2 + 1) * C + ch] = a2;
+        }
     }
 }
 
@@ -486,8 +536,12 @@ __global__ __launch_bounds__(256) void fft_reflect_fold_kernel(const float* __re
 
 // forward: patch (halo = 1: rows/cols start at -pad, full 32; halo = 0: the T x T tile, zero padded) -> Xf[bin][tile][C]
 // two waves per SIMD: at four (128 VGPRs) the two 32-point transforms spill 44 dwords per lane and the kernel is 15 % slower
+// in_scale != NULL: the tensor read is the RAW output of the producer convolution and the layer input is
+// [relu](x * in_scale[c] + in_shift[c]) -- the producer's train-mode BatchNorm (+ReLU) applied on load, so that
+// activation is never written to memory (ResidualBlock AE_model_unet.py:49-54).  Padding stays zero.
 __global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ Xf,
-                                                        FftGeom g, int halo) {
+                                                        FftGeom g, int halo, const float* __restrict__ in_scale,
+                                                        const float* __restrict__ in_shift, int in_relu) {
     __shared__ float2 lds[FFT_LDS_ELEMS];
     // XCD-aware order: XCD j (= blockIdx & 7) owns the contiguous tile range [j, j+1) * ceil(M/8) and runs the channel
     // groups of one tile back to back, so the half cache lines the groups share and the halo rows / columns neighbouring
@@ -512,13 +566,17 @@ __global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restri
         const float* img = x + (size_t)b * g.H * g.W * ldx + cg;
         const int row_off = (row_ok ? iyr : 0) * g.W * ldx + c;
         int off_x = ix0 * ldx;                             // running ix * ldx (interior columns: no multiply per element)
+        const float is = in_scale ? in_scale[cg + c] : 1.f, it = in_scale ? in_shift[cg + c] : 0.f;
+        const float lo = in_relu ? 0.f : -3.402823466e38f;
 #pragma unroll
         for (int bb = 0; bb < 32; ++bb) {
             const int ix = ix0 + bb;
             const bool ok = row_ok && bb < nvalid && ix >= -lim && ix < g.W + lim;
             const bool inside = ix >= 0 && ix < g.W;
             const int ixr = ix < 0 ? -ix : 2 * g.W - 2 - ix;         // mirrored column (border patches only)
-            re[bb] = ok ? img[row_off + (inside ? off_x : ixr * ldx)] : 0.f;
+            float v = ok ? img[row_off + (inside ? off_x : ixr * ldx)] : 0.f;
+            if (in_scale) v = ok ? fmaxf(v * is + it, lo) : 0.f;
+            re[bb] = v;
             im[bb] = 0.f;
             off_x += ldx; GDN_KEEP(off_x);
         }
@@ -700,12 +758,12 @@ void launch_weights(const FftGeom& f, const float* w, float* Wf, hipStream_t st)
 
 extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w, float* y, int32_t ldy,
                                const float* addsrc, int32_t ld_add, float* stats, const float* ep_scale,
-                               const float* ep_shift, int32_t act, void* xf_out, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               const float* ep_shift, int32_t act, const float* in_scale, const float* in_shift,
+                               int32_t in_relu, void* xf_out, void* workspace, size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     FftGeom f;
     if (!fft_geom(g, f)) return GDN_ERR_UNSUPPORTED;
-    if (!x || !w || !y || (!ep_scale) != (!ep_shift)) return GDN_ERR_BAD_ARG;
+    if (!x || !w || !y || (!ep_scale) != (!ep_shift) || (!in_scale) != (!in_shift)) return GDN_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gdn_fftconv_fwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* p = (char*)workspace;
@@ -716,7 +774,8 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
         Xf = (float2*)xf_out;
         Wf = (float*)((char*)xf_out + al256((size_t)f.M * FFT_BINS * f.C * 8));
     }
-    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.C / FFT_CG * 8 * cdiv(f.M, 8)), dim3(512), 0, st, x, ldx, Xf, f, 1);
+    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.C / FFT_CG * 8 * cdiv(f.M, 8)), dim3(512), 0, st, x, ldx, Xf, f, 1, in_scale,
+                       in_shift, in_relu);
     launch_weights(f, w, Wf, st);
     hipLaunchKernelGGL(cgemm_bins_kernel<false>, dim3(cdiv(f.M, 64) * (f.N / 64) * FFT_BINS), dim3(256), 0, st,
                        (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, f.N, f.C);
@@ -736,15 +795,26 @@ extern "C" size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
            al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)FFT_BINS * 3 * f.C * f.N * 4) + padded;
 }
 
+// slots of the BatchNorm-backward partials the data-gradient epilogue can emit (0: not available for this layer)
+extern "C" int64_t gdn_fftconv_bnb_slots(const gdn_conv_geom* g) {
+    FftGeom f;
+    if (!fft_geom(g, f) || f.flip || f.reflect) return 0;
+    return (int64_t)2 * f.B * f.H * cdiv((f.tiles_x + 1) / 2, 4);
+}
+
 extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w, const void* xf,
-                               float* dx, int32_t ldx, const float* addsrc, int32_t ld_add, float* dw, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               float* dx, int32_t ldx, const float* addsrc, int32_t ld_add, float* dw,
+                               const float* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu,
+                               float* bnb_partial, int32_t phases, void* workspace, size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
     FftGeom f;
     if (!fft_geom(g, f) || f.flip) return GDN_ERR_UNSUPPORTED;
     if (!dy || (!dx && !dw) || (dx && !w && !xf) || (dw && !xf)) return GDN_ERR_BAD_ARG;
     if (dx && f.reflect && ((ldx % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
+    if (bnb_y && (!dx || !bnb_co || !bnb_partial)) return GDN_ERR_BAD_ARG;
+    if (bnb_y && f.reflect) return GDN_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < gdn_fftconv_bwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
+    if (phases == 0) phases = GDN_FFT_BWD_ALL;
     hipStream_t st = (hipStream_t)stream;
     const size_t cm = f.C > f.N ? f.C : f.N;
     char* p = (char*)workspace;
@@ -754,42 +824,30 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     float* Wf = (float*)p; p += al256((size_t)FFT_BINS * 3 * f.C * f.N * 4);   // weight-gradient products P, or the weight spectrum when the forward saved none
     float* dxp = (float*)p;          // reflection layers: gradient over the padded domain
     auto blocks = [](int64_t n) { const int64_t b = cdiv64(n, 256); return (unsigned)(b < 65536 * 8 ? b : 65536 * 8); };
-    // spectrum of the dy tiles (no halo: rows / columns >= T are the zero padding of the linear convolution)
-    FftGeom fd = f;
-    fd.C = f.N;
-    fd.reflect = 0;
-    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.N / FFT_CG * 8 * cdiv(f.M, 8)), dim3(512), 0, st, dy, ldy, Df, fd, 0);
-    // The weight-gradient chain (reduction GEMM + tap transform) and the data-gradient chain only share Df.  Each is
-    // HBM-latency-bound at ~3.3 of the ~6.3 TB/s a pure copy reaches, so with both wanted the first runs on a side stream
-    // next to the second (fork after the dy transform, join before returning: the workspace is free again for the caller).
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    static const bool overlap_ok = getenv("GDN_FFT_NO_OVERLAP") == nullptr;
-    hipStream_t sw = st;
-    if (dw && dx && overlap_ok) {
-        if (!side) {
-            if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
-                return GDN_ERR_LAUNCH;
-        }
-        if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return GDN_ERR_LAUNCH;
-        sw = side;
+    if (phases & GDN_FFT_BWD_TRANSFORM) {
+        // spectrum of the dy tiles (no halo: rows / columns >= T are the zero padding of the linear convolution)
+        FftGeom fd = f;
+        fd.C = f.N;
+        fd.reflect = 0;
+        hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.N / FFT_CG * 8 * cdiv(f.M, 8)), dim3(512), 0, st, dy, ldy, Df, fd, 0,
+                           (const float*)nullptr, (const float*)nullptr, 0);
     }
-    if (dw) {
+    // The weight-gradient chain (reduction GEMM + tap transform) and the data-gradient chain only share Df and use disjoint
+    // parts of the workspace, so a caller may run them as separate calls on two streams of its own (phases; the library
+    // itself holds no stream, event or other state).
+    if (dw && (phases & GDN_FFT_BWD_DW)) {
         float* P = Wf;
-        hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * FFT_BINS), dim3(256), 0, sw,
+        hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * FFT_BINS), dim3(256), 0, st,
                            (const float*)Df, (const float*)xf, P, f.M, f.N, f.C);
 #define GDN_TAPS(KK) case KK: \
-            hipLaunchKernelGGL(fft_wgrad_taps_kernel<KK>, dim3(f.N * f.C / 64), dim3(256), 0, sw, (const float*)P, dw, f.N, f.C); \
+            hipLaunchKernelGGL(fft_wgrad_taps_kernel<KK>, dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
             break;
         switch (f.k) {
             GDN_TAPS(3) GDN_TAPS(5) GDN_TAPS(7) GDN_TAPS(9)
         }
 #undef GDN_TAPS
-        if (sw != st && hipEventRecord(ev_join, sw) != hipSuccess) return GDN_ERR_LAUNCH;
     }
-    if (dx) {
+    if (dx && (phases & GDN_FFT_BWD_DX)) {
         const float* Wsaved = xf ? (const float*)((const char*)xf + al256((size_t)f.M * FFT_BINS * f.C * 8)) : nullptr;
         if (!Wsaved) launch_weights(f, w, Wf, st);
         hipLaunchKernelGGL(cgemm_bins_kernel<true>, dim3(cdiv(f.M, 64) * (f.C / 64) * FFT_BINS), dim3(256), 0, st,
@@ -803,19 +861,21 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         const int Ho = f.reflect ? f.H + 2 * f.pad : f.H, Wo = f.reflect ? f.W + 2 * f.pad : f.W;
         for (int parity = 0; parity < 2; ++parity) {
             const int ntx = (f.tiles_x + 1 - parity) / 2;
-            if (ntx == 0) continue;
-            const dim3 gr(cdiv(ntx, 4) << cq_shift, Ho, f.B);
+            if (ntx == 0 && !bnb_y) continue;
+            // with BatchNorm partials both launches use the parity-0 grid (every slot is written)
+            const dim3 gr(cdiv(bnb_y ? (f.tiles_x + 1) / 2 : ntx, 4) << cq_shift, Ho, f.B);
             if (f.reflect)
                 hipLaunchKernelGGL(ifft_rows_overlap_kernel, gr, dim3(256), 0, st,
-                                   (const float2*)R, dxp, f.C, (const float*)nullptr, 0, f, parity, Ho, Wo, 0, cq_shift);
+                                   (const float2*)R, dxp, f.C, (const float*)nullptr, 0, f, parity, Ho, Wo, 0, cq_shift,
+                                   (const float*)nullptr, 0, (const float*)nullptr, 0, (float*)nullptr);
             else
                 hipLaunchKernelGGL(ifft_rows_overlap_kernel, gr, dim3(256), 0, st,
-                                   (const float2*)R, dx, ldx, addsrc, ld_add, f, parity, Ho, Wo, f.pad, cq_shift);
+                                   (const float2*)R, dx, ldx, addsrc, ld_add, f, parity, Ho, Wo, f.pad, cq_shift,
+                                   bnb_y, ld_bnb, bnb_co, bnb_relu, bnb_partial);
         }
         if (f.reflect)
             hipLaunchKernelGGL(fft_reflect_fold_kernel, dim3(blocks((int64_t)f.B * f.H * f.W * (f.C / 4))), dim3(256), 0, st,
                                (const float*)dxp, dx, ldx, addsrc, ld_add, f.B, f.H, f.W, f.C, f.pad);
     }
-    if (sw != st && hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return GDN_ERR_LAUNCH;
     return gdn_launch_status();
 }

@@ -41,9 +41,16 @@ __device__ __forceinline__ bool wino_decode(int M, int q_shift, int& t, int& c) 
 }
 
 // V = B^T d B of the 4x4 patch whose top-left corner is (2a - pad_off, 2b - pad_off)
-__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V, WinoGeom g) {
+// in_scale != NULL: x is the RAW output of the producer convolution and the layer input is
+// [relu](x * in_scale[c] + in_shift[c]) -- the producer's train-mode BatchNorm (+ReLU) applied on load, so that
+// activation is never written to memory (ResidualBlock AE_model_unet.py:49-54).  Padding stays zero.
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V, WinoGeom g,
+                                                         const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                         int in_relu) {
     int t, c;
     if (!wino_decode(g.M, g.cq_shift, t, c)) return;
+    const float is = in_scale ? in_scale[c] : 1.f, it = in_scale ? in_shift[c] : 0.f;
+    const float lo = in_relu ? 0.f : -3.402823466e38f;
     const int b2 = t % g.tiles_x, a2 = (t / g.tiles_x) % g.tiles_y, img = t / (g.tiles_x * g.tiles_y);
     float d[4][4];
     const int lim = g.reflect ? 1 : 0;      // mirrored border rows / columns -1 and H (W); anything further out reads zero
@@ -57,7 +64,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         for (int j = 0; j < 4; ++j) {
             const int ix = 2 * b2 - g.pad_off + j;
             const int ixr = ix < 0 ? -ix : (ix >= g.W ? 2 * g.W - 2 - ix : ix);
-            d[i][j] = (row_ok && ix >= -lim && ix < g.W + lim) ? row[(size_t)ixr * ldx] : 0.f;
+            const bool ok = row_ok && ix >= -lim && ix < g.W + lim;
+            float v = ok ? row[(size_t)ixr * ldx] : 0.f;
+            if (in_scale) v = ok ? fmaxf(v * is + it, lo) : 0.f;
+            d[i][j] = v;
         }
     }
     float r[4][4];
@@ -274,11 +284,15 @@ __global__ __launch_bounds__(256, 4) void wino_gemm_tn_kernel(const float* __res
 }
 
 // y = A^T m A (2x2 outputs per tile) with the conv_igemm epilogue; stats slot = group of 4 tiles
+// bnb_y != NULL (data gradient): y is the gradient of a train-mode BatchNorm's output z = [relu](BN(bnb_y)); `stats` then
+// receives that layer's backward partials (sum dz, sum dz*xhat per slot; bnb_co = [scale, shift, mean, invstd][Nout])
+// instead of sum / sum of squares, so the stand-alone reduce pass over (dy, y) disappears.
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mo, float* __restrict__ y, int ldy,
                                                           const float* __restrict__ addsrc, int ld_add,
                                                           float* __restrict__ stats, const float* __restrict__ ep_scale,
                                                           const float* __restrict__ ep_shift, int act, WinoGeom g, int Nout,
-                                                          int q_shift) {
+                                                          int q_shift, const float* __restrict__ bnb_y, int ld_bnb,
+                                                          const float* __restrict__ bnb_co, int bnb_relu) {
     __shared__ float red[256 * 2];
     int t, n;
     const bool live = wino_decode(g.M, q_shift, t, n);
@@ -296,6 +310,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) { r[0][j] = m[0][j] + m[1][j] + m[2][j]; r[1][j] = m[1][j] - m[2][j] - m[3][j]; }
         const float es = ep_scale ? ep_scale[n] : 1.f, et = ep_shift ? ep_shift[n] : 0.f;
+        float bsc = 0.f, bt = 0.f, bmu = 0.f, bis = 0.f;
+        if (bnb_y) { bsc = bnb_co[n]; bt = bnb_co[Nout + n]; bmu = bnb_co[2 * Nout + n]; bis = bnb_co[3 * Nout + n]; }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float o[2] = {r[i][0] + r[i][1] + r[i][2], r[i][1] - r[i][2] - r[i][3]};
@@ -304,13 +320,19 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                 const int oy = 2 * a2 + i, ox = 2 * b2 + j;
                 if (oy < g.Ho && ox < g.Wo) {
                     float val = o[j];
-                    s1 += val; s2 += val * val;
+                    if (!bnb_y) { s1 += val; s2 += val * val; }
                     if (ep_scale) val = val * es + et;
                     if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
                     const size_t px = (size_t)(img * g.Ho + oy) * g.Wo + ox;
                     if (addsrc) val += addsrc[px * ld_add + n];
                     if (act & GDN_ACT_TANH) val = tanhf(val);
                     y[px * ldy + n] = val;
+                    if (bnb_y) {
+                        const float yv = bnb_y[px * ld_bnb + n];
+                        float dz = val;
+                        if (bnb_relu && !(yv * bsc + bt > 0.f)) dz = 0.f;
+                        s1 += dz; s2 += dz * ((yv - bmu) * bis);
+                    }
                 }
             }
         }
@@ -432,12 +454,13 @@ extern "C" int64_t gdn_winoconv_stats_slots(const gdn_conv_geom* g) {
 
 extern "C" int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w, float* y, int32_t ldy,
                                 const float* addsrc, int32_t ld_add, float* stats, const float* ep_scale,
-                                const float* ep_shift, int32_t act, void* state_out, void* workspace,
+                                const float* ep_shift, int32_t act, const float* in_scale, const float* in_shift,
+                                int32_t in_relu, void* state_out, void* workspace,
                                 size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     WinoGeom f;
     if (!wino_geom(g, f)) return GDN_ERR_UNSUPPORTED;
-    if (!x || !w || !y || (!ep_scale) != (!ep_shift)) return GDN_ERR_BAD_ARG;
+    if (!x || !w || !y || (!ep_scale) != (!ep_shift) || (!in_scale) != (!in_shift)) return GDN_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gdn_winoconv_fwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* p = (char*)workspace;
@@ -445,11 +468,13 @@ extern "C" int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t 
     float* U = (float*)p; p += u_bytes(f);
     float* Mo = (float*)p;
     if (state_out) V = (float*)state_out;
-    hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(f.M, 4) << f.cq_shift), dim3(256), 0, st, x, ldx, V, f);
+    hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(f.M, 4) << f.cq_shift), dim3(256), 0, st, x, ldx, V, f, in_scale, in_shift,
+                       in_relu);
     hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 0);
     launch_wino_gemm((const float*)V, (const float*)U, Mo, f.M, f.N, f.C, st);
     hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, (const float*)Mo, y, ldy, addsrc,
-                       ld_add, stats, ep_scale, ep_shift, act, f, f.N, f.nq_shift);
+                       ld_add, stats, ep_scale, ep_shift, act, f, f.N, f.nq_shift, (const float*)nullptr, 0,
+                       (const float*)nullptr, 0);
     return gdn_launch_status();
 }
 
@@ -464,13 +489,23 @@ extern "C" size_t gdn_winoconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     return (vd > m_bytes(f) ? vd : m_bytes(f)) + u_bytes(f) + (eo > u_bytes(f) ? eo : u_bytes(f)) + padded;
 }
 
+// slots of the BatchNorm-backward partials the data-gradient epilogue can emit (0: not available for this layer)
+extern "C" int64_t gdn_winoconv_bnb_slots(const gdn_conv_geom* g) {
+    WinoGeom f;
+    if (!wino_geom(g, f) || f.reflect) return 0;
+    return cdiv(f.M, 4);
+}
+
 extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w, const void* state,
-                                float* dx, int32_t ldx, const float* addsrc, int32_t ld_add, float* dw, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                float* dx, int32_t ldx, const float* addsrc, int32_t ld_add, float* dw,
+                                const float* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu,
+                                float* bnb_partial, void* workspace, size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
     WinoGeom f;
     if (!wino_geom(g, f)) return GDN_ERR_UNSUPPORTED;
     if (!dy || (!dx && !dw) || (dx && !w) || (dw && !state)) return GDN_ERR_BAD_ARG;
+    if (bnb_y && (!dx || !bnb_co || !bnb_partial)) return GDN_ERR_BAD_ARG;
+    if (bnb_y && f.reflect) return GDN_ERR_UNSUPPORTED;
     if (dx && f.reflect && ((ldx % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < gdn_winoconv_bwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -500,12 +535,13 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
             out = Eo + (size_t)WINO_BINS * fd.M * f.C;                 // padded-domain gradient, behind the GEMM output
             ld_out = f.C;
         }
-        hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(fd.M, 4) << fd.cq_shift), dim3(256), 0, st, dy, ldy, Vd, fd);
+        hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(fd.M, 4) << fd.cq_shift), dim3(256), 0, st, dy, ldy, Vd, fd,
+                           (const float*)nullptr, (const float*)nullptr, 0);
         hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 1);
         launch_wino_gemm((const float*)Vd, (const float*)U, Eo, fd.M, f.C, f.N, st);
         hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(fd.M, 4) << fd.nq_shift), dim3(256), 0, st, (const float*)Eo, out, ld_out,
-                           f.reflect ? (const float*)nullptr : addsrc, ld_add, (float*)nullptr, (const float*)nullptr,
-                           (const float*)nullptr, 0, fd, f.C, fd.nq_shift);
+                           f.reflect ? (const float*)nullptr : addsrc, ld_add, bnb_y ? bnb_partial : (float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, 0, fd, f.C, fd.nq_shift, bnb_y, ld_bnb, bnb_co, bnb_relu);
         if (f.reflect) {
             const int64_t nb = cdiv64((int64_t)f.B * f.H * f.W * (f.C / 4), 256);
             hipLaunchKernelGGL(wino_reflect_fold_kernel, dim3((unsigned)(nb < 65536 * 8 ? nb : 65536 * 8)), dim3(256), 0, st,

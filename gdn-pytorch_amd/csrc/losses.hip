@@ -37,16 +37,20 @@ inline int loss_blocks(int64_t n) {
 
 __device__ __forceinline__ float sgn(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 
-// out = scale * sum(part[0..n)) (+ previous *out when accumulate)
+// out = scale * sum(part[0..n)) (+ previous *out when accumulate);  total (nullable) = out + *plus + *plus2: the sum of a
+// step's loss terms (trainer.py:456, :757) without a separate add kernel
 __global__ __launch_bounds__(256) void finalize_sum_kernel(const double* __restrict__ part, int n, double scale,
-                                                           int accumulate, float* out) {
+                                                           int accumulate, float* out, const float* plus = nullptr,
+                                                           const float* plus2 = nullptr, float* total = nullptr) {
     __shared__ double sh[4];
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) s += part[i];
     s = block_sum_d256(s, sh);
     if (threadIdx.x == 0) {
         const double r = s * scale;
-        *out = accumulate ? (float)((double)*out + r) : (float)r;
+        const float o = accumulate ? (float)((double)*out + r) : (float)r;
+        *out = o;
+        if (total) *total = (plus ? o + *plus : o) + (plus2 ? *plus2 : 0.f);
     }
 }
 
@@ -266,7 +270,8 @@ extern "C" int gdn_berhu_masked(const float* out, const float* gt, const float* 
 }
 
 extern "C" int gdn_sobel_l1(const float* pred, const float* gt, int32_t B, int32_t H, int32_t W, float weight,
-                            float* loss, float* dpred, void* workspace, size_t workspace_bytes, void* stream) {
+                            float* loss, float* dpred, const float* plus, float* total, void* workspace,
+                            size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!pred || !gt || !loss || B <= 0 || H <= 0 || W <= 0) return GDN_ERR_BAD_ARG;
     const int64_t n = (int64_t)B * H * W;
@@ -278,12 +283,13 @@ extern "C" int gdn_sobel_l1(const float* pred, const float* gt, int32_t B, int32
         hipLaunchKernelGGL(sobel_bwd_kernel, dim3(nb), dim3(256), 0, ST(stream), (const float*)w.fa, (const float*)w.fb,
                            B, H, W, weight / (float)n, dpred);
     hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)w.part, nb,
-                       (double)weight / (double)n, 0, loss);
+                       (double)weight / (double)n, 0, loss, plus, (const float*)nullptr, total);
     return gdn_launch_status();
 }
 
 extern "C" int gdn_smoothness(const float* depth, const float* img, int32_t Ci, int32_t B, int32_t H, int32_t W,
-                              float* loss, float* ddepth, void* workspace, size_t workspace_bytes, void* stream) {
+                              float* loss, float* ddepth, const float* plus, const float* plus2, float* total,
+                              void* workspace, size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!depth || !img || !loss || Ci <= 0 || B <= 0 || H <= 0 || W <= 0) return GDN_ERR_BAD_ARG;
     const int64_t n = (int64_t)B * H * W;
@@ -292,7 +298,7 @@ extern "C" int gdn_smoothness(const float* depth, const float* img, int32_t Ci, 
     const int nb = loss_blocks(n);
     hipLaunchKernelGGL(smooth_kernel, dim3(nb), dim3(256), 0, ST(stream), depth, img, Ci, B, H, W, w.part, ddepth);
     hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)w.part, nb,
-                       0.1 / (double)n, 0, loss);
+                       0.1 / (double)n, 0, loss, plus, plus2, total);
     return gdn_launch_status();
 }
 

@@ -26,9 +26,10 @@ inline int stream_blocks(int64_t n_items, int threads = 256, int cap = 2048) {
 __global__ __launch_bounds__(256) void bn_finalize_train_kernel(
     const float* __restrict__ stats, int64_t slots, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
-    float* scale, float* shift, float* mean_out, float* invstd_out) {
+    float* scale, float* shift, float* mean_out, float* invstd_out, long long* num_batches_tracked) {
     __shared__ double sh[8];
     const int c = blockIdx.x;
+    if (num_batches_tracked && c == 0 && threadIdx.x == 0) *num_batches_tracked += 1;   // nn.BatchNorm2d bookkeeping
     double s1 = 0.0, s2 = 0.0;
     for (int64_t s = threadIdx.x; s < slots; s += 256) {
         s1 += (double)stats[(s * 2 + 0) * C + c];
@@ -389,6 +390,23 @@ __global__ void add_kernel(const void* __restrict__ a, const void* __restrict__ 
     for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         st1_any(o, i, ld1_any(a, i, dt & 1) + ld1_any(b, i, dt & 2), dt & 4);
 }
+// out[p][c] = a[p][c] (+ b[p][c]); each tensor with its own pixel pitch (channel slices of wider tensors)
+__global__ __launch_bounds__(256) void add_pitched_kernel(const void* __restrict__ a, int lda, const void* __restrict__ b, int ldb,
+                                                          void* __restrict__ o, int ldo, int64_t npix, int C, int dt, int sh) {
+    const int cq = C >> 2;
+    const int64_t total = npix * cq;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        SPLIT_PIX_C(i, cq, sh, pix, c);
+        f32x4 v = ld4_any(a, pix * lda + c, dt & 1);
+        if (b) v += ld4_any(b, pix * ldb + c, dt & 2);
+        st4_any(o, pix * ldo + c, v, dt & 4);
+    }
+}
+// out[i] = x[i] * (*s): the chain rule through a scalar loss whose upstream gradient lives on the device
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ o, int64_t n) {
+    const float k = *s;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) o[i] = x[i] * k;
+}
 __global__ void cast_kernel(const void* __restrict__ a, void* __restrict__ o, int64_t n, int dt) {
     const int64_t n4 = n >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
@@ -453,11 +471,13 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
 
 extern "C" int gdn_bn_finalize_train(const float* stats, int64_t slots, int32_t C, int64_t count, const float* gamma,
                                      const float* beta, float* running_mean, float* running_var, float momentum,
-                                     float eps, float* scale, float* shift, float* mean, float* invstd, void* stream) {
+                                     float eps, float* scale, float* shift, float* mean, float* invstd,
+                                     int64_t* num_batches_tracked, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!stats || slots <= 0 || C <= 0 || count <= 0 || !scale || !shift) return GDN_ERR_BAD_ARG;
     hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(256), 0, ST(stream), stats, slots, C, (double)count,
-                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
+                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd,
+                       (long long*)num_batches_tracked);
     return gdn_launch_status();
 }
 
@@ -500,20 +520,28 @@ extern "C" size_t gdn_bn_bwd_workspace_bytes(int64_t npix, int32_t C) {
 extern "C" int gdn_bn_bwd(const void* dout, int32_t ld_dout, const void* y, int32_t ldy, const float* gamma,
                           const float* scale, const float* shift, const float* mean, const float* invstd, void* dy,
                           int32_t ld_dy, float* dgamma, float* dbeta, int64_t npix, int32_t C, int32_t relu,
+                          const float* ext_partial, int64_t ext_slots,
                           void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     (void)gamma;
     if (!dout || !y || !scale || !shift || !mean || !invstd || !dy || npix <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
+    if (ext_partial && (ext_slots <= 0 || ext_slots > 0x7fffffff)) return GDN_ERR_BAD_ARG;
     if ((C % 4) || (ldy % 4) || (ld_dout % 4) || (ld_dy % 4)) return GDN_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < gdn_bn_bwd_workspace_bytes(npix, C)) return GDN_ERR_WORKSPACE;
     const int nblk = bnb_blocks(npix);
     float* partial = (float*)workspace;
     float* k1 = partial + (size_t)nblk * 2 * C;
     float* k2 = k1 + C;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, ST(stream), dout, ld_dout, y, ldy, scale, shift,
-                       mean, invstd, partial, npix, C, relu, dtypes);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, ST(stream), (const float*)partial, nblk, C,
-                       (double)npix, dgamma, dbeta, k1, k2);
+    if (ext_partial) {
+        // pass 1 already happened in the epilogue of the kernel that produced dout (gdn_winoconv_bwd / gdn_fftconv_bwd)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, ST(stream), ext_partial, (int)ext_slots, C,
+                           (double)npix, dgamma, dbeta, k1, k2);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, ST(stream), dout, ld_dout, y, ldy, scale, shift,
+                           mean, invstd, partial, npix, C, relu, dtypes);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, ST(stream), (const float*)partial, nblk, C,
+                           (double)npix, dgamma, dbeta, k1, k2);
+    }
     if (dtypes && (C % 8) == 0 && (ldy % 8) == 0 && (ld_dout % 8) == 0 && (ld_dy % 8) == 0)
         hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(stream_blocks(npix * (C / 8))), dim3(256), 0, ST(stream), dout,
                            ld_dout, y, ldy, scale, shift, mean, invstd, (const float*)k1, (const float*)k2, dy, ld_dy,
@@ -635,6 +663,23 @@ extern "C" int gdn_add(const void* a, const void* b, void* out, int64_t n, int32
     hipLaunchKernelGGL(add_kernel, dim3(stream_blocks(n / 4 + 1)), dim3(256), 0, ST(stream), a, b, out, n, dtypes);
     return gdn_launch_status();
 }
+extern "C" int gdn_add_pitched(const void* a, int32_t lda, const void* b, int32_t ldb, void* out, int32_t ld_out,
+                               int64_t npix, int32_t C, int32_t dtypes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    if (!a || !out || npix <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
+    if ((C % 4) || (lda % 4) || (ld_out % 4) || (b && (ldb % 4))) return GDN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(add_pitched_kernel, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, ST(stream), a, lda, b, ldb, out,
+                       ld_out, npix, C, dtypes, pow2_shift(C / 4));
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_scale_dev(const float* x, const float* s, float* out, int64_t n, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    if (!x || !s || !out || n <= 0) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(stream_blocks(n)), dim3(256), 0, ST(stream), x, s, out, n);
+    return gdn_launch_status();
+}
+
 extern "C" int gdn_cast(const void* src, void* dst, int64_t n, int32_t dtypes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!src || !dst || n <= 0) return GDN_ERR_BAD_ARG;
@@ -675,7 +720,7 @@ extern "C" int gdn_adam_step_dev(float* p, const float* g, float* m, float* v, i
     return gdn_launch_status();
 }
 
-extern "C" int gdn_version(void) { return 100; }
+extern "C" int gdn_version(void) { return 200; }
 
 extern "C" const char* gdn_strerror(int status) {
     switch (status) {

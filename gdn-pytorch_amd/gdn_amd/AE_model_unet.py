@@ -112,8 +112,13 @@ class _Bridge(torch.autograd.Function):
                 continue
             ctx.add_grad(o, E.grad_to_nhwc(g))
         ctx.backward()
+        if trainable:
+            arena.finish_grads()
         for p, old in pending:       # a caller-owned .grad existed: accumulate like autograd would
-            p.grad.add_(old)
+            if p.grad is None:
+                p.grad = old
+            else:
+                p.grad.add_(old)
         dx = None
         if ctx.input_needs_grad:
             g = ctx.pop_grad(ctx.input)
@@ -138,7 +143,8 @@ class ResidualBlock(_HipModule):
 
     def run(self, ctx, x):
         m = self.main
-        a = E.conv_bn_act(ctx, x, m[0], m[1], relu=True)
+        # a = relu(bn1(conv1 x)) has one consumer: deferred into conv2's patch loader (never written in train mode)
+        a = E.conv_bn_act(ctx, x, m[0], m[1], relu=True, defer=True)
         return E.conv_bn_act(ctx, a, m[3], m[4], relu=False, residual=x)
 
     def _run(self, ctx, x):

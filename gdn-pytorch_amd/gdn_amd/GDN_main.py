@@ -3,9 +3,11 @@
 Mirrors GDN_main.py:22-307 of the reference for the hot path: same flags
 (option.py), same mode dispatch (:150-201), same optimiser settings
 (Adam, betas from --momentum/--beta, eps 1e-8, weight decay hard-wired to 5e-4,
-:157,173).  ``--gpu_num`` selects devices as in the reference when launched as a
-single process; under ``python -m torch.distributed.run`` each rank takes its
-LOCAL_RANK GPU and gradients are all-reduced with RCCL (nn.DataParallel is gone).
+:157,173).  ``--gpu_num 0,1,2,3`` trains on the listed GPUs from one command like the
+reference (README.md:82): ``main`` starts one child process per device
+(``distributed.launch_ranks``) and gradients are all-reduced with RCCL
+(nn.DataParallel is gone); under ``python -m torch.distributed.run`` each rank
+takes its LOCAL_RANK GPU instead.
 
 The KITTI/NYU file pipeline (datasets_list.py / transform_list.py) is host I/O
 outside the hot path: pass ``--synthetic`` for KITTI-shaped random batches, or
@@ -52,10 +54,13 @@ def run(args, train_loader=None, val_loader=None):
             # the reference's file layout (datasets_list.py:61-76); decode on the host, augment on the GPU
             if args.dataset != "KITTI":
                 raise RuntimeError("only the KITTI pipeline (GDN_main.py:56-80) is implemented; NYU is out of scope")
-            train_set = SequenceFolder(args.data, args, seed=args.seed + rank, train=True, mode=args.mode)
+            train_set = SequenceFolder(args.data, args, seed=args.seed, train=True, mode=args.mode)     # same file order on every rank
             val_set = SequenceFolder(args.data, args, seed=args.seed, train=False, mode=args.mode)
+            # data parallelism: a common shuffle, rank r takes samples r, r + world, ... (each sample once per epoch);
+            # --batch_size is per GPU, so the global batch is world * batch_size at the given learning rate
             train_loader = GpuAugmentLoader(train_set, args.batch_size, dev, train=True, seed=args.seed + rank,
-                                            workers=args.workers, drop_last=True)
+                                            workers=args.workers, drop_last=True, rank=rank, world=world,
+                                            order_seed=args.seed + 1)
             val_loader = GpuAugmentLoader(val_set, args.batch_size, dev, train=False, workers=args.workers)
         elif not args.synthetic:
             raise RuntimeError("dataset directory %r not found; pass a KITTI root laid out like the reference's "
@@ -76,6 +81,7 @@ def run(args, train_loader=None, val_loader=None):
 
     if args.mode == 'DtoD':
         G = AutoEncoder_DtoD(norm=args.norm, input_dim=1, height=H, width=W).to(dev).compute_dtype(args.dtype)
+        D.broadcast_parameters(G)             # rank 0's weights / BN buffers everywhere (identical seeds make this a no-op)
         opt = _make_optimizer(G, args)
         loss = train_AE_DtoD(args, G, None, None, opt, train_loader, val_loader, args.batch_size, args.epochs,
                              args.lr, logger, None)
@@ -94,6 +100,7 @@ def run(args, train_loader=None, val_loader=None):
             if getattr(args, "latent_grad", False):
                 G.requires_grad_(False)       # the guide only passes d(latent)/d(outputs) through
         R = AutoEncoder_2(norm=args.norm, input_dim=3, height=H, width=W).to(dev).compute_dtype(args.dtype)
+        D.broadcast_parameters(R)
         opt = _make_optimizer(R, args)
         return train_AE_RtoD(args, R, G, None, None, opt, train_loader, val_loader, args.batch_size, args.epochs,
                              args.lr, logger, None)
@@ -115,7 +122,16 @@ def run(args, train_loader=None, val_loader=None):
 
 
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = option.parse_args(argv)
+    devices = [d for d in str(args.gpu_num).split(",") if d != ""]
+    if len(devices) > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # the reference's `--gpu_num 0,1,2,3` (README.md:82): one process per listed GPU, started before anything here
+        # touches the GPU; this parent only waits and propagates a failure
+        rc = D.launch_ranks(argv, devices)
+        if rc != 0:
+            sys.exit(rc)
+        return None
     return run(args)
 
 

@@ -45,38 +45,42 @@ _SIGS = {
     "gdn_fftconv_fwd_workspace_bytes": (_sz, [_PG]),
     "gdn_fftconv_spectrum_bytes": (_sz, [_PG]),
     "gdn_fftconv_stats_slots": (_i64, [_PG]),
-    "gdn_fftconv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _P, _P, _sz, _P]),
+    "gdn_fftconv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _P, _P, _i32, _P, _P, _sz, _P]),
     "gdn_fftconv_bwd_workspace_bytes": (_sz, [_PG]),
-    "gdn_fftconv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _P, _i32, _P, _i32, _P, _P, _sz, _P]),
+    "gdn_fftconv_bnb_slots": (_i64, [_PG]),
+    "gdn_fftconv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _P, _i32, _P, _i32, _P, _P, _i32, _P, _i32, _P, _i32, _P, _sz, _P]),
     "gdn_winoconv_fwd_workspace_bytes": (_sz, [_PG]),
     "gdn_winoconv_state_bytes": (_sz, [_PG]),
     "gdn_winoconv_stats_slots": (_i64, [_PG]),
-    "gdn_winoconv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _P, _P, _sz, _P]),
+    "gdn_winoconv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _P, _P, _i32, _P, _P, _sz, _P]),
     "gdn_winoconv_bwd_workspace_bytes": (_sz, [_PG]),
+    "gdn_winoconv_bnb_slots": (_i64, [_PG]),
     "gdn_winoconv_gemm": (c_int32, [_PG, _P, _P, _P, _P]),
-    "gdn_winoconv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _P, _i32, _P, _i32, _P, _P, _sz, _P]),
+    "gdn_winoconv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _P, _i32, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _sz, _P]),
     "gdn_transpose_taps": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P]),
     "gdn_cast": (c_int32, [_P, _P, _i64, _i32, _P]),
     "gdn_weight_to_tapmajor": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P]),
     "gdn_weight_from_tapmajor": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P]),
-    "gdn_bn_finalize_train": (c_int32, [_P, _i64, _i32, _i64, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _P]),
+    "gdn_bn_finalize_train": (c_int32, [_P, _i64, _i32, _i64, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _P, _P]),
     "gdn_bn_eval_coeffs": (c_int32, [_P, _P, _P, _P, _f, _i32, _P, _P, _P]),
     "gdn_bn_apply": (c_int32, [_P, _i32, _P, _P, _P, _i32, _P, _i32, _i64, _i32, _i32, _i32, _P]),
     "gdn_bn_bwd_workspace_bytes": (_sz, [_i64, _i32]),
-    "gdn_bn_bwd": (c_int32, [_P, _i32, _P, _i32, _P, _P, _P, _P, _P, _P, _i32, _P, _P, _i64, _i32, _i32, _P, _sz, _i32, _P]),
+    "gdn_bn_bwd": (c_int32, [_P, _i32, _P, _i32, _P, _P, _P, _P, _P, _P, _i32, _P, _P, _i64, _i32, _i32, _P, _i64, _P, _sz, _i32, _P]),
     "gdn_bn_eval_bwd": (c_int32, [_P, _i32, _P, _i32, _P, _P, _P, _i32, _i64, _i32, _i32, _i32, _P]),
     "gdn_upsample2x_fwd": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "gdn_upsample2x_bwd": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "gdn_nchw_to_nhwc": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _i32, _P]),
     "gdn_nhwc_to_nchw": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _i32, _P]),
     "gdn_add": (c_int32, [_P, _P, _P, _i64, _i32, _P]),
+    "gdn_add_pitched": (c_int32, [_P, _i32, _P, _i32, _P, _i32, _i64, _i32, _i32, _P]),
+    "gdn_scale_dev": (c_int32, [_P, _P, _P, _i64, _P]),
     "gdn_tanh_bwd": (c_int32, [_P, _P, _P, _i64, _P]),
     "gdn_fill": (c_int32, [_P, _f, _i64, _P]),
     "gdn_loss_workspace_bytes": (_sz, [_i64]),
     "gdn_absdiff_max": (c_int32, [_P, _P, _i64, _P, _P]),
     "gdn_berhu_masked": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, POINTER(c_int32), _P, _P, _P, _P, _sz, _P]),
-    "gdn_sobel_l1": (c_int32, [_P, _P, _i32, _i32, _i32, _f, _P, _P, _P, _sz, _P]),
-    "gdn_smoothness": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P, _P, _P, _sz, _P]),
+    "gdn_sobel_l1": (c_int32, [_P, _P, _i32, _i32, _i32, _f, _P, _P, _P, _P, _P, _sz, _P]),
+    "gdn_smoothness": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "gdn_mse": (c_int32, [_P, _P, _i64, _f, _i32, _P, _P, _sz, _i32, _P]),
     "gdn_kitti_augment_workspace_bytes": (_sz, [_i32]),
     "gdn_kitti_augment": (c_int32, [_P, _i32, _i32, _i32, _i32, _i32, _P, _i32, _P, _P, _sz, _P]),

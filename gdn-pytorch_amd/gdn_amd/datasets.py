@@ -102,17 +102,28 @@ class GpuAugmentLoader:
     dataset: indexable of (gt, rgb, sparse) raw HWC arrays, uint8 (or float32: bytescaled on the GPU like imresize).
     train=False applies the validation transform (ArrayToTensor + Normalize) and keeps the order."""
 
-    def __init__(self, dataset, batch_size, device, train=True, seed=None, shuffle=None, workers=0, drop_last=False):
+    def __init__(self, dataset, batch_size, device, train=True, seed=None, shuffle=None, workers=0, drop_last=False,
+                 rank=0, world=1, order_seed=None):
+        """rank / world: data-parallel sharding like DistributedSampler -- every rank shuffles with the SAME order_seed and
+        takes order[rank::world], so one epoch visits each sample once over all ranks (batch_size is per rank: the global
+        batch is world * batch_size).  The augmentation draws stay rank-specific (seed)."""
         self.ds, self.bs, self.dev, self.train = dataset, int(batch_size), torch.device(device), train
         self.shuffle = train if shuffle is None else shuffle
         self.drop_last = drop_last
+        self.rank, self.world = int(rank), max(1, int(world))
         self.py_rng, self.np_rng = random.Random(seed), np.random.RandomState(seed)
-        self.order_rng = random.Random(None if seed is None else seed + 1)
+        if order_seed is None:
+            order_seed = None if seed is None else seed + 1
+        self.order_rng = random.Random(order_seed)
         self.pool = cf.ThreadPoolExecutor(workers) if workers > 0 else None
         self.last_params = None
 
-    def __len__(self):
+    def _shard_len(self):
         n = len(self.ds)
+        return n // self.world if self.world > 1 else n       # equal shards: every rank runs the same number of steps
+
+    def __len__(self):
+        n = self._shard_len()
         return n // self.bs if self.drop_last else (n + self.bs - 1) // self.bs
 
     def _fetch(self, idxs):
@@ -125,10 +136,16 @@ class GpuAugmentLoader:
         t = torch.from_numpy(a)
         return t.pin_memory().to(self.dev, non_blocking=True) if self.dev.type == "cuda" else t
 
-    def __iter__(self):
+    def _epoch_order(self):
         order = list(range(len(self.ds)))
         if self.shuffle:
             self.order_rng.shuffle(order)
+        if self.world > 1:
+            order = order[self.rank::self.world][:self._shard_len()]
+        return order
+
+    def __iter__(self):
+        order = self._epoch_order()
         for b in range(len(self)):
             idxs = order[b * self.bs:(b + 1) * self.bs]
             samples = self._fetch(idxs)

@@ -17,10 +17,18 @@ def env_rank():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+def forced():
+    """GDN_FORCE_DIST=1: run the data-parallel machinery (process group, bucketed async all-reduce, GradReducer overlap)
+    even at world size 1.  A 1-rank RCCL all-reduce is the identity, but it goes through RCCL's own stream, its
+    async_op work handles and their ordering against the kernels just enqueued on the compute stream -- the part of the
+    path that gloo does not model and a 1-GPU box can still exercise."""
+    return os.environ.get("GDN_FORCE_DIST") == "1"
+
+
 def init(backend=None):
-    """Initialise torch.distributed from the launcher's environment (no-op for world size 1)."""
+    """Initialise torch.distributed from the launcher's environment (no-op for world size 1 unless GDN_FORCE_DIST=1)."""
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -35,6 +43,11 @@ def init(backend=None):
 
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def active():
+    """True when gradients go through the all-reduce path."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or forced())
 
 
 def rank():
@@ -53,7 +66,7 @@ def flat_buckets(flat, bucket_elems=BUCKET_ELEMS):
 
 def allreduce_flat(flat, bucket_elems=BUCKET_ELEMS, async_op=True):
     """SUM all-reduce a flat buffer in buckets; returns the work handles (already waited if not async)."""
-    if world_size() == 1:
+    if not active():
         return []
     works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in flat_buckets(flat, bucket_elems)]
     if not async_op:
@@ -125,7 +138,7 @@ class GradReducer:
 
 def attach_reducer(model):
     """Enable overlapped gradient reduction for `model` (no-op for world size 1)."""
-    if world_size() == 1 or os.environ.get("GDN_OVERLAP_ALLREDUCE", "1") == "0":
+    if not active() or os.environ.get("GDN_OVERLAP_ALLREDUCE", "1") == "0":
         return None
     ar = getattr(model, "_gdn_param_arena", None)
     if ar is None:
@@ -143,7 +156,7 @@ def sync_gradients(model, optimizer=None):
     If a GradReducer overlapped the reduction with backward, this only waits for its tail."""
     ws = world_size()
     ar = getattr(model, "_gdn_param_arena", None)
-    if ws == 1:
+    if not active():
         return
     if ar is None:
         raise RuntimeError("sync_gradients: model has no gradient arena yet (run a forward/backward first)")
@@ -159,7 +172,7 @@ def sync_gradients(model, optimizer=None):
 
 def broadcast_parameters(model, src=0):
     """Make every rank start from rank `src`'s weights and BN buffers (once, at start)."""
-    if world_size() == 1:
+    if not active():
         return
     ar = getattr(model, "_gdn_param_arena", None)
     if ar is not None:
@@ -174,6 +187,60 @@ def broadcast_parameters(model, src=0):
 
 def allreduce_max_scalar(t):
     """4-byte MAX all-reduce (the optional global BerHu threshold)."""
-    if world_size() > 1:
+    if active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
+
+
+# ----------------------------------------------------------------------------
+# The reference's multi-GPU idiom: `python GDN_main.py DATA --gpu_num 0,1,2,3` (README.md:82, GDN_main.py:24,150-173)
+# trains on four GPUs from ONE command (nn.DataParallel).  Here that command becomes one process per listed device.
+# ----------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(argv, devices, module="gdn_amd.GDN_main", extra_env=None, timeout=None):
+    """Start one fresh child process per entry of `devices` running ``python -m <module> <argv>`` with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, wait for all of them and return the first non-zero exit code (0 if
+    all succeeded; the others are terminated as soon as one fails).  The parent must not have touched the GPU: the
+    children are started with subprocess (fork + exec of a new interpreter), never by exec-ing over an initialised
+    process.  LOCAL_RANK indexes the visible-device list, which is set to exactly `devices` for every child (RCCL needs
+    to see its peers' devices for xGMI peer access)."""
+    import subprocess
+    import sys
+    import time
+    world = len(devices)
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        if devices and all(d is not None for d in devices):
+            env["HIP_VISIBLE_DEVICES"] = ",".join(str(d) for d in devices)
+        env["GDN_SPAWNED"] = "1"
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable, "-m", module, *argv], env=env))
+    rc, t0 = 0, time.time()
+    alive = list(procs)
+    while alive:
+        for pr in list(alive):
+            code = pr.poll()
+            if code is None:
+                continue
+            alive.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in alive:               # a dead rank would leave the others hanging in a collective
+                    other.terminate()
+        if timeout is not None and time.time() - t0 > timeout and alive:
+            for other in alive:
+                other.kill()
+            rc = rc or 124
+        time.sleep(0.05)
+    return rc

@@ -20,6 +20,9 @@ _FUSE_EVAL_BN = os.environ.get("GDN_FUSE_EVAL_BN", "1") != "0"     # A/B switch 
 _FFT_MIN_K = int(os.environ.get("GDN_FFT_MIN_K", "5"))
 # fp32 3x3 stride-1 zero-padded layers on 64..512 channels run as Winograd F(2x2,3x3) (csrc/conv_wino.hip)
 _WINOGRAD = os.environ.get("GDN_WINOGRAD", "1") != "0"
+# train-mode BatchNorm fusion (A/B switch): scale/shift/ReLU of a ResidualBlock's first half applied in the consumer's
+# loader, BatchNorm-backward reductions emitted by the data-gradient epilogues
+_FUSE_TRAIN_BN = os.environ.get("GDN_FUSE_TRAIN_BN", "1") != "0"
 _GRAPH_EPOCH = 0
 
 
@@ -89,9 +92,14 @@ class ParamArena:
         """Called by writers that bypass torch (the fused Adam kernel): parameters changed."""
         self.generation += 1
 
+    def versions(self):
+        """Sum of the parameters' own torch version counters: `p.data = view` gives every parameter a counter of its own,
+        so load_state_dict / p.copy_() / a stock torch optimizer bump THESE and not the arena tensor's."""
+        return sum(p._version for p, _, _, _ in self.items)
+
     def bf16_data(self):
         """bf16 shadow of the parameter arena (same offsets/layout), re-cast when the master changed."""
-        key = (self.generation, self.data._version, _GRAPH_EPOCH)
+        key = (self.generation, self.data._version, self.versions(), _GRAPH_EPOCH)
         if self.data16 is None:
             self.data16 = torch.empty(self.numel, dtype=torch.bfloat16, device=self.device)
             self._key16 = None
@@ -123,16 +131,47 @@ class ParamArena:
         raise KeyError("parameter not in arena")
 
     def bind_grads(self):
-        """Point every .grad at its arena slice.  Returns the params whose existing grad must be accumulated."""
+        """Point every .grad at its arena slice for one backward.  Returns the params whose existing, caller-owned grad
+        must be accumulated afterwards.  A .grad that already IS the arena slice (a second backward without zero_grad:
+        gradient accumulation) is carried over: the kernels overwrite their slices, finish_grads() adds the carry back."""
         self._gv = {}
+        self._written = set()
+        self._bound_before = set()
+        self._carry = None
         accumulate = []
         for p, o, n, tr in self.items:
             gv = self._view(self.grad, o, p.shape, tr)
-            if p.grad is not None and p.grad.data_ptr() != gv.data_ptr():
-                accumulate.append((p, p.grad))
+            if p.grad is not None:
+                if p.grad.data_ptr() == gv.data_ptr():
+                    self._bound_before.add(id(p))
+                else:
+                    accumulate.append((p, p.grad))
             p.grad = gv
             self._gv[id(p)] = gv
+        if self._bound_before:
+            self._carry = self.grad.clone()
+            for p, o, n, tr in self.items:
+                if id(p) not in self._bound_before:
+                    self._carry[o:o + n].zero_()
         return accumulate
+
+    def mark_written(self, params):
+        self._written.update(id(p) for p in params)
+
+    def finish_grads(self):
+        """After the tape ran: parameters no kernel wrote a gradient for (requires_grad False, an unused branch) get the
+        state autograd would leave -- their previous gradient, or None -- instead of whatever an earlier step left in the
+        arena; a carried gradient (see bind_grads) is added back."""
+        for p, o, n, tr in self.items:
+            if id(p) in self._written:
+                continue
+            if id(p) in self._bound_before:
+                self.grad[o:o + n].zero_()            # the carry holds the old value
+            else:
+                p.grad = None
+        if self._carry is not None:
+            self.grad.add_(self._carry)
+            self._carry = None
 
 
 def ensure_arena(module, device):
@@ -156,11 +195,24 @@ class Ctx:
         self.input = None                      # the model's NHWC input buffer
         self.input_needs_grad = input_needs_grad
         self.reducer = None                    # distributed.GradReducer while a backward is running
+        self.bn_src = {}                       # id(activation) -> BnOut of the train-mode BatchNorm that produced it
 
     def grads_done(self, *params):
         """Parameters whose gradient has just been written (lets the all-reduce start early)."""
+        if self.arena is not None:
+            self.arena.mark_written(params)
         if self.reducer is not None:
             self.reducer.mark(params)
+
+    def claim(self, x):
+        """Called by whatever consumes activation x FIRST in the forward.  That consumer's backward runs after every other
+        consumer's, so its data gradient (with the accumulated `addsrc`) is the final value of dL/dx: if x came out of a
+        train-mode BatchNorm, the kernel writing it can also emit that BatchNorm's backward reduction (BnOut.partial).
+        Returns the BnOut (once), or None."""
+        if isinstance(x, BnOut):
+            return x if x.claim() else None
+        info = self.bn_src.pop(id(x), None)
+        return info if info is not None and info.claim() else None
 
     def wants_dx(self, x):
         """Data gradients stop at the network input unless the caller asked for them."""
@@ -173,7 +225,7 @@ class Ctx:
         if old is None:
             self.grads[k] = (t, g)
         else:
-            self.grads[k] = (t, ops.add(_dense(old[1]), _dense(g), out_dtype=t.dtype))
+            self.grads[k] = (t, _add(old[1], g, t.dtype))
 
     def pop_grad_as(self, t, dtype):
         """pop_grad, converted to `dtype` (the head's fp32 input gradient meeting a bf16 consumer)."""
@@ -195,12 +247,48 @@ class Ctx:
 
 
 def _dense(t):
+    """Dense copy of a channel-slice view (the gradient of a torch.cat half); contiguous tensors pass through."""
     if t.is_contiguous():
         return t
-    # channel-slice views are compacted by the add-with-zero-stride-free path
+    if t.dim() == 4 and t.shape[3] % 4 == 0 and t.stride(3) == 1:
+        return ops.add_pitched(t)
     out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
     out.copy_(t)
     return out
+
+
+def _add(a, b, out_dtype):
+    if a.is_contiguous() and b.is_contiguous():
+        return ops.add(a, b, out_dtype=out_dtype)
+    if a.dim() == 4 and a.shape[3] % 4 == 0 and a.stride(3) == 1 and b.stride(3) == 1:
+        return ops.add_pitched(a, b, out_dtype=out_dtype)
+    return ops.add(_dense(a), _dense(b), out_dtype=out_dtype)
+
+
+class BnOut:
+    """What a train-mode conv + BatchNorm (+ReLU) layer leaves behind for its backward: the raw conv output y, the
+    coefficients co = [scale, shift, mean, invstd] and, once the kernel that writes the final dL/d(output) has run, that
+    kernel's per-slot partial sums of the BatchNorm backward reduction (`partial`, or None: run the reduce pass).
+
+    It doubles as the DEFERRED activation of a ResidualBlock's first half: `a = relu(bn1(conv1 x))` has exactly one
+    consumer (conv2), whose patch loader applies scale / shift / ReLU on the fly, so `a` is never written to memory
+    (AE_model_unet.py:49-54; north_star "conv+BN+ReLU fused").  A consumer that cannot do that calls dense()."""
+
+    def __init__(self, y, co, relu):
+        self.y, self.co, self.relu = y, co, relu
+        self.partial = None
+        self._claimed = False
+        self._dense = None
+        self.shape, self.dtype = y.shape, y.dtype
+
+    def claim(self):
+        first, self._claimed = not self._claimed, True
+        return first
+
+    def dense(self, out_dtype=None):
+        if self._dense is None:
+            self._dense = ops.bn_apply(self.y, self.co[0], self.co[1], self.relu, None, out_dtype=out_dtype)
+        return self._dense
 
 
 def _conv_op(mod, reflect):
@@ -254,8 +342,10 @@ def _wgrad_into(ctx, mod, x, dy, x2=None):
 
 def _eval_coeffs(bn):
     """scale/shift of an eval-mode BatchNorm, cached until its tensors change."""
+    ar = getattr(bn.weight, "_gdn_arena", None)       # the fused Adam writes gamma / beta behind torch's version counters
     key = (_GRAPH_EPOCH, getattr(bn, "_gdn_stats_ver", 0), bn.running_mean._version, bn.running_var._version,
-           bn.weight._version, bn.bias._version, bn.running_mean.data_ptr(), bn.weight.data_ptr())
+           bn.weight._version, bn.bias._version, bn.running_mean.data_ptr(), bn.weight.data_ptr(),
+           None if ar is None else ar.generation)
     c = getattr(bn, "_gdn_eval_cache", None)
     if c is None or c[0] != key:
         co = ops.bn_eval_coeffs(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
@@ -264,10 +354,19 @@ def _eval_coeffs(bn):
     return c[1]
 
 
-def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_dx=True):
-    """[relu](BN(conv(cat(x, x2)))) (+ residual): ConvBlock / ResidualBlock halves / ConvTBlock."""
+def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_dx=True, defer=False):
+    """[relu](BN(conv(cat(x, x2)))) (+ residual): ConvBlock / ResidualBlock halves / ConvTBlock.
+
+    x may be a BnOut (the deferred activation of the previous layer): the transform-domain paths apply its scale / shift /
+    ReLU while loading; any other path materialises it first.  defer=True (the caller guarantees a single consumer)
+    returns this layer's output as a BnOut instead of running the BatchNorm-apply pass, when the layer is a train-mode
+    fp32 one without a residual."""
     op = _conv_op(conv, reflect)
     ldt = _layer_dtype(ctx, conv)
+    xin = ctx.claim(x)                   # BnOut of the train-mode BatchNorm that produced x, if we are its first consumer
+    lazy = isinstance(x, BnOut)
+    if x2 is not None:
+        ctx.claim(x2)
     if x.dtype != ldt:
         raise GdnError("layer %d->%d computes in %s but its input is %s" % (conv.in_channels, conv.out_channels, ldt, x.dtype))
     w, tr = _w_for(ctx, conv, ldt)
@@ -281,38 +380,55 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     # the two transform-domain paths share one call shape: forward (+ saved state), backward from that state
     alt_fwd = op.fft_fwd if use_fft else op.wino_fwd if use_wino else None
     alt_bwd = op.fft_bwd if use_fft else op.wino_bwd if use_wino else None
+    bnb_slots = op.fft_bnb_slots if use_fft else op.wino_bnb_slots if use_wino else None
     state_kw = "spectrum" if use_fft else "state"
     bstate_kw = "xf" if use_fft else "state"
     use_fft = use_fft or use_wino
+    in_kw = {}
+    xt = x                               # the tensor the conv kernels read
+    if lazy:
+        if use_fft and _FUSE_TRAIN_BN:
+            in_kw = dict(in_affine=(x.co[0], x.co[1]), in_relu=x.relu)
+            xt = x.y
+        else:
+            xt = x.dense(ctx.dtype)      # (the direct kernels' loaders go straight to LDS: materialise)
     xf = None
     keep_xf = use_fft and ctx.record and conv.weight.requires_grad
     if bn.training:
         if use_fft:
-            r = alt_fwd(x, w, stats=True, **{state_kw: keep_xf})
+            r = alt_fwd(xt, w, stats=True, **{state_kw: keep_xf}, **in_kw)
             y, st = r[0], r[1]
             xf = r[2] if keep_xf else None
         else:
-            y, st = op.fwd(x, w, x2=x2, stats=True)
+            y, st = op.fwd(xt, w, x2=x2, stats=True)
         count = y.shape[0] * y.shape[1] * y.shape[2]
         mom = 0.1 if bn.momentum is None else bn.momentum
-        co = ops.bn_finalize_train(st, count, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, mom, bn.eps)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        co = ops.bn_finalize_train(st, count, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, mom, bn.eps,
+                                   num_batches_tracked=bn.num_batches_tracked)
         bn._gdn_stats_ver = getattr(bn, "_gdn_stats_ver", 0) + 1
     else:
         co = _eval_coeffs(bn)
     fused = (_FUSE_EVAL_BN and not bn.training and ldt == ctx.dtype and not (relu and residual is not None)
              and (residual is None or residual.dtype == ldt) and conv.out_channels > 1)
+    out_info = None
     if fused:
         # eval-mode BN folded into the conv epilogue: conv + scale/shift + ReLU (+ residual) in one pass
         if use_fft:
-            y = a = alt_fwd(x, w, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
+            y = a = alt_fwd(xt, w, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual, **in_kw)
         else:
-            y = a = op.fwd(x, w, x2=x2, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
+            y = a = op.fwd(xt, w, x2=x2, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
     else:
         if not bn.training:
-            y = alt_fwd(x, w) if use_fft else op.fwd(x, w, x2=x2)
-        a = ops.bn_apply(y, co[0], co[1], relu, residual, out_dtype=ctx.dtype)
+            y = alt_fwd(xt, w, **in_kw) if use_fft else op.fwd(xt, w, x2=x2)
+        else:
+            out_info = BnOut(y, co, relu)
+        if (defer and out_info is not None and residual is None and _FUSE_TRAIN_BN and ldt == torch.float32
+                and ctx.dtype == torch.float32):
+            a = out_info                                  # scale / shift / ReLU happen in the consumer's loader
+        else:
+            a = ops.bn_apply(y, co[0], co[1], relu, residual, out_dtype=ctx.dtype)
+            if out_info is not None and ctx.record and _FUSE_TRAIN_BN:
+                ctx.bn_src[id(a)] = out_info
     if ctx.record:
         in_hw = (x.shape[1], x.shape[2])
         bn_training = bn.training
@@ -329,7 +445,8 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                 ctx.add_grad(residual, da)
             if bn_training:
                 dy = ops.bn_bwd(da, y, bn.weight.data, co, relu, bn.weight.grad if not frozen else None,
-                                bn.bias.grad if not frozen else None, out_dtype=ldt)
+                                bn.bias.grad if not frozen else None, out_dtype=ldt, partial=out_info.partial)
+                out_info.partial = None
             else:
                 dy = ops.bn_eval_bwd(da, y, co, (2 if fused else 1) if relu else 0, out_dtype=ldt)
             want_dx = need_dx and ctx.wants_dx(x)
@@ -341,15 +458,25 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                     if gv is None:
                         raise GdnError("weight.grad is not tap-major")
                 if gv is not None or want_dx:
+                    bnb = None
+                    if xin is not None and want_dx and xin.y.dtype == torch.float32:
+                        # x = [relu](BN_train(xin.y)) and this data gradient is its final gradient: emit the producer's
+                        # BatchNorm-backward partial sums from the epilogue that writes dx
+                        slots = bnb_slots(x.shape[0], x.shape[1], x.shape[2])
+                        if slots > 0:
+                            part = torch.empty((slots, 2, conv.in_channels), dtype=torch.float32, device=dy.device)
+                            bnb = (xin.y, xin.co, xin.relu, part)
                     dx = alt_bwd(dy, w, in_hw, dw_tap=gv, need_dx=want_dx, **{bstate_kw: xf},
-                                    addsrc=ctx.pop_grad_as(x, ldt) if want_dx else None)
+                                 addsrc=ctx.pop_grad_as(x, ldt) if want_dx else None, bnb=bnb)
                     if want_dx:
                         ctx.grads[id(x)] = (x, dx)
+                        if bnb is not None:
+                            xin.partial = bnb[3]
                 if not frozen:
                     ctx.grads_done(bn.weight, bn.bias, conv.weight)
                 return
             if not frozen:
-                _wgrad_into(ctx, conv, x, dy, x2)
+                _wgrad_into(ctx, conv, xt, dy, x2)
                 ctx.grads_done(bn.weight, bn.bias, conv.weight)
             if want_dx:
                 wt = ops.transpose_taps(_w_tap(conv)[0], dtype=ldt)
@@ -369,6 +496,7 @@ def conv_head_tanh(ctx, x, conv):
     """Final 9x9 (transposed) conv to one channel + tanh (AE_model_unet.py:362-363, :570-571).
     On the bf16 path only x is bf16: weights, the depth map and this layer's backward are fp32."""
     op = _conv_op(conv, 0)
+    ctx.claim(x)
     w, tr = _w_tap(conv)
     out = op.fwd(x, w, act=ops.ACT_TANH)
     if ctx.record:
@@ -392,6 +520,7 @@ def conv_head_tanh(ctx, x, conv):
 def conv_plain(ctx, x, conv, x2=None):
     """Bare convolution without norm/activation (legacy AutoEncoder 1x1 after cat, :210)."""
     op = _conv_op(conv, 0)
+    ctx.claim(x)
     w, tr = _w_for(ctx, conv, _layer_dtype(ctx, conv))
     y = op.fwd(x, w, x2=x2)
     if ctx.record:
@@ -400,6 +529,7 @@ def conv_plain(ctx, x, conv, x2=None):
 
 
 def upsample(ctx, x, align_corners=False):
+    ctx.claim(x)
     y = ops.upsample2x(x, align_corners)
     if ctx.record:
         def bwd():

@@ -5,6 +5,7 @@ fp32, channel stride 1; a channel slice of a wider tensor is allowed (pixel
 pitch ``ld`` = stride(2)).  Everything launches on torch's current stream.
 """
 import ctypes
+import os
 
 import torch
 
@@ -67,13 +68,31 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device, tag="ws"):
-    """Grow-only scratch buffer per (device, tag); reused across calls on one stream."""
-    key = (device, tag)
+    """Grow-only scratch buffer per (device, tag, current stream): calls on one stream are ordered, so they may share
+    scratch memory; two streams (or threads driving their own streams) never do.  Inside a hipGraph capture a missing or
+    too small buffer is allocated as a plain temporary instead (it lives in the graph's private pool and must not be
+    handed to later eager calls)."""
+    key = (device, tag, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+        if not torch.cuda.is_current_stream_capturing():
+            _ws_cache[key] = buf
     return buf
+
+
+_side_streams = {}
+_FFT_OVERLAP = os.environ.get("GDN_FFT_NO_OVERLAP") is None
+
+
+def side_stream(device):
+    """The caller-owned second stream gdn_fftconv_bwd's weight-gradient chain runs on (one per device; every use is a
+    fork from / join into the caller's current stream, so sharing it only serialises)."""
+    st = _side_streams.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[device] = st
+    return st
 
 
 class Conv:
@@ -179,9 +198,10 @@ class Conv:
         return int(lib.gdn_fftconv_stats_slots(ref))
 
     def fft_fwd(self, x, w_tap, stats=False, addsrc=None, spectrum=False, out=None, stats_out=None, affine=None,
-                act=ACT_NONE):
+                act=ACT_NONE, in_affine=None, in_relu=False):
         """y = conv(x) (+ addsrc) through the frequency domain; returns y, then the BatchNorm partials when `stats`,
-        then the input spectrum (opaque uint8 buffer for fft_bwd) when `spectrum`."""
+        then the input spectrum (opaque uint8 buffer for fft_bwd) when `spectrum`.
+        in_affine = (scale, shift): x is a raw conv output and the layer input is [relu](x*scale + shift), applied on load."""
         _chk(x, "x"); _chk(w_tap, "w")
         B, H, W, C1 = x.shape
         _, ref, Ho, Wo = self.geom(B, H, W)
@@ -197,14 +217,25 @@ class Conv:
         ws = workspace(nb, x.device, "fft")
         lib.gdn_fftconv_fwd(ref, _p(x), _ld(x), _p(w_tap), _p(y), _ld(y), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
                             _p(st), _p(affine[0]) if affine else None, _p(affine[1]) if affine else None, int(act),
-                            _p(xf), _p(ws), nb, stream())
+                            _p(in_affine[0]) if in_affine else None, _p(in_affine[1]) if in_affine else None,
+                            1 if in_relu else 0, _p(xf), _p(ws), nb, stream())
         res = (y,) + ((st,) if stats else ()) + ((xf,) if spectrum else ())
         return res if len(res) > 1 else y
 
-    def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None):
+    def fft_bnb_slots(self, B, H, W):
+        _, ref, _, _ = self.geom(B, H, W)
+        return int(lib.gdn_fftconv_bnb_slots(ref))
+
+    def wino_bnb_slots(self, B, H, W):
+        _, ref, _, _ = self.geom(B, H, W)
+        return int(lib.gdn_winoconv_bnb_slots(ref))
+
+    def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None, bnb=None):
         """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's saved state xf:
         input + weight spectra) from one transform of dy.  w_tap is the FORWARD tap-major weight [k*k, Cout, Cin]; it is
-        only read when xf is None."""
+        only read when xf is None.
+        bnb = (y_raw, coeffs[4,Cin], relu, partial_out): dx is the gradient of [relu](BN_train(y_raw)); the epilogue also
+        writes that BatchNorm's backward partials (see gdn_fftconv_bwd)."""
         _chk(dy, "dy")
         B = dy.shape[0]
         H, W = in_hw
@@ -216,9 +247,25 @@ class Conv:
             raise GdnError("fft_bwd: dy shape %s does not match layer output" % (tuple(dy.shape),))
         dx = torch.empty((B, H, W, self.cin), dtype=torch.float32, device=dy.device) if need_dx else None
         ws = workspace(nb, dy.device, "fft")
-        lib.gdn_fftconv_bwd(ref, _p(dy), _ld(dy), _p(w_tap), _p(xf), _p(dx),
-                            0 if dx is None else _ld(dx), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
-                            _p(dw_tap), _p(ws), nb, stream())
+        by, bco, brelu, bpart = bnb if (bnb is not None and need_dx) else (None, None, False, None)
+
+        def call(phases, st):
+            lib.gdn_fftconv_bwd(ref, _p(dy), _ld(dy), _p(w_tap), _p(xf), _p(dx),
+                                0 if dx is None else _ld(dx), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
+                                _p(dw_tap), _p(by), 0 if by is None else _ld(by), _p(bco), 1 if brelu else 0, _p(bpart),
+                                phases, _p(ws), nb, st)
+        if dw_tap is not None and need_dx and _FFT_OVERLAP:
+            # the two chains only share the spectrum of dy and are each latency-bound: the weight-gradient chain runs on a
+            # second stream of OURS next to the data-gradient chain (fork after the transform, join before returning)
+            main = torch.cuda.current_stream(dy.device)
+            side = side_stream(dy.device)
+            call(1, main.cuda_stream)
+            side.wait_stream(main)
+            call(2, side.cuda_stream)
+            call(4, main.cuda_stream)
+            main.wait_stream(side)
+        else:
+            call(0, stream())
         return dx
 
     # ---- Winograd F(2x2,3x3) path (csrc/conv_wino.hip): 3x3 stride-1 zero-padded fp32 layers with 64..512 channels ----
@@ -226,7 +273,8 @@ class Conv:
         _, ref, _, _ = self.geom(B, H, W)
         return int(lib.gdn_winoconv_state_bytes(ref)) > 0
 
-    def wino_fwd(self, x, w_tap, stats=False, addsrc=None, state=False, affine=None, act=ACT_NONE):
+    def wino_fwd(self, x, w_tap, stats=False, addsrc=None, state=False, affine=None, act=ACT_NONE, in_affine=None,
+                 in_relu=False):
         """y = conv3x3(x) (+ epilogue) by Winograd F(2x2,3x3); returns y, then the BatchNorm partials when `stats`, then
         the transformed input (opaque buffer for wino_bwd) when `state`."""
         _chk(x, "x"); _chk(w_tap, "w")
@@ -242,7 +290,8 @@ class Conv:
         ws = workspace(nb, x.device, "fft")
         lib.gdn_winoconv_fwd(ref, _p(x), _ld(x), _p(w_tap), _p(y), _ld(y), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
                              _p(st), _p(affine[0]) if affine else None, _p(affine[1]) if affine else None, int(act),
-                             _p(sv), _p(ws), nb, stream())
+                             _p(in_affine[0]) if in_affine else None, _p(in_affine[1]) if in_affine else None,
+                             1 if in_relu else 0, _p(sv), _p(ws), nb, stream())
         res = (y,) + ((st,) if stats else ()) + ((sv,) if state else ())
         return res if len(res) > 1 else y
 
@@ -251,7 +300,7 @@ class Conv:
         _, ref, _, _ = self.geom(B, H, W)
         lib.gdn_winoconv_gemm(ref, _p(V), _p(U), _p(Mo), stream())
 
-    def wino_bwd(self, dy, w_tap, in_hw, state=None, dw_tap=None, need_dx=True, addsrc=None):
+    def wino_bwd(self, dy, w_tap, in_hw, state=None, dw_tap=None, need_dx=True, addsrc=None, bnb=None):
         """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's `state`).
         w_tap is the FORWARD tap-major weight [9, Cout, Cin]."""
         _chk(dy, "dy")
@@ -265,8 +314,10 @@ class Conv:
             raise GdnError("wino_bwd: dy shape %s does not match layer output" % (tuple(dy.shape),))
         dx = torch.empty((B, H, W, self.cin), dtype=torch.float32, device=dy.device) if need_dx else None
         ws = workspace(nb, dy.device, "fft")
+        by, bco, brelu, bpart = bnb if (bnb is not None and need_dx) else (None, None, False, None)
         lib.gdn_winoconv_bwd(ref, _p(dy), _ld(dy), _p(w_tap), _p(state), _p(dx), 0 if dx is None else _ld(dx), _p(addsrc),
-                             0 if addsrc is None else _ld(addsrc), _p(dw_tap), _p(ws), nb, stream())
+                             0 if addsrc is None else _ld(addsrc), _p(dw_tap), _p(by), 0 if by is None else _ld(by), _p(bco),
+                             1 if brelu else 0, _p(bpart), _p(ws), nb, stream())
         return dx
 
     def wgrad(self, x, dy, dw_tap, ci_off=0, cfg=0):
@@ -327,11 +378,14 @@ def weight_from_tapmajor(w_tap, k, transposed):
     return out
 
 
-def bn_finalize_train(stats, count, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM, eps=BN_EPS):
+def bn_finalize_train(stats, count, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM, eps=BN_EPS,
+                      num_batches_tracked=None):
     slots, _, C = stats.shape
     co = torch.empty((4, C), dtype=torch.float32, device=stats.device)   # scale, shift, mean, invstd
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+        raise GdnError("num_batches_tracked must be a device int64 tensor")
     lib.gdn_bn_finalize_train(_p(stats), slots, C, int(count), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                              momentum, eps, _p(co[0]), _p(co[1]), _p(co[2]), _p(co[3]), stream())
+                              momentum, eps, _p(co[0]), _p(co[1]), _p(co[2]), _p(co[3]), _p(num_batches_tracked), stream())
     return co
 
 
@@ -350,16 +404,17 @@ def bn_apply(y, scale, shift, relu, residual=None, out=None, out_dtype=None):
     return o
 
 
-def bn_bwd(dout, y, gamma, coeffs, relu, dgamma, dbeta, out_dtype=None):
-    """coeffs = [scale, shift, mean, invstd] from bn_finalize_train. Returns dy."""
+def bn_bwd(dout, y, gamma, coeffs, relu, dgamma, dbeta, out_dtype=None, partial=None):
+    """coeffs = [scale, shift, mean, invstd] from bn_finalize_train. Returns dy.
+    partial [slots,2,C]: the reduce pass was done by the epilogue that wrote dout (fft_bwd / wino_bwd `bnb`)."""
     B, H, W, C = y.shape
     npix = B * H * W
     dy = torch.empty((B, H, W, C), dtype=out_dtype or y.dtype, device=y.device)
     nb = int(lib.gdn_bn_bwd_workspace_bytes(npix, C))
     ws = workspace(nb, y.device, "bnbwd")
     lib.gdn_bn_bwd(_p(dout), _ld(dout), _p(y), _ld(y), _p(gamma), _p(coeffs[0]), _p(coeffs[1]), _p(coeffs[2]),
-                   _p(coeffs[3]), _p(dy), _ld(dy), _p(dgamma), _p(dbeta), npix, C, 1 if relu else 0, _p(ws), nb,
-                   _mask(dout, y, dy), stream())
+                   _p(coeffs[3]), _p(dy), _ld(dy), _p(dgamma), _p(dbeta), npix, C, 1 if relu else 0,
+                   _p(partial), 0 if partial is None else partial.shape[0], _p(ws), nb, _mask(dout, y, dy), stream())
     return dy
 
 
@@ -413,6 +468,21 @@ def add(a, b, out_dtype=None):
     return o
 
 
+def add_pitched(a, b=None, out_dtype=None):
+    """Dense a (+ b) of [B,H,W,C] tensors that may be channel slices of wider ones (b None: compacting copy)."""
+    B, H, W, C = a.shape
+    o = torch.empty((B, H, W, C), dtype=out_dtype or a.dtype, device=a.device)
+    lib.gdn_add_pitched(_p(a), _ld(a), _p(b), 0 if b is None else _ld(b), _p(o), C, B * H * W, C, _mask(a, b, o), stream())
+    return o
+
+
+def scale_dev(x, s):
+    """x * s with s a 0-dim device tensor (no host sync, no torch kernel)."""
+    o = torch.empty_like(x)
+    lib.gdn_scale_dev(_p(x), _p(s), _p(o), x.numel(), stream())
+    return o
+
+
 def tanh_bwd(dout, out):
     r = torch.empty_like(out)
     lib.gdn_tanh_bwd(_p(dout), _p(out), _p(r), out.numel(), stream())
@@ -449,16 +519,18 @@ def berhu_masked(out, gt, sparse, box, dout, loss, ext_max=None):
                          _p(ext_max), _p(loss), _p(dout), _p(ws), nb, stream())
 
 
-def sobel_l1(pred, gt, weight, dpred, loss):
+def sobel_l1(pred, gt, weight, dpred, loss, plus=None, total=None):
+    """total (0-dim device tensor) = loss + plus: the step's loss sum comes out of the same kernel."""
     B, _, H, W = pred.shape
     ws, nb = _loss_ws(B * H * W, pred.device)
-    lib.gdn_sobel_l1(_p(pred), _p(gt), B, H, W, float(weight), _p(loss), _p(dpred), _p(ws), nb, stream())
+    lib.gdn_sobel_l1(_p(pred), _p(gt), B, H, W, float(weight), _p(loss), _p(dpred), _p(plus), _p(total), _p(ws), nb, stream())
 
 
-def smoothness(depth, img, ddepth, loss):
+def smoothness(depth, img, ddepth, loss, plus=None, plus2=None, total=None):
     B, _, H, W = depth.shape
     ws, nb = _loss_ws(B * H * W, depth.device)
-    lib.gdn_smoothness(_p(depth), _p(img), img.shape[1], B, H, W, _p(loss), _p(ddepth), _p(ws), nb, stream())
+    lib.gdn_smoothness(_p(depth), _p(img), img.shape[1], B, H, W, _p(loss), _p(ddepth), _p(plus), _p(plus2), _p(total),
+                       _p(ws), nb, stream())
 
 
 def mse_accum(a, b, weight, loss, accumulate):

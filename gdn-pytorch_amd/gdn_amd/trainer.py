@@ -16,6 +16,7 @@ import time
 import torch
 
 from . import distributed as D
+from . import tracing
 from . import utils as U
 from .calculate_error import ERROR_NAMES, compute_errors_device
 
@@ -76,12 +77,17 @@ def train_AE_DtoD(args, model, criterion_L2, criterion_L1, optimizer, dataset_lo
         for i, (gt_data, _, gt_data_2) in enumerate(dataset_loader):
             depths = _to_dev(gt_data, dev)
             sparse = _to_dev(gt_data_2, dev) if kitti else None       # None <=> NYU: unmasked BerHu
-            outputs = model(depths, istrain=False)
-            loss, output_loss, gradient_loss = U.dtod_loss(outputs, depths, sparse)
+            with tracing.span("gdn.forward"):
+                outputs = model(depths, istrain=False)
+            with tracing.span("gdn.losses"):
+                loss, output_loss, gradient_loss = U.dtod_loss(outputs, depths, sparse)
             optimizer.zero_grad()
-            loss.backward()
-            D.sync_gradients(model, optimizer)
-            optimizer.step()
+            with tracing.span("gdn.backward"):
+                U.backward(loss)            # == loss.backward(), seed gradient cached
+            with tracing.span("gdn.allreduce"):
+                D.sync_gradients(model, optimizer)
+            with tracing.span("gdn.adam"):
+                optimizer.step()
             seen += depths.shape[0] * D.world_size()
             if i >= epoch_size - 1:
                 break
@@ -158,16 +164,25 @@ def train_AE_RtoD(args, model, DtoD_model, criterion_L2, criterion_L1, optimizer
         for i, (gt_data, rgb_data, gt_data_2) in enumerate(dataset_loader):
             inputs, depths = _to_dev(rgb_data, dev), _to_dev(gt_data, dev)
             sparse = _to_dev(gt_data_2, dev) if kitti else None
-            outputs = model(inputs, istrain=False)
+            with tracing.span("gdn.forward"):
+                outputs = model(inputs, istrain=False)
+            tracing.push("gdn.losses")
             if not single:
                 latent = guide_latent_loss(DtoD_model, depths, outputs, faithful=getattr(args, "faithful_guide", False),
                                            latent_grad=getattr(args, "latent_grad", False))
-            pix, output_loss, smooth = U.rtod_pixel_loss(outputs, depths, inputs, sparse)
-            loss = pix + latent
+            if latent.requires_grad:            # --latent_grad: a differentiable term joins through autograd
+                pix, output_loss, smooth = U.rtod_pixel_loss(outputs, depths, inputs, sparse)
+                loss = pix + latent
+            else:                               # value-only latent loss (F3): summed by the loss kernel itself
+                loss, output_loss, smooth = U.rtod_pixel_loss(outputs, depths, inputs, sparse, plus=latent)
+            tracing.pop()
             optimizer.zero_grad()
-            loss.backward()
-            D.sync_gradients(model, optimizer)
-            optimizer.step()
+            with tracing.span("gdn.backward"):
+                U.backward(loss)            # == loss.backward(), seed gradient cached
+            with tracing.span("gdn.allreduce"):
+                D.sync_gradients(model, optimizer)
+            with tracing.span("gdn.adam"):
+                optimizer.step()
             seen += depths.shape[0] * D.world_size()
             if i >= epoch_size - 1:
                 break

@@ -78,13 +78,11 @@ class _PixelLoss(torch.autograd.Function):
             gt, sparse, box, parts = args
             g = _c1(gt, "gt")
             _berhu(p, g, None if sparse is None else _nchw(sparse, "sparse"), box, dp, parts[0])
-            ops.sobel_l1(p, g, 3.0, dp, parts[1])
-            torch.add(parts[0], parts[1], out=loss)
-        elif kind == "rtod":          # BerHu + smoothness
-            gt, sparse, box, img, parts = args
+            ops.sobel_l1(p, g, 3.0, dp, parts[1], plus=parts[0], total=loss)      # loss = BerHu + 3*Sobel, same kernel
+        elif kind == "rtod":          # BerHu + smoothness (+ a value-only extra term: the latent loss)
+            gt, sparse, box, img, parts, extra = args
             _berhu(p, _c1(gt, "gt"), None if sparse is None else _nchw(sparse, "sparse"), box, dp, parts[0])
-            ops.smoothness(p, _nchw(img, "img"), dp, parts[1])
-            torch.add(parts[0], parts[1], out=loss)
+            ops.smoothness(p, _nchw(img, "img"), dp, parts[1], plus=parts[0], plus2=extra, total=loss)
         else:
             raise ValueError(kind)
         ctx.dp = dp
@@ -95,7 +93,7 @@ class _PixelLoss(torch.autograd.Function):
         dp, ctx.dp = ctx.dp, None
         if dp is None:
             return None, None, None
-        return dp * gout, None, None
+        return ops.scale_dev(dp, gout.contiguous()), None, None
 
 
 def berhu_masked_loss(outputs, depths, sparse_depths=None, box=None):
@@ -124,13 +122,31 @@ def dtod_loss(outputs, depths, sparse_depths=None, box=None):
     return loss, parts[0], parts[1]
 
 
-def rtod_pixel_loss(outputs, depths, rgb, sparse_depths=None, box=None):
-    """BerHu + smoothness part of the RtoD loss, trainer.py:705-720,753-757."""
+def rtod_pixel_loss(outputs, depths, rgb, sparse_depths=None, box=None, plus=None):
+    """BerHu + smoothness part of the RtoD loss, trainer.py:705-720,753-757.
+    plus: a 0-dim device tensor WITHOUT autograd history (the value-only latent loss, F3) summed into the returned loss
+    by the same kernel: loss = (BerHu + smoothness) + plus, the association of trainer.py:757."""
     if sparse_depths is not None and box is None:
         box = crop_box_kitti(outputs.shape[2], outputs.shape[3])
+    if plus is not None and (plus.requires_grad or plus.dim() != 0 or plus.dtype != torch.float32 or not plus.is_cuda):
+        raise GdnError("rtod_pixel_loss: `plus` must be a detached 0-dim float32 device tensor (add a differentiable term "
+                       "with torch's +)")
     parts = torch.empty(2, dtype=torch.float32, device=outputs.device)
-    loss = _PixelLoss.apply(outputs, "rtod", (depths, sparse_depths, box, rgb, (parts[0], parts[1])))
+    loss = _PixelLoss.apply(outputs, "rtod", (depths, sparse_depths, box, rgb, (parts[0], parts[1]), plus))
     return loss, parts[0], parts[1]
+
+
+_ONES = {}
+
+
+def backward(loss):
+    """loss.backward() with a cached unit seed gradient: autograd's implicit ones_like(loss) is a torch fill kernel per
+    step, the only one left between the first and the last HIP kernel of a training step."""
+    one = _ONES.get(loss.device)
+    if one is None:
+        one = ops.fill_(torch.empty((), dtype=torch.float32, device=loss.device), 1.0)
+        _ONES[loss.device] = one
+    loss.backward(one)
 
 
 LATENT_WEIGHTS = (1.0, 2.5, 14.0, 12.0)

@@ -18,7 +18,9 @@
  *     channels lives at base + p*ld (ld >= C floats, lets a tensor be a channel
  *     slice of a wider one); weights are fp32 in "tap-major" layout
  *     [kh*kw][Cout][Cin] (Cin contiguous) for both Conv2d and ConvTranspose2d;
- *   - stateless and thread-safe.
+ *   - stateless and thread-safe: the library owns no stream, event, buffer or cache.
+ *     Work that profits from a second stream (gdn_fftconv_bwd's two chains) is split
+ *     into phases the CALLER places on streams of its own.
  */
 #ifndef GDN_HIP_H
 #define GDN_HIP_H
@@ -136,6 +138,10 @@ int gdn_conv_wgrad(const gdn_conv_geom* g, const void* x, int32_t ldx, int32_t C
  * one complex (real-embedded, MFMA) GEMM per frequency bin, inverse FFT of the valid outputs.
  * Same contract as gdn_conv_fwd for y / addsrc / stats / ep_scale / ep_shift / act (slots:
  * gdn_fftconv_stats_slots).
+ * in_scale / in_shift (nullable pair, Cin floats) + in_relu: x is the RAW output of the producer
+ * convolution and the layer input is [relu](x*in_scale[c] + in_shift[c]) -- the producer's train-mode
+ * BatchNorm (+ReLU) applied while the patch is loaded, so `a = relu(bn1(conv1 x))` of a ResidualBlock
+ * (AE_model_unet.py:49-54) is never written to memory.  Padding stays zero.
  * xf_out (nullable, gdn_fftconv_spectrum_bytes) receives the input and weight spectra, which
  * gdn_fftconv_bwd reuses (weight gradient; data gradient without a second weight transform).
  * GDN_ERR_UNSUPPORTED for other geometries; transposed (stride-1) layers are forward-only
@@ -146,20 +152,37 @@ int64_t gdn_fftconv_stats_slots(const gdn_conv_geom* g);
 int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w,
                     float* y, int32_t ldy, const float* addsrc, int32_t ld_add, float* stats,
                     const float* ep_scale, const float* ep_shift, int32_t act,
+                    const float* in_scale, const float* in_shift, int32_t in_relu,
                     void* xf_out, void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the same layer from one transform of dy: dx = dgrad (+ addsrc) when dx != NULL,
  * dw[tap][Cout][Cin] = wgrad when dw != NULL (needs xf, the state saved by the forward; with
- * xf == NULL the data gradient transforms w itself). */
+ * xf == NULL the data gradient transforms w itself).
+ * phases: 0 / GDN_FFT_BWD_ALL = everything on `stream`.  The weight-gradient chain and the
+ * data-gradient chain only share the spectrum of dy and use disjoint parts of the workspace, so a
+ * caller may issue GDN_FFT_BWD_TRANSFORM on stream A, let stream B wait for it, issue GDN_FFT_BWD_DW
+ * on B and GDN_FFT_BWD_DX on A (same arguments, same workspace) and join B into A: the two
+ * latency-bound chains then overlap.  The library creates no stream or event itself.
+ * bnb_* (nullable; replaces the reduce pass of gdn_bn_bwd, AE_model_unet.py:51,54,68): dx is the
+ * gradient of z = [relu](BN_train(bnb_y)), bnb_y [B,H,W,Cin] with pitch ld_bnb being that BatchNorm's
+ * input and bnb_co = {scale, shift, mean, invstd}[Cin]; the epilogue that writes dx (+ addsrc) also
+ * writes bnb_partial[slot][2][Cin] = per-slot sum(dz), sum(dz*xhat), dz = dx*[z>0 if bnb_relu],
+ * slots = gdn_fftconv_bnb_slots(g) (0: not available -- reflection-padded layers). */
+enum { GDN_FFT_BWD_TRANSFORM = 1, GDN_FFT_BWD_DW = 2, GDN_FFT_BWD_DX = 4, GDN_FFT_BWD_ALL = 7 };
 size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g);
+int64_t gdn_fftconv_bnb_slots(const gdn_conv_geom* g);
 int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w,
                     const void* xf, float* dx, int32_t ldx, const float* addsrc, int32_t ld_add,
-                    float* dw, void* workspace, size_t workspace_bytes, void* stream);
+                    float* dw, const float* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu,
+                    float* bnb_partial, int32_t phases,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* Winograd F(2x2,3x3) convolution for the 3x3 stride-1 layers (zero or reflection padding 1) on
  * 64..512 channels (the 512-channel ResidualBlocks of levels 3 and 4, AE_model_unet.py:45-57; R's
  * decoder ConvBlocks upconv0 / upconv1, :60-77), fp32: 2.25x fewer
  * multiplies than the direct kernel, transforms that only add and halve.  Same contract as
  * gdn_conv_fwd for y / addsrc / stats / ep_scale / ep_shift / act (slots: gdn_winoconv_stats_slots).
+ * in_scale / in_shift / in_relu: as for gdn_fftconv_fwd (the producer's train-mode BatchNorm + ReLU
+ * applied while the 4x4 patches are loaded).
  * state_out (nullable, gdn_winoconv_state_bytes) receives the transformed input, which
  * gdn_winoconv_bwd needs for the weight gradient.  Cin/64 and Cout/64 must be powers of two. */
 size_t gdn_winoconv_fwd_workspace_bytes(const gdn_conv_geom* g);
@@ -168,16 +191,19 @@ int64_t gdn_winoconv_stats_slots(const gdn_conv_geom* g);
 int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w,
                      float* y, int32_t ldy, const float* addsrc, int32_t ld_add, float* stats,
                      const float* ep_scale, const float* ep_shift, int32_t act,
+                     const float* in_scale, const float* in_shift, int32_t in_relu,
                      void* state_out, void* workspace, size_t workspace_bytes, void* stream);
 /* dx = dgrad (+ addsrc) when dx != NULL (needs w), dw[tap][Cout][Cin] = wgrad when dw != NULL
- * (needs state). */
+ * (needs state).  bnb_*: as for gdn_fftconv_bwd (slots: gdn_winoconv_bnb_slots). */
 size_t gdn_winoconv_bwd_workspace_bytes(const gdn_conv_geom* g);
+int64_t gdn_winoconv_bnb_slots(const gdn_conv_geom* g);
 /* Measurement hook: only the 16 per-bin MFMA GEMMs of one forward, V [16][tiles][Cin] x U [16][Cout][Cin]
  * -> Mo [16][tiles][Cout] (tiles = B * ceil(H/2) * ceil(W/2)). */
 int gdn_winoconv_gemm(const gdn_conv_geom* g, const float* V, const float* U, float* Mo, void* stream);
 int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w,
                      const void* state, float* dx, int32_t ldx, const float* addsrc, int32_t ld_add,
-                     float* dw, void* workspace, size_t workspace_bytes, void* stream);
+                     float* dw, const float* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu,
+                     float* bnb_partial, void* workspace, size_t workspace_bytes, void* stream);
 
 /* bf16 weight gradient (BASELINE configs[2]): x and dy hold bfloat16, dw is fp32 (the master
  * gradient arena).  Same contract as gdn_conv_wgrad otherwise.  Needs Cx and Cout multiples of
@@ -211,11 +237,12 @@ int gdn_weight_from_tapmajor(const float* w_tap, float* w_torch, int32_t Cout, i
 /* Train mode: reduce the conv kernel's partial statistics (fp64), update the
  * running stats (momentum, unbiased variance), and emit the per-channel
  * affine  scale = gamma*invstd,  shift = beta - mean*scale  plus mean/invstd
- * for backward. */
+ * for backward.  num_batches_tracked (nullable, device int64): += 1, nn.BatchNorm2d's counter. */
 int gdn_bn_finalize_train(const float* stats, int64_t slots, int32_t C, int64_t count,
                           const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float momentum, float eps,
-                          float* scale, float* shift, float* mean, float* invstd, void* stream);
+                          float* scale, float* shift, float* mean, float* invstd,
+                          int64_t* num_batches_tracked, void* stream);
 /* Eval mode: scale/shift from the running statistics. */
 int gdn_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, int32_t C,
@@ -230,6 +257,8 @@ int gdn_bn_apply(const void* y, int32_t ldy, const float* scale, const float* sh
  *   pass 2 (apply) : dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)),
  *                    dgamma = sum(dz*xhat), dbeta = sum(dz).
  * Both passes inside one call; workspace from gdn_bn_bwd_workspace_bytes.
+ * ext_partial (nullable, [ext_slots][2][C]): pass 1 was already done by the epilogue of the kernel that wrote
+ * dout (bnb_partial of gdn_winoconv_bwd / gdn_fftconv_bwd) and is skipped.
  * dtypes: bit0 dout, bit1 y, bit2 dy. */
 size_t gdn_bn_bwd_workspace_bytes(int64_t npix, int32_t C);
 int gdn_bn_bwd(const void* dout, int32_t ld_dout, const void* y, int32_t ldy,
@@ -237,6 +266,7 @@ int gdn_bn_bwd(const void* dout, int32_t ld_dout, const void* y, int32_t ldy,
                const float* mean, const float* invstd,
                void* dy, int32_t ld_dy, float* dgamma, float* dbeta,
                int64_t npix, int32_t C, int32_t relu,
+               const float* ext_partial, int64_t ext_slots,
                void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream);
 
 /* Backward of out = [relu](y*scale + shift) through an EVAL-mode BatchNorm (fixed coefficients from
@@ -262,6 +292,13 @@ int gdn_upsample2x_bwd(const void* dy, void* dx, int32_t B, int32_t H, int32_t W
 int gdn_nchw_to_nhwc(const void* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtypes, void* stream);
 int gdn_nhwc_to_nchw(const void* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtypes, void* stream);
 int gdn_add(const void* a, const void* b, void* out, int64_t n, int32_t dtypes, void* stream);
+/* out[p][c] = a[p][c] (+ b[p][c], b nullable): npix pixels of C channels, each tensor with its own pixel pitch -- the
+ * gradient of a torch.cat half (AE_model_unet.py:340,346,352,358) is a channel slice of the 1x1 conv's data gradient.
+ * dtypes: bit0 a, bit1 b, bit2 out. */
+int gdn_add_pitched(const void* a, int32_t lda, const void* b, int32_t ldb, void* out, int32_t ld_out,
+                    int64_t npix, int32_t C, int32_t dtypes, void* stream);
+/* out[i] = x[i] * (*s), s a device scalar: d(loss)/d(pred) times the upstream gradient of the loss node. */
+int gdn_scale_dev(const float* x, const float* s, float* out, int64_t n, void* stream);
 /* dpre = dout * (1 - out^2): backward of x15.tanh() (AE_model_unet.py:363,571). */
 int gdn_tanh_bwd(const float* dout, const float* out, float* dpre, int64_t n, void* stream);
 int gdn_fill(float* p, float value, int64_t n, void* stream);
@@ -283,13 +320,17 @@ int gdn_absdiff_max(const float* a, const float* b, int64_t n, float* max_out, v
 int gdn_berhu_masked(const float* out, const float* gt, const float* sparse, int32_t Cs,
                      int32_t B, int32_t H, int32_t W, const int32_t box[4], const float* ext_max,
                      float* loss, float* dout, void* workspace, size_t workspace_bytes, void* stream);
-/* Sobel L1, utils.py:105-131 with the factor 3 of trainer.py:453 passed as `weight`. */
+/* Sobel L1, utils.py:105-131 with the factor 3 of trainer.py:453 passed as `weight`.
+ * total (nullable): *total = *loss + *plus (plus nullable) -- the step's loss sum, trainer.py:456. */
 int gdn_sobel_l1(const float* pred, const float* gt, int32_t B, int32_t H, int32_t W, float weight,
-                 float* loss, float* dpred, void* workspace, size_t workspace_bytes, void* stream);
+                 float* loss, float* dpred, const float* plus, float* total,
+                 void* workspace, size_t workspace_bytes, void* stream);
 /* Edge-aware smoothness, utils.py:139-178 + trainer.py:753-754.
- * depth [B,1,H,W], img [B,Ci,H,W] NCHW.  loss = mean|0.1*smooth|. */
+ * depth [B,1,H,W], img [B,Ci,H,W] NCHW.  loss = mean|0.1*smooth|.
+ * total (nullable): *total = (*loss + *plus) + *plus2 (both nullable) -- trainer.py:757. */
 int gdn_smoothness(const float* depth, const float* img, int32_t Ci, int32_t B, int32_t H, int32_t W,
-                   float* loss, float* ddepth, void* workspace, size_t workspace_bytes, void* stream);
+                   float* loss, float* ddepth, const float* plus, const float* plus2, float* total,
+                   void* workspace, size_t workspace_bytes, void* stream);
 /* loss_accum (+)= weight * mean((a-b)^2): the latent MSE terms, trainer.py:728-733
  * (value only, F3).  accumulate != 0 adds to the existing *loss.  dtypes: bit0 a, bit1 b. */
 int gdn_mse(const void* a, const void* b, int64_t n, float weight, int32_t accumulate,

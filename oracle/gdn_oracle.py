@@ -216,13 +216,15 @@ def _bf16_layer(w, transposed=False):
     return _EMU_BF16 and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
 
 
-def _conv(x, w, stride, pad, transposed=False):
-    """Convolution as the HIP path runs it: bf16 operands + bf16-stored result when the layer is a bf16 layer."""
+def _conv(x, w, stride, pad, transposed=False, stored=True):
+    """Convolution as the HIP path runs it: bf16 operands + bf16-stored result when the layer is a bf16 layer.
+    stored=False: the raw result is never stored -- an eval-mode BatchNorm (+ReLU, +residual) is folded into the conv
+    epilogue on the HIP path, so only the block output is rounded."""
     bf = _bf16_layer(w)
     if bf:
         w = _RoundFwd.apply(w)
     y = F.conv_transpose2d(x, w, None, stride, pad) if transposed else F.conv2d(x, w, None, stride, pad)
-    return _q(y) if bf else y
+    return _q(y) if bf and stored else y
 
 
 def _bn(x, sd, key, training):
@@ -238,21 +240,21 @@ def conv_block(x, sd, name, k, stride, pad, training):
     """ConvBlock: ReflectionPad -> Conv(pad 0, no bias) -> BN -> ReLU. AE_model_unet.py:60-77."""
     if pad:
         x = F.pad(x, (pad, pad, pad, pad), mode="reflect")
-    y = _conv(x, sd[name + ".main.1.weight"], stride, 0)
+    y = _conv(x, sd[name + ".main.1.weight"], stride, 0, stored=training)
     return _q(F.relu(_bn(y, sd, name + ".main.2", training)))
 
 
 def convt_block(x, sd, name, k, stride, pad, training):
     """ConvTBlock: ConvTranspose2d -> BN -> ReLU. AE_model_unet.py:79-94."""
-    y = _conv(x, sd[name + ".main.0.weight"], stride, pad, transposed=True)
+    y = _conv(x, sd[name + ".main.0.weight"], stride, pad, transposed=True, stored=training)
     return _q(F.relu(_bn(y, sd, name + ".main.1", training)))
 
 
 def residual_block(x, sd, name, k, pad, training):
     """ResidualBlock: x + BN(Conv(ReLU(BN(Conv x)))), zero pad, no post-add act. AE_model_unet.py:45-57."""
-    y = _conv(x, sd[name + ".main.0.weight"], 1, pad)
+    y = _conv(x, sd[name + ".main.0.weight"], 1, pad, stored=training)
     y = _q(F.relu(_bn(y, sd, name + ".main.1", training)))
-    y = _conv(y, sd[name + ".main.3.weight"], 1, pad)
+    y = _conv(y, sd[name + ".main.3.weight"], 1, pad, stored=training)
     y = _bn(y, sd, name + ".main.4", training)
     return _q(x + y)
 
@@ -359,10 +361,10 @@ def forward_legacy(sd, x, istrain=True, training=False, height=None, width=None)
     t = training
 
     def cbr(v, conv, bn, stride, pad):
-        return _q(F.relu(_bn(_conv(v, sd[conv + ".weight"], stride, pad), sd, bn, t)))
+        return _q(F.relu(_bn(_conv(v, sd[conv + ".weight"], stride, pad, stored=t), sd, bn, t)))
 
     def up(v, convt, bn, pad):
-        y = _conv(_up_ac1(v), sd[convt + ".weight"], 1, pad, transposed=True)
+        y = _conv(_up_ac1(v), sd[convt + ".weight"], 1, pad, transposed=True, stored=t)
         return _q(F.relu(_bn(y, sd, bn, t)))
 
     x3 = cbr(x, "downconv0", "N64_down", 1, 4)

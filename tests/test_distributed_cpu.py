@@ -101,3 +101,77 @@ def test_two_rank_gradient_allreduce_gloo():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_launch_ranks_spawns_one_process_per_device(tmp_path):
+    """`GDN_main --gpu_num 0,1,2` (the reference's multi-GPU idiom, README.md:82) -> distributed.launch_ranks: one fresh
+    process per listed device with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; the ranks find each other (gloo here)."""
+    import json
+    import pathlib
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "gdn-pytorch_amd"))
+    from gdn_amd import distributed as D
+    env = {"PYTHONPATH": os.pathsep.join([str(root / "tests"), str(root / "gdn-pytorch_amd"), str(root)]),
+           "GDN_DIST_BACKEND": "gloo"}
+    rc = D.launch_ranks([str(tmp_path), "-1"], ["0", "1", "2"], module="spawn_worker", extra_env=env, timeout=120)
+    assert rc == 0
+    seen = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(3)]
+    assert [s["rank"] for s in seen] == [0, 1, 2] and [s["local_rank"] for s in seen] == [0, 1, 2]
+    assert all(s["world"] == 3 and s["sum"] == 6.0 and s["visible"] == "0,1,2" for s in seen)
+
+
+def test_launch_ranks_propagates_failure(tmp_path):
+    """A rank that exits non-zero ends the job with that code; the surviving ranks (blocked in the collective) are stopped."""
+    import pathlib
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "gdn-pytorch_amd"))
+    from gdn_amd import distributed as D
+    env = {"PYTHONPATH": os.pathsep.join([str(root / "tests"), str(root / "gdn-pytorch_amd"), str(root)]),
+           "GDN_DIST_BACKEND": "gloo"}
+    rc = D.launch_ranks([str(tmp_path), "1"], ["0", "1"], module="spawn_worker", extra_env=env, timeout=120)
+    assert rc == 7
+
+
+def test_gdn_main_gpu_num_list_goes_through_the_launcher(monkeypatch):
+    """main() with --gpu_num 0,1,2,3 and no launcher environment hands the SAME argv to launch_ranks with the four devices
+    and never touches the GPU itself; with RANK set (a child, or torch.distributed.run) it runs in-process."""
+    import pathlib
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "gdn-pytorch_amd"))
+    from gdn_amd import GDN_main
+    calls = []
+    monkeypatch.setattr(GDN_main.D, "launch_ranks", lambda argv, devices, **kw: calls.append((list(argv), list(devices))) or 0)
+    monkeypatch.setattr(GDN_main, "run", lambda args, *a, **k: calls.append("run") or "ran")
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    argv = ["DATA", "--mode", "DtoD", "--gpu_num", "0,1,2,3", "--synthetic"]
+    assert GDN_main.main(argv) is None
+    assert calls == [(argv, ["0", "1", "2", "3"])]
+    monkeypatch.setenv("RANK", "2")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert GDN_main.main(argv) == "ran" and calls[-1] == "run"
+    monkeypatch.delenv("RANK")
+    monkeypatch.delenv("WORLD_SIZE")
+    assert GDN_main.main(["DATA", "--gpu_num", "3", "--synthetic"]) == "ran"      # a single device: in-process as before
+
+
+def test_rank_sharded_loader_order():
+    """Every rank shuffles with the same order seed and takes order[rank::world]: the shards are disjoint, equally long and
+    cover the epoch once (DistributedSampler semantics)."""
+    import pathlib
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "gdn-pytorch_amd"))
+    from gdn_amd.datasets import GpuAugmentLoader
+    ds = list(range(103))
+    loaders = [GpuAugmentLoader(ds, 5, "cpu", train=True, seed=7 + r, rank=r, world=4, order_seed=99, drop_last=True)
+               for r in range(4)]
+    orders = [ld._epoch_order() for ld in loaders]
+    assert all(len(o) == 25 for o in orders) and all(len(ld) == 5 for ld in loaders)
+    flat = [i for o in orders for i in o]
+    assert len(set(flat)) == 100 and set(flat) <= set(ds)
+    single = GpuAugmentLoader(ds, 5, "cpu", train=True, seed=7, order_seed=99)._epoch_order()
+    assert sorted(single) == ds and [single[r::4][:25] for r in range(4)] == orders

@@ -372,3 +372,77 @@ def test_bf16_odd_shapes_train_step(gpu, name, B, H, W):
         assert all(torch.isfinite(p.grad).all() for p in m.parameters())
         losses.append(float(loss.detach()))
     assert losses[1] == pytest.approx(losses[0], rel=5e-2)
+
+
+def test_bf16_rtod_vs_emulation(gpu):
+    """BASELINE configs[2] (RtoD, bf16) at network level against the ORACLE: AutoEncoder_2 (bilinear upsample, concat 1x1,
+    reflection-padded decoder ConvBlocks, smoothness loss) + the frozen eval-mode guide, B = 2, 128x416, one RtoD step.
+    The reference for a bf16 implementation is oracle.bf16_emulation(): the reference's fp32 CPU arithmetic with every
+    tensor the HIP path stores as bfloat16 rounded where it is stored.  Two roundings of the same tensors still differ by
+    summation order -- and a 1-ulp bf16 flip (2^-8) is amplified like any other perturbation -- so bars are stated per
+    quantity:
+      * guide features of the ground truth (eval-mode BatchNorm: no batch-statistics feedback), HIP bf16 vs emulation:
+        relative L2 <= 2e-2 on all four;
+      * R's feature maps (train-mode BatchNorm), HIP bf16 vs emulation: no further from the emulation than 1.25x the
+        emulation is from the fp32 oracle (+2e-3), and <= 2e-2 on x1 / x2;
+      * loss terms: BerHu and smoothness within 2e-2 relative of the emulation's, latent within 5e-2;
+      * parameter gradients: median relative L2 distance to the emulation's no larger than 1.25x the emulation's distance
+        to the fp32 oracle (+2e-2)."""
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import utils as U
+    from oracle import gdn_oracle as O
+    depth, rgb, sparse = O.synthetic_batch(2, 128, 416, seed=0)
+    sd_r = O.init_state_dict("AutoEncoder_2", seed=0)
+    sd_g = O.init_state_dict("AutoEncoder_DtoD", seed=1)
+    cl = lambda d: {k: v.clone() for k, v in d.items()}
+    torch.set_num_threads(max(1, min(len(__import__("os").sched_getaffinity(0)), 32)))
+    ref32 = O.train_step("RtoD", cl(sd_r), (depth, rgb, sparse), {}, g_sd=cl(sd_g))
+    with torch.no_grad():
+        f32 = O.forward_r(cl(sd_r), rgb, istrain=True, training=True)
+    with O.bf16_emulation():
+        emu = O.train_step("RtoD", cl(sd_r), (depth, rgb, sparse), {}, g_sd=cl(sd_g))
+        with torch.no_grad():
+            f_emu = O.forward_r(cl(sd_r), rgb, istrain=True, training=True)
+            g_emu = O.forward_dtod(cl(sd_g), depth, istrain=True, training=False)[:4]
+    R = M.AutoEncoder_2(input_dim=3)
+    R.load_state_dict(sd_r)
+    R = R.to(gpu).train().compute_dtype("bf16")
+    G = M.AutoEncoder_DtoD(input_dim=1)
+    G.load_state_dict(sd_g)
+    G = G.to(gpu).eval().compute_dtype("bf16")
+    d, r, s = depth.to(gpu), rgb.to(gpu), sparse.to(gpu)
+    feats = R(r, istrain=True)
+    out = feats[7]
+    with torch.no_grad():
+        ft_tar = G(d, istrain=True)[:4]
+        ft = G(out, istrain=True)[:4]
+    lat = U.latent_loss(ft, ft_tar)
+    loss, ol, sm = U.rtod_pixel_loss(out, d, r, s, plus=lat)
+    loss.backward()
+    # guide features of the ground-truth depth
+    gd = [rel_l2(a.detach().float().cpu(), b) for a, b in zip(ft_tar, g_emu)]
+    print("guide features HIP bf16 vs emulation: " + " ".join("%.4f" % v for v in gd))
+    assert max(gd) <= 2e-2
+    # R's features
+    hip = [rel_l2(a.detach().float().cpu(), b) for a, b in zip(feats, f_emu)]
+    emu_drift = [rel_l2(a, b) for a, b in zip(f_emu, f32)]
+    print("R features HIP bf16 vs emulation : " + " ".join("%.4f" % v for v in hip))
+    print("R features emulation vs fp32     : " + " ".join("%.4f" % v for v in emu_drift))
+    assert hip[0] <= 2e-2 and hip[1] <= 2e-2
+    for i, (h, c) in enumerate(zip(hip, emu_drift)):
+        assert h <= 1.25 * c + 2e-3, "feature %d: HIP-vs-emulation %.4f, emulation-vs-fp32 %.4f" % (i, h, c)
+    print("loss HIP %.5f (berhu %.5f smooth %.5f latent %.5f) | emulation %.5f (%.5f %.5f %.5f) | fp32 oracle %.5f"
+          % (loss.item(), ol.item(), sm.item(), lat.item(), emu["loss"], emu["output_loss"], emu["smoothness_loss"],
+             emu["latent_loss"], ref32["loss"]))
+    assert ol.item() == pytest.approx(emu["output_loss"], rel=2e-2)
+    assert sm.item() == pytest.approx(emu["smoothness_loss"], rel=2e-2)
+    assert lat.item() == pytest.approx(emu["latent_loss"], rel=5e-2)
+    assert loss.item() == pytest.approx(ol.item() + sm.item() + lat.item(), rel=1e-5)
+    g_hip = {k: p.grad.detach().cpu() for k, p in R.named_parameters()}
+    med = np.median([float(v.norm()) for v in ref32["grads"].values()])
+    keys = [k for k in g_hip if ref32["grads"][k].norm() > 1e-3 * med]
+    dh = np.array([rel_l2(g_hip[k], emu["grads"][k]) for k in keys])
+    dc = np.array([rel_l2(emu["grads"][k], ref32["grads"][k]) for k in keys])
+    print("gradient distance (median / 90th pct): HIP-vs-emulation %.3f / %.3f, emulation-vs-fp32 %.3f / %.3f"
+          % (np.median(dh), np.percentile(dh, 90), np.median(dc), np.percentile(dc, 90)))
+    assert np.median(dh) <= 1.25 * np.median(dc) + 2e-2

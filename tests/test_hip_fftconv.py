@@ -191,3 +191,54 @@ def test_fftconv_full_size_adjoint_and_direct(gpu, C, k, H, W):
     dw_d = torch.empty_like(w)
     op.wgrad(x, g, dw_d)
     close(dw, dw_d, rtol=1e-4, atol_scale=2e-5, what="wgrad vs direct, full size")
+
+
+@pytest.mark.parametrize("path,k,C,B,H,W", [("fft", 9, 64, 2, 40, 70), ("fft", 5, 128, 1, 33, 47), ("wino", 3, 128, 2, 17, 30)])
+def test_input_affine_and_bn_backward_partials(gpu, path, k, C, B, H, W):
+    """The two train-mode BatchNorm fusions of the transform-domain layers:
+    (1) in_affine: conv(relu(y1*scale + shift)) with the affine applied in the patch loader == conv of the materialised
+        activation (zero padding stays zero);
+    (2) bnb: the data-gradient epilogue's per-slot partials sum to sum(dz), sum(dz*xhat) of the BatchNorm backward, dz
+        being the final dx (+ addsrc) masked by the producer's ReLU."""
+    from gdn_amd import ops
+    g = torch.Generator().manual_seed(k * 100 + C)
+    op = ops.Conv(C, C, k, 1, k // 2)
+    y1 = torch.randn(B, H, W, C, generator=g).to(gpu)
+    w = (torch.randn(k * k, C, C, generator=g) * 0.05).to(gpu)
+    scale = (torch.rand(C, generator=g) + 0.5).to(gpu)
+    shift = (torch.randn(C, generator=g) * 0.3).to(gpu)
+    mean = (torch.randn(C, generator=g) * 0.1).to(gpu)
+    invstd = (torch.rand(C, generator=g) + 0.7).to(gpu)
+    co = torch.stack([scale, shift, mean, invstd]).contiguous()
+    fwd = op.fft_fwd if path == "fft" else op.wino_fwd
+    bwd = op.fft_bwd if path == "fft" else op.wino_bwd
+    a = ops.bn_apply(y1, scale, shift, True)
+    ref = fwd(a, w)
+    got = fwd(y1, w, in_affine=(scale, shift), in_relu=True)
+    close(got, ref, rtol=1e-5, atol_scale=1e-6, what=path + " in_affine forward")
+    got2 = fwd(y1, w, in_affine=(scale, shift), in_relu=False)
+    close(got2, fwd(ops.bn_apply(y1, scale, shift, False), w), rtol=1e-5, atol_scale=1e-6, what=path + " in_affine (no relu)")
+    dy = torch.randn(B, H, W, C, generator=g).to(gpu)
+    skip = torch.randn(B, H, W, C, generator=g).to(gpu)
+    slots = op.fft_bnb_slots(B, H, W) if path == "fft" else op.wino_bnb_slots(B, H, W)
+    assert slots > 0
+    for relu in (True, False):
+        part = torch.full((slots, 2, C), float("nan"), device=gpu)
+        dx_ref = bwd(dy, w, (H, W), addsrc=skip)
+        dx = bwd(dy, w, (H, W), addsrc=skip, bnb=(y1, co, relu, part))
+        assert torch.equal(dx, dx_ref)
+        dz = dx.double()
+        if relu:
+            dz = dz * ((y1 * scale + shift) > 0)
+        xhat = (y1.double() - mean.double()) * invstd.double()
+        s = part.double().sum(0)
+        assert torch.isfinite(part).all()
+        close(s[0], dz.sum((0, 1, 2)), rtol=1e-4, atol_scale=1e-5, what=path + " bnb sum dz relu=%s" % relu)
+        close(s[1], (dz * xhat).sum((0, 1, 2)), rtol=1e-4, atol_scale=1e-5, what=path + " bnb sum dz*xhat relu=%s" % relu)
+        # and through gdn_bn_bwd: identical dy / dgamma / dbeta to the stand-alone reduce
+        dg0, db0, dg1, db1 = [torch.empty(C, device=gpu) for _ in range(4)]
+        r0 = ops.bn_bwd(dx, y1, scale, co, relu, dg0, db0)
+        r1 = ops.bn_bwd(dx, y1, scale, co, relu, dg1, db1, partial=part)
+        close(r1, r0, rtol=1e-4, atol_scale=1e-5, what=path + " bn_bwd dy from partials")
+        close(dg1, dg0, rtol=1e-4, atol_scale=1e-5, what="dgamma")
+        close(db1, db0, rtol=1e-4, atol_scale=1e-5, what="dbeta")

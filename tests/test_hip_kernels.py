@@ -29,6 +29,16 @@ def close(got, ref, rtol=RTOL, atol_scale=1e-4, what="", outliers=0.0):
         what, int(bad.sum()), bad.numel(), float(err.max()), scale)
 
 
+def close_abs(got, ref, atol=1e-3, what=""):
+    """max|got - ref| <= atol: THE north-star bar for depth maps (values in (-1, 1), "within 1e-3 of the reference").
+    One absolute bound, no relative term on top."""
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = float((got - ref).abs().max())
+    assert err <= atol, "%s: max abs error %.3e > %.1e" % (what, err, atol)
+
+
 def nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 

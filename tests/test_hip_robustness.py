@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import gdn_oracle as O
-from test_hip_kernels import close
+from test_hip_kernels import close, close_abs
 
 pytestmark = pytest.mark.gpu
 
@@ -218,7 +218,7 @@ def test_input_gradient_vs_oracle(gpu, name):
     model = model.to(gpu).eval().requires_grad_(False)
     xg = x.to(gpu).requires_grad_(True)
     out = model(xg, istrain=False)
-    close(out, out_ref, atol_scale=1e-3, what=name + " eval forward")
+    close_abs(out, out_ref, 1e-3, what=name + " eval forward")
     out.backward(gy.to(gpu))
     close(xg.grad, xr.grad, rtol=5e-3, atol_scale=5e-3, what=name + " d out / d input")
 
@@ -305,7 +305,7 @@ def test_legacy_instance_norm_eval(gpu):
         x3_torch = torch.relu(cb(rgb))
     m = m.to(gpu).eval()
     out = m(rgb.to(gpu), istrain=False)
-    close(out, ref, atol_scale=1e-3, what="legacy InstanceNorm eval output")
+    close_abs(out, ref, 1e-3, what="legacy InstanceNorm eval output")
     blk = M.ConvBlock(3, 64, kernel_size=9, stride=1, padding=4, norm='Instance')
     with torch.no_grad():
         blk.main[1].weight.copy_(sd["downconv0.weight"])

@@ -514,7 +514,9 @@ def test_train_bn_fusion_matches_unfused(gpu, monkeypatch):
         typical = float(np.median([g.double().norm().item() for g in res[0][2].values()]))
         for k in res[0][2]:
             a, b = res[0][2][k].double(), res[1][2][k].double()
-            rel = float((a - b).norm() / (a.norm() + 1e-3 * typical))
+            # (a BN bias in front of a conv + train-mode BN has an analytically zero gradient: both runs hold rounding
+            # noise ~1e-6 of the typical gradient there, so the distance is measured on |a| + 5 % of the typical norm)
+            rel = float((a - b).norm() / (a.norm() + 5e-2 * typical))
             assert rel < 2e-4, "%s %s: fused vs unfused gradient rel-L2 %.3e" % (name, k, rel)
 
 

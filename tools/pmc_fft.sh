@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: HBM-side traffic of the frequency-domain kernels (separate PMC passes, kernel-trace only), level-0 9x9 shape
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$R/gpurun_out/pmc_fft
 mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: VALU / wait counters of the frequency-domain kernels (one PMC pass, kernel-trace only)
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$R/gpurun_out/pmc_fft_valu
 mkdir -p $out
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/p -- python3 $R/tests/diag/fft_kernels_time.py > $out/p.log 2>&1
@@ -10,6 +10,10 @@ python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
 files = glob.glob(out + "/p/*/*counter_collection.csv")
+if not files:
+    print("no counter file; tail of the profiler log:")
+    print("".join(open(out + "/p.log").readlines()[-30:]))
+    sys.exit(1)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(files[0])):
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:34]

@@ -2,7 +2,7 @@
 # usage: pmc_run.sh <tag> <prof_layer args...>   -- separate PMC passes (never combined with trace domains other than kernel-trace)
 tag=$1; shift
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$R/gpurun_out/pmc_$tag
 mkdir -p $out
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/p1 -- python3 $R/tools/prof_layer.py "$@" > $out/p1.log 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: PMC passes (separate runs, kernel-trace only) of the Winograd kernels at level 3 / level 4, B=20 -> JSON summary
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$R/gpurun_out/pmc_wino
 mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -285,14 +285,19 @@ __global__ __launch_bounds__(256) void ifft_cols_kernel(const float2* __restrict
 // (D = spectrum of dy [M][N], X = spectrum of x [M][C]; both operands are read as they lie, rows = tiles), again with three
 // real products:  g1 = dr (xr + xi), g2 = (dr + di) xr, g3 = (dr - di) xi;  re = g1 - g3, im = g1 - g2.
 // 64 x 64 complex output tile, 16 tiles of the reduction per step; every MFMA operand pair is one conflict-free ds_read_b64.
+// nsplit > 1: the reduction over the M tiles is cut into nsplit chunks (one workgroup each, partial spectra [split][bin][n][c]
+// summed in fixed order by the tap kernel): with 64 channels there are only 544 (bin, tile) workgroups otherwise -- two per CU.
 __global__ __launch_bounds__(256, 4) void cgemm_tn_bins_kernel(const float* __restrict__ D, const float* __restrict__ X,
-                                                            float* __restrict__ dWf, int M, int N, int C) {
+                                                            float* __restrict__ dWf, int M, int N, int C, int nsplit) {
     constexpr int LD = 128;                              // 64 complex per row
     __shared__ __attribute__((aligned(16))) float Ds[16 * LD], Xs[16 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wi = wave >> 1, wj = wave & 1;
     const int TI = N / 64, TJ = C / 64;
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int bin = (sq / (TI * TJ)) * 8 + xcd, i0 = ((sq / TJ) % TI) * 64, j0 = (sq % TJ) * 64;
+    const int bin = (sq / (TI * TJ * nsplit)) * 8 + xcd, split = (sq / (TI * TJ)) % nsplit;
+    const int i0 = ((sq / TJ) % TI) * 64, j0 = (sq % TJ) * 64;
+    const int mchunk = ((M + nsplit - 1) / nsplit + 15) / 16 * 16;
+    const int mb = split * mchunk, me = mb + mchunk < M ? mb + mchunk : M;        // this workgroup reduces tiles [mb, me)
     const float* Db = D + ((size_t)bin * M * N + i0) * 2;
     const float* Xb = X + ((size_t)bin * M * C + j0) * 2;
     f32x16 acc1, acc2, acc3;
@@ -304,8 +309,8 @@ __global__ __launch_bounds__(256, 4) void cgemm_tn_bins_kernel(const float* __re
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
             const int m = m0 + ps * 8 + lr;
-            rd[ps] = m < M ? *reinterpret_cast<const f32x4*>(Db + (size_t)m * N * 2 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rx[ps] = m < M ? *reinterpret_cast<const f32x4*>(Xb + (size_t)m * C * 2 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rd[ps] = m < me ? *reinterpret_cast<const f32x4*>(Db + (size_t)m * N * 2 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rx[ps] = m < me ? *reinterpret_cast<const f32x4*>(Xb + (size_t)m * C * 2 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto lstore = [&]() {
@@ -317,11 +322,11 @@ __global__ __launch_bounds__(256, 4) void cgemm_tn_bins_kernel(const float* __re
     };
     const int d_off = (lane >> 5) * LD + (wi * 32 + (lane & 31)) * 2;
     const int x_off = (lane >> 5) * LD + (wj * 32 + (lane & 31)) * 2;
-    gload(0);
+    gload(mb);
     lstore();
     __syncthreads();
-    for (int m0 = 0; m0 < M; m0 += 16) {
-        if (m0 + 16 < M) gload(m0 + 16);
+    for (int m0 = mb; m0 < me; m0 += 16) {
+        if (m0 + 16 < me) gload(m0 + 16);
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 2) {
             const float2 d = *reinterpret_cast<const float2*>(&Ds[d_off + kk * LD]);
@@ -331,9 +336,9 @@ __global__ __launch_bounds__(256, 4) void cgemm_tn_bins_kernel(const float* __re
             acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(d.x - d.y, x.y, acc3, 0, 0, 0);
         }
         __syncthreads();
-        if (m0 + 16 < M) { lstore(); __syncthreads(); }
+        if (m0 + 16 < me) { lstore(); __syncthreads(); }
     }
-    float2* Pb = reinterpret_cast<float2*>(dWf) + (size_t)bin * N * C;
+    float2* Pb = reinterpret_cast<float2*>(dWf) + ((size_t)split * FFT_BINS + bin) * N * C;
     const int col = j0 + wj * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -350,7 +355,8 @@ __global__ __launch_bounds__(256, 4) void cgemm_tn_bins_kernel(const float* __re
 // block = 64 (n, c) pairs x 4 groups of kx (one wave each: every twiddle index is wave-uniform); the four partial tap sets
 // meet in LDS in a fixed order.
 template <int K>
-__global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C) {
+__global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C,
+                                                             int nsplit) {
     __shared__ float red[3][K * K][64];
     const int pl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + pl;             // N*C is a multiple of 64
@@ -367,7 +373,11 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
         for (int ty = 0; ty < K; ++ty) { gr[ty] = 0.f; gi[ty] = 0.f; }
 #pragma unroll 8
         for (int ky = 0; ky < FFT_N; ++ky) {
-            const float2 v = F[(size_t)(ky * FFT_NK + kx) * bs];
+            float2 v = F[(size_t)(ky * FFT_NK + kx) * bs];
+            for (int sp = 1; sp < nsplit; ++sp) {              // partial spectra of a split reduction, fixed order
+                const float2 u = F[((size_t)sp * FFT_BINS + ky * FFT_NK + kx) * bs];
+                v.x += u.x; v.y += u.y;
+            }
 #pragma unroll
             for (int ty = 0; ty < K; ++ty) {
                 const int ph = (ky * ty) & 31;
@@ -539,9 +549,15 @@ __global__ __launch_bounds__(256) void fft_reflect_fold_kernel(const float* __re
 // in_scale != NULL: the tensor read is the RAW output of the producer convolution and the layer input is
 // [relu](x * in_scale[c] + in_shift[c]) -- the producer's train-mode BatchNorm (+ReLU) applied on load, so that
 // activation is never written to memory (ResidualBlock AE_model_unet.py:49-54).  Padding stays zero.
+// bnb_y != NULL (halo = 0, the dy transform of a backward): x is dout, the gradient of z = [relu](BN_train(bnb_y)), and
+// the tile transformed is this layer's dy = scale*(dz - k1 - xhat*k2), dz = dout*[z>0] (pass 3 of the BatchNorm backward,
+// AE_model_unet.py:51,54) computed on load from bnb_co = {scale, shift, mean, invstd}[C] and bnb_kk = {k1, k2}[C]: dy is
+// never written to memory.
 __global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ Xf,
                                                         FftGeom g, int halo, const float* __restrict__ in_scale,
-                                                        const float* __restrict__ in_shift, int in_relu) {
+                                                        const float* __restrict__ in_shift, int in_relu,
+                                                        const float* __restrict__ bnb_y, int ld_bnb,
+                                                        const float* __restrict__ bnb_co, const float* __restrict__ bnb_kk) {
     __shared__ float2 lds[FFT_LDS_ELEMS];
     // XCD-aware order: XCD j (= blockIdx & 7) owns the contiguous tile range [j, j+1) * ceil(M/8) and runs the channel
     // groups of one tile back to back, so the half cache lines the groups share and the halo rows / columns neighbouring
@@ -568,17 +584,42 @@ __global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restri
         int off_x = ix0 * ldx;                             // running ix * ldx (interior columns: no multiply per element)
         const float is = in_scale ? in_scale[cg + c] : 1.f, it = in_scale ? in_shift[cg + c] : 0.f;
         const float lo = in_relu ? 0.f : -3.402823466e38f;
+        if (!bnb_y) {
 #pragma unroll
-        for (int bb = 0; bb < 32; ++bb) {
-            const int ix = ix0 + bb;
-            const bool ok = row_ok && bb < nvalid && ix >= -lim && ix < g.W + lim;
-            const bool inside = ix >= 0 && ix < g.W;
-            const int ixr = ix < 0 ? -ix : 2 * g.W - 2 - ix;         // mirrored column (border patches only)
-            float v = ok ? img[row_off + (inside ? off_x : ixr * ldx)] : 0.f;
-            if (in_scale) v = ok ? fmaxf(v * is + it, lo) : 0.f;
-            re[bb] = v;
-            im[bb] = 0.f;
-            off_x += ldx; GDN_KEEP(off_x);
+            for (int bb = 0; bb < 32; ++bb) {
+                const int ix = ix0 + bb;
+                const bool ok = row_ok && bb < nvalid && ix >= -lim && ix < g.W + lim;
+                const bool inside = ix >= 0 && ix < g.W;
+                const int ixr = ix < 0 ? -ix : 2 * g.W - 2 - ix;         // mirrored column (border patches only)
+                float v = ok ? img[row_off + (inside ? off_x : ixr * ldx)] : 0.f;
+                if (in_scale) v = ok ? fmaxf(v * is + it, lo) : 0.f;
+                re[bb] = v;
+                im[bb] = 0.f;
+                off_x += ldx; GDN_KEEP(off_x);
+            }
+        } else {
+            // dy = scale * (dz - k1 - xhat * k2) from (dout, y): no halo, no reflection in this mode
+            const int ch = cg + c;
+            const float bs = bnb_co[ch], bt = bnb_co[g.C + ch], bmu = bnb_co[2 * g.C + ch], bis = bnb_co[3 * g.C + ch];
+            const float k1 = bnb_kk[ch], k2 = bnb_kk[g.C + ch];
+            const float* yimg = bnb_y + (size_t)b * g.H * g.W * ld_bnb + cg;
+            const int yrow = (row_ok ? iy : 0) * g.W * ld_bnb + c;
+            int off_y = ix0 * ld_bnb;
+#pragma unroll
+            for (int bb = 0; bb < 32; ++bb) {
+                const int ix = ix0 + bb;
+                const bool ok = row_ok && bb < nvalid && ix < g.W;
+                float v = 0.f;
+                if (ok) {
+                    const float d = img[row_off + off_x], yv = yimg[yrow + off_y];
+                    const float dz = (in_relu && !(yv * bs + bt > 0.f)) ? 0.f : d;
+                    v = bs * (dz - k1 - ((yv - bmu) * bis) * k2);
+                }
+                re[bb] = v;
+                im[bb] = 0.f;
+                off_x += ldx; GDN_KEEP(off_x);
+                off_y += ld_bnb; GDN_KEEP(off_y);
+            }
         }
         fft32<-1>(re, im);
 #pragma unroll
@@ -721,6 +762,20 @@ bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
 
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
+// splits of the weight-gradient reduction: enough workgroups for ~4 per CU, chunks of at least 64 tiles
+inline int tn_splits(const FftGeom& f) {
+    const int wgs = (f.N / 64) * (f.C / 64) * FFT_BINS;
+    int s = (4096 + wgs - 1) / wgs;
+    if (s > 4) s = 4;
+    while (s > 1 && f.M / s < 64) --s;
+    return s < 1 ? 1 : s;
+}
+// weight-spectrum / weight-gradient-product region of the backward workspace
+inline size_t wf_region_bytes(const FftGeom& f) {
+    const size_t planes = (size_t)FFT_BINS * 3 * f.C * f.N * 4, prod = (size_t)tn_splits(f) * FFT_BINS * 2 * f.C * f.N * 4;
+    return al256(planes > prod ? planes : prod);
+}
+
 }  // namespace
 
 // workspace: Xf, Yf (M*544*C / N complex), Wf (544 * 3 * N * C floats)
@@ -775,7 +830,7 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
         Wf = (float*)((char*)xf_out + al256((size_t)f.M * FFT_BINS * f.C * 8));
     }
     hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.C / FFT_CG * 8 * cdiv(f.M, 8)), dim3(512), 0, st, x, ldx, Xf, f, 1, in_scale,
-                       in_shift, in_relu);
+                       in_shift, in_relu, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr);
     launch_weights(f, w, Wf, st);
     hipLaunchKernelGGL(cgemm_bins_kernel<false>, dim3(cdiv(f.M, 64) * (f.N / 64) * FFT_BINS), dim3(256), 0, st,
                        (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, f.N, f.C);
@@ -792,7 +847,7 @@ extern "C" size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     const size_t cm = f.C > f.N ? f.C : f.N;
     const size_t padded = f.reflect ? al256((size_t)f.B * (f.H + 2 * f.pad) * (f.W + 2 * f.pad) * f.C * 4) : 0;
     return al256((size_t)f.M * FFT_N * FFT_NK * cm * 8) + al256((size_t)f.M * FFT_BINS * f.N * 8) +
-           al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)FFT_BINS * 3 * f.C * f.N * 4) + padded;
+           al256((size_t)f.M * FFT_BINS * f.C * 8) + wf_region_bytes(f) + padded;
 }
 
 // slots of the BatchNorm-backward partials the data-gradient epilogue can emit (0: not available for this layer)
@@ -805,10 +860,13 @@ extern "C" int64_t gdn_fftconv_bnb_slots(const gdn_conv_geom* g) {
 extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w, const void* xf,
                                float* dx, int32_t ldx, const float* addsrc, int32_t ld_add, float* dw,
                                const float* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu,
-                               float* bnb_partial, int32_t phases, void* workspace, size_t workspace_bytes, void* stream) {
+                               float* bnb_partial, const float* dyb_y, int32_t ld_dyb, const float* dyb_co,
+                               const float* dyb_kk, int32_t dyb_relu, int32_t phases, void* workspace,
+                               size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
     FftGeom f;
     if (!fft_geom(g, f) || f.flip) return GDN_ERR_UNSUPPORTED;
+    if (dyb_y && (!dyb_co || !dyb_kk)) return GDN_ERR_BAD_ARG;
     if (!dy || (!dx && !dw) || (dx && !w && !xf) || (dw && !xf)) return GDN_ERR_BAD_ARG;
     if (dx && f.reflect && ((ldx % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
     if (bnb_y && (!dx || !bnb_co || !bnb_partial)) return GDN_ERR_BAD_ARG;
@@ -821,7 +879,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     float2* R = (float2*)p; p += al256((size_t)f.M * FFT_N * FFT_NK * cm * 8);
     float2* Df = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.N * 8);
     float2* Ef = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.C * 8);
-    float* Wf = (float*)p; p += al256((size_t)FFT_BINS * 3 * f.C * f.N * 4);   // weight-gradient products P, or the weight spectrum when the forward saved none
+    float* Wf = (float*)p; p += wf_region_bytes(f);   // weight-gradient products P (per split), or the weight spectrum when the forward saved none
     float* dxp = (float*)p;          // reflection layers: gradient over the padded domain
     auto blocks = [](int64_t n) { const int64_t b = cdiv64(n, 256); return (unsigned)(b < 65536 * 8 ? b : 65536 * 8); };
     if (phases & GDN_FFT_BWD_TRANSFORM) {
@@ -830,17 +888,18 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         fd.C = f.N;
         fd.reflect = 0;
         hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.N / FFT_CG * 8 * cdiv(f.M, 8)), dim3(512), 0, st, dy, ldy, Df, fd, 0,
-                           (const float*)nullptr, (const float*)nullptr, 0);
+                           (const float*)nullptr, (const float*)nullptr, dyb_relu, dyb_y, ld_dyb, dyb_co, dyb_kk);
     }
     // The weight-gradient chain (reduction GEMM + tap transform) and the data-gradient chain only share Df and use disjoint
     // parts of the workspace, so a caller may run them as separate calls on two streams of its own (phases; the library
     // itself holds no stream, event or other state).
     if (dw && (phases & GDN_FFT_BWD_DW)) {
         float* P = Wf;
-        hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * FFT_BINS), dim3(256), 0, st,
-                           (const float*)Df, (const float*)xf, P, f.M, f.N, f.C);
+        const int ns = tn_splits(f);
+        hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * FFT_BINS * ns), dim3(256), 0, st,
+                           (const float*)Df, (const float*)xf, P, f.M, f.N, f.C, ns);
 #define GDN_TAPS(KK) case KK: \
-            hipLaunchKernelGGL(fft_wgrad_taps_kernel<KK>, dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
+            hipLaunchKernelGGL(fft_wgrad_taps_kernel<KK>, dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C, ns); \
             break;
         switch (f.k) {
             GDN_TAPS(3) GDN_TAPS(5) GDN_TAPS(7) GDN_TAPS(9)

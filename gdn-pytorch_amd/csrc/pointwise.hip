@@ -553,6 +553,32 @@ extern "C" int gdn_bn_bwd(const void* dout, int32_t ld_dout, const void* y, int3
     return gdn_launch_status();
 }
 
+// Passes 1 + 2 only: dgamma, dbeta and kk = {k1 = mean(dz), k2 = mean(dz*xhat)}[C] for a consumer that applies pass 3 itself while
+// loading (gdn_fftconv_bwd's dyb_* arguments).  ext_partial as in gdn_bn_bwd.
+extern "C" int gdn_bn_bwd_coeffs(const void* dout, int32_t ld_dout, const void* y, int32_t ldy, const float* scale,
+                                 const float* shift, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                 float* kk, int64_t npix, int32_t C, int32_t relu, const float* ext_partial,
+                                 int64_t ext_slots, void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    if (!scale || !shift || !mean || !invstd || !kk || npix <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
+    if (ext_partial && (ext_slots <= 0 || ext_slots > 0x7fffffff)) return GDN_ERR_BAD_ARG;
+    if (ext_partial) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, ST(stream), ext_partial, (int)ext_slots, C,
+                           (double)npix, dgamma, dbeta, kk, kk + C);
+        return gdn_launch_status();
+    }
+    if (!dout || !y) return GDN_ERR_BAD_ARG;
+    if ((C % 4) || (ldy % 4) || (ld_dout % 4)) return GDN_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < gdn_bn_bwd_workspace_bytes(npix, C)) return GDN_ERR_WORKSPACE;
+    const int nblk = bnb_blocks(npix);
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, ST(stream), dout, ld_dout, y, ldy, scale, shift,
+                       mean, invstd, partial, npix, C, relu, dtypes);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, ST(stream), (const float*)partial, nblk, C,
+                       (double)npix, dgamma, dbeta, kk, kk + C);
+    return gdn_launch_status();
+}
+
 // Backward of out = [relu](y*scale + shift) with FIXED per-channel coefficients (eval-mode BatchNorm of a frozen
 // network): dy = scale * dout * [z > 0].  No reductions, no parameter gradients.
 __global__ __launch_bounds__(256) void bn_eval_bwd_kernel(const void* __restrict__ dout, int ld_dout,

@@ -383,6 +383,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     bnb_slots = op.fft_bnb_slots if use_fft else op.wino_bnb_slots if use_wino else None
     state_kw = "spectrum" if use_fft else "state"
     bstate_kw = "xf" if use_fft else "state"
+    use_fft_only = use_fft
     use_fft = use_fft or use_wino
     in_kw = {}
     xt = x                               # the tensor the conv kernels read
@@ -443,7 +444,15 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                                "(requires_grad False on the conv and BN parameters): the guide network of --latent_grad")
             if residual is not None:
                 ctx.add_grad(residual, da)
-            if bn_training:
+            dyb = None
+            if bn_training and use_fft_only and _FUSE_TRAIN_BN and da.is_contiguous() and da.dtype == torch.float32:
+                # frequency-domain layer: dy has one reader (the dy transform), which applies pass 3 of the BatchNorm
+                # backward while loading -- dy is never written
+                kk = ops.bn_bwd_coeffs(da, y, co, relu, bn.weight.grad if not frozen else None,
+                                       bn.bias.grad if not frozen else None, partial=out_info.partial)
+                out_info.partial = None
+                dy, dyb = da, (y, co, kk, relu)
+            elif bn_training:
                 dy = ops.bn_bwd(da, y, bn.weight.data, co, relu, bn.weight.grad if not frozen else None,
                                 bn.bias.grad if not frozen else None, out_dtype=ldt, partial=out_info.partial)
                 out_info.partial = None
@@ -466,8 +475,9 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                         if slots > 0:
                             part = torch.empty((slots, 2, conv.in_channels), dtype=torch.float32, device=dy.device)
                             bnb = (xin.y, xin.co, xin.relu, part)
+                    extra = {"dyb": dyb} if dyb is not None else {}
                     dx = alt_bwd(dy, w, in_hw, dw_tap=gv, need_dx=want_dx, **{bstate_kw: xf},
-                                 addsrc=ctx.pop_grad_as(x, ldt) if want_dx else None, bnb=bnb)
+                                 addsrc=ctx.pop_grad_as(x, ldt) if want_dx else None, bnb=bnb, **extra)
                     if want_dx:
                         ctx.grads[id(x)] = (x, dx)
                         if bnb is not None:

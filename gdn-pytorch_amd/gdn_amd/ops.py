@@ -230,12 +230,14 @@ class Conv:
         _, ref, _, _ = self.geom(B, H, W)
         return int(lib.gdn_winoconv_bnb_slots(ref))
 
-    def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None, bnb=None):
+    def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None, bnb=None, dyb=None):
         """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's saved state xf:
         input + weight spectra) from one transform of dy.  w_tap is the FORWARD tap-major weight [k*k, Cout, Cin]; it is
         only read when xf is None.
         bnb = (y_raw, coeffs[4,Cin], relu, partial_out): dx is the gradient of [relu](BN_train(y_raw)); the epilogue also
-        writes that BatchNorm's backward partials (see gdn_fftconv_bwd)."""
+        writes that BatchNorm's backward partials (see gdn_fftconv_bwd).
+        dyb = (y_raw, coeffs[4,Cout], kk[2,Cout], relu): `dy` is dout of THIS layer's train-mode BatchNorm; the dy transform
+        applies scale*(dz - k1 - xhat*k2) while loading (kk from bn_bwd_coeffs)."""
         _chk(dy, "dy")
         B = dy.shape[0]
         H, W = in_hw
@@ -248,11 +250,13 @@ class Conv:
         dx = torch.empty((B, H, W, self.cin), dtype=torch.float32, device=dy.device) if need_dx else None
         ws = workspace(nb, dy.device, "fft")
         by, bco, brelu, bpart = bnb if (bnb is not None and need_dx) else (None, None, False, None)
+        yy, yco, ykk, yrelu = dyb if dyb is not None else (None, None, None, False)
 
         def call(phases, st):
             lib.gdn_fftconv_bwd(ref, _p(dy), _ld(dy), _p(w_tap), _p(xf), _p(dx),
                                 0 if dx is None else _ld(dx), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
                                 _p(dw_tap), _p(by), 0 if by is None else _ld(by), _p(bco), 1 if brelu else 0, _p(bpart),
+                                _p(yy), 0 if yy is None else _ld(yy), _p(yco), _p(ykk), 1 if yrelu else 0,
                                 phases, _p(ws), nb, st)
         if dw_tap is not None and need_dx and _FFT_OVERLAP:
             # the two chains only share the spectrum of dy and are each latency-bound: the weight-gradient chain runs on a
@@ -416,6 +420,20 @@ def bn_bwd(dout, y, gamma, coeffs, relu, dgamma, dbeta, out_dtype=None, partial=
                    _p(coeffs[3]), _p(dy), _ld(dy), _p(dgamma), _p(dbeta), npix, C, 1 if relu else 0,
                    _p(partial), 0 if partial is None else partial.shape[0], _p(ws), nb, _mask(dout, y, dy), stream())
     return dy
+
+
+def bn_bwd_coeffs(dout, y, coeffs, relu, dgamma, dbeta, partial=None):
+    """Passes 1 + 2 of the BatchNorm backward: writes dgamma / dbeta (may be None), returns kk [2,C] = mean(dz), mean(dz*xhat)
+    for a consumer that applies pass 3 in its loader (Conv.fft_bwd dyb)."""
+    B, H, W, C = y.shape
+    npix = B * H * W
+    kk = torch.empty((2, C), dtype=torch.float32, device=y.device)
+    nb = int(lib.gdn_bn_bwd_workspace_bytes(npix, C))
+    ws = workspace(nb, y.device, "bnbwd")
+    lib.gdn_bn_bwd_coeffs(_p(dout), _ld(dout), _p(y), _ld(y), _p(coeffs[0]), _p(coeffs[1]), _p(coeffs[2]), _p(coeffs[3]),
+                          _p(dgamma), _p(dbeta), _p(kk), npix, C, 1 if relu else 0, _p(partial),
+                          0 if partial is None else partial.shape[0], _p(ws), nb, _mask(dout, y), stream())
+    return kk
 
 
 def bn_eval_bwd(dout, y, coeffs, relu, out_dtype=None):

@@ -166,14 +166,19 @@ int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const f
  * gradient of z = [relu](BN_train(bnb_y)), bnb_y [B,H,W,Cin] with pitch ld_bnb being that BatchNorm's
  * input and bnb_co = {scale, shift, mean, invstd}[Cin]; the epilogue that writes dx (+ addsrc) also
  * writes bnb_partial[slot][2][Cin] = per-slot sum(dz), sum(dz*xhat), dz = dx*[z>0 if bnb_relu],
- * slots = gdn_fftconv_bnb_slots(g) (0: not available -- reflection-padded layers). */
+ * slots = gdn_fftconv_bnb_slots(g) (0: not available -- reflection-padded layers).
+ * dyb_* (nullable; replaces pass 3 of gdn_bn_bwd for THIS layer's own BatchNorm): `dy` is dout, the
+ * gradient of z = [relu](BN_train(dyb_y)) with dyb_y this layer's raw conv output, dyb_co = {scale, shift,
+ * mean, invstd}[Cout] and dyb_kk = {k1, k2}[Cout] from gdn_bn_bwd_coeffs; the dy transform computes
+ * dy = scale*(dz - k1 - xhat*k2) while loading, so dy itself is never written to memory. */
 enum { GDN_FFT_BWD_TRANSFORM = 1, GDN_FFT_BWD_DW = 2, GDN_FFT_BWD_DX = 4, GDN_FFT_BWD_ALL = 7 };
 size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g);
 int64_t gdn_fftconv_bnb_slots(const gdn_conv_geom* g);
 int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w,
                     const void* xf, float* dx, int32_t ldx, const float* addsrc, int32_t ld_add,
                     float* dw, const float* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu,
-                    float* bnb_partial, int32_t phases,
+                    float* bnb_partial, const float* dyb_y, int32_t ld_dyb, const float* dyb_co,
+                    const float* dyb_kk, int32_t dyb_relu, int32_t phases,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* Winograd F(2x2,3x3) convolution for the 3x3 stride-1 layers (zero or reflection padding 1) on
@@ -268,6 +273,14 @@ int gdn_bn_bwd(const void* dout, int32_t ld_dout, const void* y, int32_t ldy,
                int64_t npix, int32_t C, int32_t relu,
                const float* ext_partial, int64_t ext_slots,
                void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream);
+
+/* Passes 1 + 2 of gdn_bn_bwd only: dgamma, dbeta (nullable) and kk = {mean(dz), mean(dz*xhat)}[C] for a consumer that
+ * applies pass 3 while loading (gdn_fftconv_bwd dyb_*).  With ext_partial, dout / y / workspace may be NULL. */
+int gdn_bn_bwd_coeffs(const void* dout, int32_t ld_dout, const void* y, int32_t ldy,
+                      const float* scale, const float* shift, const float* mean, const float* invstd,
+                      float* dgamma, float* dbeta, float* kk, int64_t npix, int32_t C, int32_t relu,
+                      const float* ext_partial, int64_t ext_slots,
+                      void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream);
 
 /* Backward of out = [relu](y*scale + shift) through an EVAL-mode BatchNorm (fixed coefficients from
  * gdn_bn_eval_coeffs): dy = scale*dout*[z>0].  Used when a gradient crosses the frozen guide network

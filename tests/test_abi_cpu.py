@@ -125,3 +125,26 @@ def test_save_path_and_options():
     sp = str(save_path_formatter(a, option.parser))
     assert sp.startswith("kitti,b20/")
     assert crop_box_kitti(128, 416) == (52, 126, 14, 401)      # SURVEY 3.1 [probed]
+
+
+def test_host_planning_code_under_asan():
+    """SURVEY 5 (sanitizers): the host side of the C ABI -- geometry, tile / split-K / segment plans, workspace and slot
+    sizes, argument checks -- built with AddressSanitizer (build.py --asan: host objects instrumented; GPU ASan is not
+    available on this pool) and driven over every layer shape of the three networks, ragged shapes and invalid
+    geometries.  ASan aborts the child on any out-of-bounds access or use-after-free."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("gdn_build", REPO / "gdn-pytorch_amd" / "build.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lib = mod.build_asan()
+    rt = mod.asan_runtime()
+    assert rt and os.path.exists(rt), "clang ASan runtime not found"
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", GDN_HIP_LIB=str(lib),
+               PYTHONPATH=os.pathsep.join([str(REPO / "gdn-pytorch_amd"), str(REPO)]))
+    r = subprocess.run([sys.executable, str(REPO / "tests" / "asan_host_queries.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "asan host queries ok" in r.stdout, r.stdout[-2000:] + r.stderr[-6000:]
+    assert "AddressSanitizer" not in r.stderr

@@ -354,9 +354,17 @@ __global__ __launch_bounds__(256, 4) void cgemm_tn_bins_kernel(const float* __re
 // lookups instead of 32*K*K (the lookups, wave-uniform scalar loads, bounded the earlier per-tap-row kernels).
 // block = 64 (n, c) pairs x 4 groups of kx (one wave each: every twiddle index is wave-uniform); the four partial tap sets
 // meet in LDS in a fixed order.
+// P[0] += P[1] + ... + P[nsplit-1] (fixed order): the partial spectra of a split weight-gradient reduction
+__global__ __launch_bounds__(256) void fft_sum_splits_kernel(float* __restrict__ P, int64_t n4, int nsplit) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(P)[i];
+        for (int sp = 1; sp < nsplit; ++sp) v += reinterpret_cast<const f32x4*>(P)[(int64_t)sp * n4 + i];
+        reinterpret_cast<f32x4*>(P)[i] = v;
+    }
+}
+
 template <int K>
-__global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C,
-                                                             int nsplit) {
+__global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C) {
     __shared__ float red[3][K * K][64];
     const int pl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + pl;             // N*C is a multiple of 64
@@ -373,11 +381,7 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
         for (int ty = 0; ty < K; ++ty) { gr[ty] = 0.f; gi[ty] = 0.f; }
 #pragma unroll 8
         for (int ky = 0; ky < FFT_N; ++ky) {
-            float2 v = F[(size_t)(ky * FFT_NK + kx) * bs];
-            for (int sp = 1; sp < nsplit; ++sp) {              // partial spectra of a split reduction, fixed order
-                const float2 u = F[((size_t)sp * FFT_BINS + ky * FFT_NK + kx) * bs];
-                v.x += u.x; v.y += u.y;
-            }
+            const float2 v = F[(size_t)(ky * FFT_NK + kx) * bs];
 #pragma unroll
             for (int ty = 0; ty < K; ++ty) {
                 const int ph = (ky * ty) & 31;
@@ -898,8 +902,12 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         const int ns = tn_splits(f);
         hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * FFT_BINS * ns), dim3(256), 0, st,
                            (const float*)Df, (const float*)xf, P, f.M, f.N, f.C, ns);
+        if (ns > 1) {
+            const int64_t n4 = (int64_t)FFT_BINS * f.N * f.C * 2 / 4;
+            hipLaunchKernelGGL(fft_sum_splits_kernel, dim3(blocks(n4)), dim3(256), 0, st, P, n4, ns);
+        }
 #define GDN_TAPS(KK) case KK: \
-            hipLaunchKernelGGL(fft_wgrad_taps_kernel<KK>, dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C, ns); \
+            hipLaunchKernelGGL(fft_wgrad_taps_kernel<KK>, dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
             break;
         switch (f.k) {
             GDN_TAPS(3) GDN_TAPS(5) GDN_TAPS(7) GDN_TAPS(9)

@@ -23,6 +23,10 @@ _WINOGRAD = os.environ.get("GDN_WINOGRAD", "1") != "0"
 # train-mode BatchNorm fusion (A/B switch): scale/shift/ReLU of a ResidualBlock's first half applied in the consumer's
 # loader, BatchNorm-backward reductions emitted by the data-gradient epilogues
 _FUSE_TRAIN_BN = os.environ.get("GDN_FUSE_TRAIN_BN", "1") != "0"
+# fp32 4x4 stride-2 pad-1 Conv2d / ConvTranspose2d layers run as Winograd F(3x3,2x2) over the polyphase images
+# (csrc/conv_wino2.hip) when both channel counts reach this value (0 disables): the transforms move ~1.8x the
+# layer's activations (measured: a gain on every such layer of G, the smallest at 64 channels, tests/diag/wino2_time.py)
+_WINO2_MIN_C = int(os.environ.get("GDN_WINO2_MIN_C", "64"))
 _GRAPH_EPOCH = 0
 
 
@@ -377,18 +381,21 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                and conv.stride[0] == 1 and op.fft_ok(x.shape[0], x.shape[1], x.shape[2], backward=ctx.record))
     use_wino = (not use_fft and _WINOGRAD and ldt == torch.float32 and x2 is None
                 and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and op.wino_ok(x.shape[0], x.shape[1], x.shape[2]))
-    # the two transform-domain paths share one call shape: forward (+ saved state), backward from that state
-    alt_fwd = op.fft_fwd if use_fft else op.wino_fwd if use_wino else None
-    alt_bwd = op.fft_bwd if use_fft else op.wino_bwd if use_wino else None
-    bnb_slots = op.fft_bnb_slots if use_fft else op.wino_bnb_slots if use_wino else None
+    use_wino2 = (not use_fft and not use_wino and _WINO2_MIN_C > 0 and ldt == torch.float32 and x2 is None
+                 and conv.kernel_size[0] == 4 and conv.stride[0] == 2 and not isinstance(x, BnOut)
+                 and min(conv.in_channels, conv.out_channels) >= _WINO2_MIN_C and op.wino2_ok(x.shape[0], x.shape[1], x.shape[2]))
+    # the transform-domain paths share one call shape: forward (+ saved state), backward from that state
+    alt_fwd = op.fft_fwd if use_fft else op.wino_fwd if use_wino else op.wino2_fwd if use_wino2 else None
+    alt_bwd = op.fft_bwd if use_fft else op.wino_bwd if use_wino else op.wino2_bwd if use_wino2 else None
+    bnb_slots = op.fft_bnb_slots if use_fft else op.wino_bnb_slots if use_wino else (lambda *a: 0)
     state_kw = "spectrum" if use_fft else "state"
     bstate_kw = "xf" if use_fft else "state"
     use_fft_only = use_fft
-    use_fft = use_fft or use_wino
+    use_fft = use_fft or use_wino or use_wino2
     in_kw = {}
     xt = x                               # the tensor the conv kernels read
     if lazy:
-        if use_fft and _FUSE_TRAIN_BN:
+        if use_fft and not use_wino2 and _FUSE_TRAIN_BN:
             in_kw = dict(in_affine=(x.co[0], x.co[1]), in_relu=x.relu)
             xt = x.y
         else:
@@ -463,7 +470,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                 # one transform of dy feeds both gradients; the forward's input spectrum is reused for dw
                 gv = None
                 if not frozen:
-                    gv = tap_view(conv.weight.grad, False)
+                    gv = tap_view(conv.weight.grad, isinstance(conv, torch.nn.ConvTranspose2d))
                     if gv is None:
                         raise GdnError("weight.grad is not tap-major")
                 if gv is not None or want_dx:

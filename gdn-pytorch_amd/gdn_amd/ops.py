@@ -324,6 +324,55 @@ class Conv:
                              1 if brelu else 0, _p(bpart), _p(ws), nb, stream())
         return dx
 
+    # ---- Winograd F(3x3,2x2) path (csrc/conv_wino2.hip): 4x4 stride-2 pad-1 Conv2d / ConvTranspose2d, fp32, 64..512 channels ----
+    def wino2_ok(self, B, H, W):
+        _, ref, _, _ = self.geom(B, H, W)
+        return int(lib.gdn_wino2conv_fwd_workspace_bytes(ref)) > 0
+
+    def wino2_fwd(self, x, w_tap, stats=False, addsrc=None, state=False, affine=None, act=ACT_NONE):
+        """y = conv / conv-transpose (k4, s2, p1) (+ epilogue) by Winograd F(3x3,2x2) over the polyphase images; returns y,
+        then the BatchNorm partials when `stats`, then the saved state for wino2_bwd when `state` (the transformed input of a
+        Conv2d; the input tensor itself for a ConvTranspose2d, whose backward transforms dy instead)."""
+        _chk(x, "x"); _chk(w_tap, "w")
+        B, H, W, C1 = x.shape
+        _, ref, Ho, Wo = self.geom(B, H, W)
+        nb = int(lib.gdn_wino2conv_fwd_workspace_bytes(ref))
+        if nb == 0 or C1 != self.cin:
+            raise GdnError("wino2conv: unsupported layer k=%d stride=%d Cin=%d Cout=%d" % (self.k, self.stride, C1, self.cout))
+        y = torch.empty((B, Ho, Wo, self.cout), dtype=torch.float32, device=x.device)
+        st = torch.empty((int(lib.gdn_wino2conv_stats_slots(ref)), 2, self.cout), dtype=torch.float32,
+                         device=x.device) if stats else None
+        sv = None
+        if state:
+            sb = int(lib.gdn_wino2conv_state_bytes(ref))
+            sv = torch.empty(sb, dtype=torch.uint8, device=x.device) if sb else x
+        ws = workspace(nb, x.device, "fft")
+        lib.gdn_wino2conv_fwd(ref, _p(x), _ld(x), _p(w_tap), _p(y), _ld(y), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
+                              _p(st), _p(affine[0]) if affine else None, _p(affine[1]) if affine else None, int(act),
+                              _p(sv) if (sv is not None and sv is not x) else None, _p(ws), nb, stream())
+        res = (y,) + ((st,) if stats else ()) + ((sv,) if state else ())
+        return res if len(res) > 1 else y
+
+    def wino2_bwd(self, dy, w_tap, in_hw, state=None, dw_tap=None, need_dx=True, addsrc=None, bnb=None):
+        """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's `state`)."""
+        _chk(dy, "dy")
+        B = dy.shape[0]
+        H, W = in_hw
+        _, ref, Ho, Wo = self.geom(B, H, W)
+        nb = int(lib.gdn_wino2conv_bwd_workspace_bytes(ref))
+        if nb == 0:
+            raise GdnError("wino2conv: unsupported layer k=%d stride=%d" % (self.k, self.stride))
+        if tuple(dy.shape[1:]) != (Ho, Wo, self.cout):
+            raise GdnError("wino2_bwd: dy shape %s does not match layer output" % (tuple(dy.shape),))
+        dx = torch.empty((B, H, W, self.cin), dtype=torch.float32, device=dy.device) if need_dx else None
+        ws = workspace(nb, dy.device, "fft")
+        xin = state if self.transposed else None
+        sv = None if self.transposed else state
+        lib.gdn_wino2conv_bwd(ref, _p(dy), _ld(dy), _p(w_tap), _p(xin), 0 if xin is None else _ld(xin), _p(sv), _p(dx),
+                              0 if dx is None else _ld(dx), _p(addsrc), 0 if addsrc is None else _ld(addsrc), _p(dw_tap),
+                              _p(ws), nb, stream())
+        return dx
+
     def wgrad(self, x, dy, dw_tap, ci_off=0, cfg=0):
         """dw_tap[tap][co][ci_off + ci] = wgrad over the channel slice x (Cx = x.shape[3]).
         bf16 x/dy take the bf16 MFMA kernel; dw_tap is fp32 either way."""

@@ -210,6 +210,29 @@ int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const
                      float* dw, const float* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu,
                      float* bnb_partial, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Winograd F(3x3,2x2) for the 4x4 stride-2 pad-1 layers of G (ConvBlock(k4,s2,p1) AE_model_unet.py:497-500 with
+ * ReflectionPad2d(1) or zero padding; ConvTBlock = ConvTranspose2d(k4,s2,p1) :517-520), fp32: the layer is a 2x2
+ * stride-1 convolution over the four polyphase images of its input, computed with 16 instead of 36 multiplies per 3x3
+ * output tile (2.25x fewer than the direct kernel; same interpolation points as F(2x2,3x3)).  Cin, Cout in
+ * {64,128,256,512}; Conv2d needs even H, W.  y / addsrc / stats / ep_scale / ep_shift / act as for gdn_conv_fwd (no tanh;
+ * slots: gdn_wino2conv_stats_slots).  state_out (Conv2d only, gdn_wino2conv_state_bytes) receives the transformed input
+ * for the weight gradient.
+ * Backward: dx = dgrad (+ addsrc) when dx != NULL (needs w); dw[tap][Cout][Cin] when dw != NULL -- a Conv2d needs `state`,
+ * a ConvTranspose2d needs x (its forward input, pitch ldx_in): its weight gradient shares the transform of dy with the
+ * data gradient. */
+size_t gdn_wino2conv_fwd_workspace_bytes(const gdn_conv_geom* g);
+size_t gdn_wino2conv_state_bytes(const gdn_conv_geom* g);
+int64_t gdn_wino2conv_stats_slots(const gdn_conv_geom* g);
+int gdn_wino2conv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w,
+                      float* y, int32_t ldy, const float* addsrc, int32_t ld_add, float* stats,
+                      const float* ep_scale, const float* ep_shift, int32_t act,
+                      void* state_out, void* workspace, size_t workspace_bytes, void* stream);
+size_t gdn_wino2conv_bwd_workspace_bytes(const gdn_conv_geom* g);
+int gdn_wino2conv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w,
+                      const float* x, int32_t ldx_in, const void* state,
+                      float* dx, int32_t ldx, const float* addsrc, int32_t ld_add, float* dw,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* bf16 weight gradient (BASELINE configs[2]): x and dy hold bfloat16, dw is fp32 (the master
  * gradient arena).  Same contract as gdn_conv_wgrad otherwise.  Needs Cx and Cout multiples of
  * 64, pixel pitches multiples of 8 and 16-byte aligned bases.  cfg: 0 automatic, 1/2 force the

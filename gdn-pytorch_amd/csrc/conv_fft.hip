@@ -416,103 +416,53 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
 // even and odd tiles are written by two launches (parity): the first writer of a column stores (+ addsrc), the second adds.
 __global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __restrict__ S, float* __restrict__ dx, int lddx,
                                                                 const float* __restrict__ addsrc, int ld_add, FftGeom g,
-                                                                int parity, int Ho, int Wo, int off, int cq_shift,
-                                                                const float* __restrict__ bnb_y, int ld_bnb,
-                                                                const float* __restrict__ bnb_co, int bnb_relu,
-                                                                float* __restrict__ bnb_partial) {
+                                                                int parity, int Ho, int Wo, int off, int cq_shift) {
     // output image Ho x Wo; patch row j of tile row ty lands on output row ty*T - off + j  (off = pad for a zero-padded
     // layer: dx itself; off = 0 for a reflection-padded one: the padded-domain gradient, folded afterwards)
     // grid: x = (tile-of-this-parity / 4) * (C / 64) + channel chunk, y = output row, z = image; block = 4 tiles x 64 channels
-    // bnb_y != NULL: dx is the gradient of a train-mode BatchNorm's output z = [relu](BN(bnb_y)); every element whose value
-    // is final after this launch also feeds that layer's backward reduction (sum dz, sum dz*xhat; slot = workgroup), so
-    // the stand-alone reduce pass over (dx, y) disappears.  Both parity launches then use the parity-0 grid.
-    __shared__ float red[256 * 2];
     const int C = g.C, T = g.T;
     const int ntx = (g.tiles_x + 1 - parity) / 2;         // tiles of this parity per row
     const int txl = (blockIdx.x >> cq_shift) * 4 + (threadIdx.x >> 6);
-    const bool live = txl < ntx;
-    if (!live && !bnb_y) return;
+    if (txl >= ntx) return;
     const int c = (blockIdx.x & ((1 << cq_shift) - 1)) * 64 + (threadIdx.x & 63);
     const int tx = txl * 2 + parity, iy = blockIdx.y, b = blockIdx.z;
-    float s1 = 0.f, s2 = 0.f;
-    if (live) {
-        const int q = iy + off;
-        const int ty_a = q / T, j_a = q - ty_a * T;
-        float re[32], im[32];
+    const int q = iy + off;
+    const int ty_a = q / T, j_a = q - ty_a * T;
+    float re[32], im[32];
 #pragma unroll
-        for (int kx = 0; kx < FFT_NK; ++kx) { re[kx] = 0.f; im[kx] = 0.f; }
-        if (ty_a < g.tiles_y) {
-            const int t = (b * g.tiles_y + ty_a) * g.tiles_x + tx;
-            const float2* src = S + (((size_t)t * FFT_N + j_a) * FFT_NK) * C + c;
+    for (int kx = 0; kx < FFT_NK; ++kx) { re[kx] = 0.f; im[kx] = 0.f; }
+    if (ty_a < g.tiles_y) {
+        const int t = (b * g.tiles_y + ty_a) * g.tiles_x + tx;
+        const float2* src = S + (((size_t)t * FFT_N + j_a) * FFT_NK) * C + c;
 #pragma unroll
-            for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = *src; re[kx] = v.x; im[kx] = v.y; src += C; GDN_KEEP(src); }
-        }
-        if (ty_a >= 1 && j_a + T < FFT_N) {
-            const int t = (b * g.tiles_y + ty_a - 1) * g.tiles_x + tx;
-            const float2* src = S + (((size_t)t * FFT_N + j_a + T) * FFT_NK) * C + c;
-#pragma unroll
-            for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = *src; re[kx] += v.x; im[kx] += v.y; src += C; GDN_KEEP(src); }
-        }
-#pragma unroll
-        for (int kx = FFT_NK; kx < 32; ++kx) { re[kx] = re[32 - kx]; im[kx] = -im[32 - kx]; }
-        fft32<1>(re, im);
-        const int ix0 = tx * T - off;
-        float* dst = dx + ((size_t)(b * Ho + iy) * Wo + ix0) * lddx + c;               // may point before the row: only
-        const float* ad = addsrc ? addsrc + ((size_t)(b * Ho + iy) * Wo + ix0) * ld_add + c : nullptr;   // dereferenced in range
-        const bool has_next = tx + 1 < g.tiles_x;
-        const int km1 = g.k - 1;
-        if (!bnb_y) {
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                const int ix = ix0 + j;
-                if (ix >= 0 && ix < Wo) {
-                    const float val = re[j] * (1.0f / 1024.0f);
-                    // odd tiles: columns shared with the even neighbours were stored by the first launch
-                    const bool second = parity == 1 && (j < km1 || (j >= T && has_next));
-                    if (second) *dst += val;
-                    else *dst = ad ? val + *ad : val;
-                }
-                dst += lddx; GDN_KEEP(dst);
-                if (ad) { ad += ld_add; GDN_KEEP(ad); }
-            }
-        } else {
-            const float* yb = bnb_y + ((size_t)(b * Ho + iy) * Wo + ix0) * ld_bnb + c;
-            const float bs = bnb_co[c], bt = bnb_co[C + c], bmu = bnb_co[2 * C + c], bis = bnb_co[3 * C + c];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                const int ix = ix0 + j;
-                if (ix >= 0 && ix < Wo) {
-                    float val = re[j] * (1.0f / 1024.0f);
-                    const bool shared = (j < km1 && tx >= 1) || (j >= T && has_next);     // a neighbour tile of the other parity also lands here
-                    if (parity == 1 && shared) val += *dst;
-                    else if (ad) val += *ad;
-                    *dst = val;
-                    if (parity == 1 || !shared) {                                       // final value of this element
-                        const float yv = *yb;
-                        float dz = val;
-                        if (bnb_relu && !(yv * bs + bt > 0.f)) dz = 0.f;
-                        s1 += dz; s2 += dz * ((yv - bmu) * bis);
-                    }
-                }
-                dst += lddx; GDN_KEEP(dst);
-                yb += ld_bnb; GDN_KEEP(yb);
-                if (ad) { ad += ld_add; GDN_KEEP(ad); }
-            }
-        }
+        for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = *src; re[kx] = v.x; im[kx] = v.y; src += C; GDN_KEEP(src); }
     }
-    if (bnb_y) {
-        red[threadIdx.x * 2] = s1; red[threadIdx.x * 2 + 1] = s2;
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            float a1 = 0.f, a2 = 0.f;
+    if (ty_a >= 1 && j_a + T < FFT_N) {
+        const int t = (b * g.tiles_y + ty_a - 1) * g.tiles_x + tx;
+        const float2* src = S + (((size_t)t * FFT_N + j_a + T) * FFT_NK) * C + c;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { a1 += red[(j * 64 + threadIdx.x) * 2]; a2 += red[(j * 64 + threadIdx.x) * 2 + 1]; }
-            const int nbx = gridDim.x >> cq_shift;
-            const size_t slot = (((size_t)parity * gridDim.z + b) * gridDim.y + iy) * nbx + (blockIdx.x >> cq_shift);
-            const int ch = (blockIdx.x & ((1 << cq_shift) - 1)) * 64 + threadIdx.x;
-            bnb_partial[(slot * 2 + 0) * C + ch] = a1;
-            bnb_partial[(slot * 2 + 1) * C + ch] = a2;
+        for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = *src; re[kx] += v.x; im[kx] += v.y; src += C; GDN_KEEP(src); }
+    }
+#pragma unroll
+    for (int kx = FFT_NK; kx < 32; ++kx) { re[kx] = re[32 - kx]; im[kx] = -im[32 - kx]; }
+    fft32<1>(re, im);
+    const int ix0 = tx * T - off;
+    float* dst = dx + ((size_t)(b * Ho + iy) * Wo + ix0) * lddx + c;               // may point before the row: only
+    const float* ad = addsrc ? addsrc + ((size_t)(b * Ho + iy) * Wo + ix0) * ld_add + c : nullptr;   // dereferenced in range
+    const bool has_next = tx + 1 < g.tiles_x;
+    const int km1 = g.k - 1;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int ix = ix0 + j;
+        if (ix >= 0 && ix < Wo) {
+            const float val = re[j] * (1.0f / 1024.0f);
+            // odd tiles: columns shared with the even neighbours were stored by the first launch
+            const bool second = parity == 1 && (j < km1 || (j >= T && has_next));
+            if (second) *dst += val;
+            else *dst = ad ? val + *ad : val;
         }
+        dst += lddx; GDN_KEEP(dst);
+        if (ad) { ad += ld_add; GDN_KEEP(ad); }
     }
 }
 
@@ -602,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restri
                 off_x += ldx; GDN_KEEP(off_x);
             }
         } else {
-            // dy = scale * (dz - k1 - xhat * k2) from (dout, y): no halo, no reflection in this mode
+            // dy = scale * (dz - k1 - xhat * k2) from (dout, y): zero border (no reflection in this mode)
             const int ch = cg + c;
             const float bs = bnb_co[ch], bt = bnb_co[g.C + ch], bmu = bnb_co[2 * g.C + ch], bis = bnb_co[3 * g.C + ch];
             const float k1 = bnb_kk[ch], k2 = bnb_kk[g.C + ch];
@@ -612,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restri
 #pragma unroll
             for (int bb = 0; bb < 32; ++bb) {
                 const int ix = ix0 + bb;
-                const bool ok = row_ok && bb < nvalid && ix < g.W;
+                const bool ok = row_ok && bb < nvalid && ix >= 0 && ix < g.W;
                 float v = 0.f;
                 if (ok) {
                     const float d = img[row_off + off_x], yv = yimg[yrow + off_y];
@@ -854,17 +804,9 @@ extern "C" size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
            al256((size_t)f.M * FFT_BINS * f.C * 8) + wf_region_bytes(f) + padded;
 }
 
-// slots of the BatchNorm-backward partials the data-gradient epilogue can emit (0: not available for this layer)
-extern "C" int64_t gdn_fftconv_bnb_slots(const gdn_conv_geom* g) {
-    FftGeom f;
-    if (!fft_geom(g, f) || f.flip || f.reflect) return 0;
-    return (int64_t)2 * f.B * f.H * cdiv((f.tiles_x + 1) / 2, 4);
-}
-
 extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w, const void* xf,
                                float* dx, int32_t ldx, const float* addsrc, int32_t ld_add, float* dw,
-                               const float* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu,
-                               float* bnb_partial, const float* dyb_y, int32_t ld_dyb, const float* dyb_co,
+                               const float* dyb_y, int32_t ld_dyb, const float* dyb_co,
                                const float* dyb_kk, int32_t dyb_relu, int32_t phases, void* workspace,
                                size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
@@ -873,8 +815,6 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     if (dyb_y && (!dyb_co || !dyb_kk)) return GDN_ERR_BAD_ARG;
     if (!dy || (!dx && !dw) || (dx && !w && !xf) || (dw && !xf)) return GDN_ERR_BAD_ARG;
     if (dx && f.reflect && ((ldx % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
-    if (bnb_y && (!dx || !bnb_co || !bnb_partial)) return GDN_ERR_BAD_ARG;
-    if (bnb_y && f.reflect) return GDN_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < gdn_fftconv_bwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     if (phases == 0) phases = GDN_FFT_BWD_ALL;
     hipStream_t st = (hipStream_t)stream;
@@ -920,7 +860,6 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         hipLaunchKernelGGL(cgemm_bins_kernel<true>, dim3(cdiv(f.M, 64) * (f.C / 64) * FFT_BINS), dim3(256), 0, st,
                            (const float*)Df, Wsaved ? Wsaved : (const float*)Wf, (float*)Ef, f.M, f.C, f.N);
         // inverse along ky into S, then rows: the tile rows that reach an image row are summed in the frequency domain
-        // (measured faster than the single-pass patch kernel with four parity launches, profiles/r01_fftconv_notes.txt)
         int cq_shift = 0;
         while ((64 << cq_shift) < f.C) ++cq_shift;           // C / 64 is 1, 2 or 4
         hipLaunchKernelGGL(ifft_cols_kernel, dim3(cdiv(f.M, 4) << cq_shift, FFT_NK), dim3(256), 0, st, (const float2*)Ef, R, f.C, f.M,
@@ -928,17 +867,14 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         const int Ho = f.reflect ? f.H + 2 * f.pad : f.H, Wo = f.reflect ? f.W + 2 * f.pad : f.W;
         for (int parity = 0; parity < 2; ++parity) {
             const int ntx = (f.tiles_x + 1 - parity) / 2;
-            if (ntx == 0 && !bnb_y) continue;
-            // with BatchNorm partials both launches use the parity-0 grid (every slot is written)
-            const dim3 gr(cdiv(bnb_y ? (f.tiles_x + 1) / 2 : ntx, 4) << cq_shift, Ho, f.B);
+            if (ntx == 0) continue;
+            const dim3 gr(cdiv(ntx, 4) << cq_shift, Ho, f.B);
             if (f.reflect)
                 hipLaunchKernelGGL(ifft_rows_overlap_kernel, gr, dim3(256), 0, st,
-                                   (const float2*)R, dxp, f.C, (const float*)nullptr, 0, f, parity, Ho, Wo, 0, cq_shift,
-                                   (const float*)nullptr, 0, (const float*)nullptr, 0, (float*)nullptr);
+                                   (const float2*)R, dxp, f.C, (const float*)nullptr, 0, f, parity, Ho, Wo, 0, cq_shift);
             else
                 hipLaunchKernelGGL(ifft_rows_overlap_kernel, gr, dim3(256), 0, st,
-                                   (const float2*)R, dx, ldx, addsrc, ld_add, f, parity, Ho, Wo, f.pad, cq_shift,
-                                   bnb_y, ld_bnb, bnb_co, bnb_relu, bnb_partial);
+                                   (const float2*)R, dx, ldx, addsrc, ld_add, f, parity, Ho, Wo, f.pad, cq_shift);
         }
         if (f.reflect)
             hipLaunchKernelGGL(fft_reflect_fold_kernel, dim3(blocks((int64_t)f.B * f.H * f.W * (f.C / 4))), dim3(256), 0, st,

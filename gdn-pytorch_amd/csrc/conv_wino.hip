@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 }
 
 // dW[tap][n][c] = (G^T P G)[ty][tx]
-__global__ __launch_bounds__(256) void wino_wgrad_output_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C) {
+__global__ __launch_bounds__(256) void wino_wgrad_output_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C,
+                                                                int nsplit) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N * C) return;
     float p[4][4];
@@ -216,7 +217,11 @@ __global__ __launch_bounds__(256) void wino_wgrad_output_kernel(const float* __r
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) { p[a][b] = *src; src += bs; GDN_KEEP(src); }
+        for (int b = 0; b < 4; ++b) {
+            float v = *src;
+            for (int sp = 1; sp < nsplit; ++sp) v += src[(size_t)sp * WINO_BINS * bs];      // split reduction, fixed order
+            p[a][b] = v; src += bs; GDN_KEEP(src);
+        }
     float r[3][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -251,6 +256,7 @@ inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 inline size_t v_bytes(const WinoGeom& f) { return al256((size_t)WINO_BINS * f.M * f.C * 4); }
 inline size_t u_bytes(const WinoGeom& f) { return al256((size_t)WINO_BINS * f.N * f.C * 4); }
 inline size_t m_bytes(const WinoGeom& f) { return al256((size_t)WINO_BINS * f.M * f.N * 4); }
+inline int tn_splits(const WinoGeom& f) { return wino_tn_splits(f.M, f.N, f.C); }
 
 }  // namespace
 
@@ -306,7 +312,8 @@ extern "C" size_t gdn_winoconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     const size_t Md = f.reflect ? (size_t)f.B * cdiv(f.H + 2, 2) * cdiv(f.W + 2, 2) : (size_t)f.M;
     const size_t vd = al256((size_t)WINO_BINS * Md * f.N * 4), eo = al256((size_t)WINO_BINS * Md * f.C * 4);
     const size_t padded = f.reflect ? al256((size_t)f.B * (f.H + 2) * (f.W + 2) * f.C * 4) : 0;
-    return (vd > m_bytes(f) ? vd : m_bytes(f)) + u_bytes(f) + (eo > u_bytes(f) ? eo : u_bytes(f)) + padded;
+    const size_t pr = (size_t)tn_splits(f) * u_bytes(f);            // weight-gradient products, one set per split
+    return (vd > m_bytes(f) ? vd : m_bytes(f)) + u_bytes(f) + (eo > pr ? eo : pr) + padded;
 }
 
 // slots of the BatchNorm-backward partials the data-gradient epilogue can emit (0: not available for this layer)
@@ -337,9 +344,9 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
     float* Eo = (float*)p;                       // data gradient: GEMM output [16][Md][C] (+ padded gradient); weight gradient: P
     if (dw) {
         hipLaunchKernelGGL(wino_dy_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, dy, ldy, Vd, f);
-        hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3((f.N / 64) * (f.C / 64) * WINO_BINS), dim3(256), 0, st, (const float*)Vd,
-                           (const float*)state, Eo, f.M, f.N, f.C);
-        hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, (const float*)Eo, dw, f.N, f.C);
+        const int ns = tn_splits(f);
+        launch_wino_gemm_tn((const float*)Vd, (const float*)state, Eo, f.M, f.N, f.C, ns, st);
+        hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, (const float*)Eo, dw, f.N, f.C, ns);
     }
     if (dx) {
         // the data gradient of a 3x3 layer is the same kind of convolution of dy with flipped, role-swapped taps: pad 1 onto

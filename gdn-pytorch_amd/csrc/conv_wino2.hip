@@ -25,7 +25,7 @@
 //     tiles on the MFMA (wino_gemm_tn_kernel), and a last small kernel that folds the 16 bins into the 2x2 taps of each phase.
 //
 // F(3,2):  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 -1 0 1],  G = [1 0; .5 .5; .5 -.5; 0 1],  A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1]
-// (verified against the direct correlation in tests/test_winoconv_model_cpu.py).
+// (verified against the direct correlation in tests/test_wino2conv_model_cpu.py).
 #include "common.h"
 #include "wino_gemm.h"
 
@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256) void w2_lift_kernel(const float* __restrict__ 
 
 // ---- weight gradient output: dw[(2u+a)*4 + (2v+b)][..] = (G^T P_ab G)[u][v],  P[bin][n][(a*2+b)*Cx + c].
 // transposed = 0: dw[tap][n][c] (conv);  1: dw[tap][c][n] (ConvTranspose: [tap][Cout_T = large-image channel][Cin_T]) ----
-__global__ __launch_bounds__(256) void w2_wgrad_output_kernel(const float* __restrict__ P, float* __restrict__ dw, int Ny, int Cx, int transposed) {
+__global__ __launch_bounds__(256) void w2_wgrad_output_kernel(const float* __restrict__ P, float* __restrict__ dw, int Ny, int Cx, int transposed,
+                                                              int nsplit) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Ny * Cx) return;
     const int c = i % Cx, n = i / Cx;
@@ -347,7 +348,11 @@ __global__ __launch_bounds__(256) void w2_wgrad_output_kernel(const float* __res
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { p[q][e] = *src; src += bs; GDN_KEEP(src); }
+                for (int e = 0; e < 4; ++e) {
+                    float v = *src;
+                    for (int sp = 1; sp < nsplit; ++sp) v += src[(size_t)sp * WINO_BINS * bs];      // split reduction, fixed order
+                    p[q][e] = v; src += bs; GDN_KEEP(src);
+                }
             float r[2][4];                  // G^T along rows: (p0 + (p1 + p2)/2, (p1 - p2)/2 + p3)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { r[0][e] = p[0][e] + 0.5f * (p[1][e] + p[2][e]); r[1][e] = 0.5f * (p[1][e] - p[2][e]) + p[3][e]; }
@@ -387,6 +392,8 @@ inline size_t ua_bytes(const W2Geom& f) { return al256((size_t)WINO_BINS * f.Cy 
 inline size_t ma_bytes(const W2Geom& f) { return al256((size_t)WINO_BINS * f.Ma * f.Cy * 4); }          // Mo / Dv, form A
 inline size_t vb_bytes(const W2Geom& f) { return al256((size_t)WINO_BINS * f.Mb * f.Cy * 4); }          // Vd, form B
 inline size_t eb_bytes(const W2Geom& f) { return al256((size_t)WINO_BINS * f.Mb * 4 * f.Cx * 4); }      // Eo, form B
+inline int w2_splits(const W2Geom& f) { return wino_tn_splits(f.Ma, f.Cy, 4 * f.Cx); }
+inline size_t p_bytes(const W2Geom& f) { return (size_t)w2_splits(f) * ua_bytes(f); }                   // P, one set per split
 inline size_t pad_bytes(const W2Geom& f) { return f.reflect ? al256((size_t)f.B * (f.Hx + 2) * (f.Wx + 2) * f.Cx * 4) : 0; }
 
 void run_form_a(const W2Geom& f, const float* x, int ldx, const float* w, int swap, float* V, float* U, float* Mo, float* y, int ldy,
@@ -458,9 +465,9 @@ extern "C" int gdn_wino2conv_fwd(const gdn_conv_geom* g, const float* x, int32_t
 extern "C" size_t gdn_wino2conv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     W2Geom f;
     if (!w2_geom(g, f)) return 0;
-    if (g->transposed) return va_bytes(f) + ua_bytes(f) + ma_bytes(f);          // form A on dz; Dv reuses the Mo region
+    if (g->transposed) return va_bytes(f) + p_bytes(f) + ma_bytes(f);           // form A on dz; Dv reuses the Mo region
     const size_t a = vb_bytes(f) > ma_bytes(f) ? vb_bytes(f) : ma_bytes(f);     // Vd (data gradient) / Dv (weight gradient)
-    return a + ua_bytes(f) + eb_bytes(f) + pad_bytes(f);
+    return a + p_bytes(f) + eb_bytes(f) + pad_bytes(f);
 }
 
 // Conv2d (transposed = 0):       dy [B,H/2,W/2,Cout]; dx [B,H,W,Cin] = dgrad (+ addsrc) when dx != NULL (needs w);
@@ -482,7 +489,7 @@ extern "C" int gdn_wino2conv_bwd(const gdn_conv_geom* g, const float* dy, int32_
         // dz = dy is the LARGE image: one form-A transform of it feeds the data gradient (a strided conv of dz with the
         // role-swapped weights) and the weight gradient (reduction against the lifted 3x3 tiles of the forward input x)
         float* V = (float*)p; p += va_bytes(f);
-        float* U = (float*)p; p += ua_bytes(f);
+        float* U = (float*)p; p += p_bytes(f);
         float* Mo = (float*)p;
         hipLaunchKernelGGL(w2_input_a_kernel, dim3(cdiv(f.Ma, 4) << f.xq), dim3(256), 0, st, dy, ldy, V, f);
         if (dx) {
@@ -495,24 +502,24 @@ extern "C" int gdn_wino2conv_bwd(const gdn_conv_geom* g, const float* dy, int32_
             float* Dv = Mo;             // (stream-ordered after the output transform above)
             float* P = U;
             hipLaunchKernelGGL(w2_lift_kernel, dim3(cdiv(f.Ma, 4) << f.yq), dim3(256), 0, st, x, ldx_in, Dv, f);
-            hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3((f.Cy / 64) * (4 * f.Cx / 64) * WINO_BINS), dim3(256), 0, st, (const float*)Dv,
-                               (const float*)V, P, f.Ma, f.Cy, 4 * f.Cx);
-            hipLaunchKernelGGL(w2_wgrad_output_kernel, dim3(cdiv(f.Cy * f.Cx, 256)), dim3(256), 0, st, (const float*)P, dw, f.Cy, f.Cx, 1);
+            const int ns = w2_splits(f);
+            launch_wino_gemm_tn((const float*)Dv, (const float*)V, P, f.Ma, f.Cy, 4 * f.Cx, ns, st);
+            hipLaunchKernelGGL(w2_wgrad_output_kernel, dim3(cdiv(f.Cy * f.Cx, 256)), dim3(256), 0, st, (const float*)P, dw, f.Cy, f.Cx, 1, ns);
         }
         return gdn_launch_status();
     }
     const size_t a = vb_bytes(f) > ma_bytes(f) ? vb_bytes(f) : ma_bytes(f);
     float* Vd = (float*)p; p += a;
-    float* U = (float*)p; p += ua_bytes(f);
+    float* U = (float*)p; p += p_bytes(f);
     float* Eo = (float*)p; p += eb_bytes(f);
     float* dxp = (float*)p;
     if (dw) {
         float* Dv = Vd;
         float* P = U;
         hipLaunchKernelGGL(w2_lift_kernel, dim3(cdiv(f.Ma, 4) << f.yq), dim3(256), 0, st, dy, ldy, Dv, f);
-        hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3((f.Cy / 64) * (4 * f.Cx / 64) * WINO_BINS), dim3(256), 0, st, (const float*)Dv,
-                           (const float*)state, P, f.Ma, f.Cy, 4 * f.Cx);
-        hipLaunchKernelGGL(w2_wgrad_output_kernel, dim3(cdiv(f.Cy * f.Cx, 256)), dim3(256), 0, st, (const float*)P, dw, f.Cy, f.Cx, 0);
+        const int ns = w2_splits(f);
+        launch_wino_gemm_tn((const float*)Dv, (const float*)state, P, f.Ma, f.Cy, 4 * f.Cx, ns, st);
+        hipLaunchKernelGGL(w2_wgrad_output_kernel, dim3(cdiv(f.Cy * f.Cx, 256)), dim3(256), 0, st, (const float*)P, dw, f.Cy, f.Cx, 0, ns);
     }
     if (dx) {
         if (f.reflect) {

@@ -103,14 +103,20 @@ __global__ __launch_bounds__(256, BM == 64 ? 4 : 3) void wino_gemm_kernel(const 
 
 // Reduction-over-tiles GEMM of the weight gradient:  P[bin][n][c] = sum_t Dv[bin][t][n] * V[bin][t][c]  (rows = tiles, both
 // operands read as they lie).  64x64 output tile, 32 tiles of the reduction per step, conflict-free ds_read_b32 row reads.
+// nsplit > 1: the reduction over the M tiles is cut into nsplit chunks, one workgroup each, writing partial products
+// P[split][bin][NI][NJ] that the tap kernels sum in fixed order (layers with few channels have too few (bin, tile)
+// workgroups to fill the chip otherwise: 128 for a 64 -> 128 stride-2 layer).
 __global__ __launch_bounds__(256, 4) void wino_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                            float* __restrict__ P, int M, int NI, int NJ) {
+                                                            float* __restrict__ P, int M, int NI, int NJ, int nsplit) {
     constexpr int LD = 64;
     __shared__ __attribute__((aligned(16))) float As[32 * LD], Bs[32 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wi = wave >> 1, wj = wave & 1;
     const int TI = NI / 64, TJ = NJ / 64;
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int bin = (sq / (TI * TJ)) * 8 + xcd, i0 = ((sq / TJ) % TI) * 64, j0 = (sq % TJ) * 64;
+    const int bin = (sq / (TI * TJ * nsplit)) * 8 + xcd, split = (sq / (TI * TJ)) % nsplit;
+    const int i0 = ((sq / TJ) % TI) * 64, j0 = (sq % TJ) * 64;
+    const int mchunk = ((M + nsplit - 1) / nsplit + 31) / 32 * 32;
+    const int mb = split * mchunk, me = mb + mchunk < M ? mb + mchunk : M;         // this workgroup reduces tiles [mb, me)
     const float* Ab = A + (size_t)bin * M * NI + i0;
     const float* Bb = Bm + (size_t)bin * M * NJ + j0;
     f32x16 acc;
@@ -122,8 +128,8 @@ __global__ __launch_bounds__(256, 4) void wino_gemm_tn_kernel(const float* __res
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
             const int m = m0 + ps * 16 + lr;
-            ra[ps] = m < M ? *reinterpret_cast<const f32x4*>(Ab + (size_t)m * NI + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rb[ps] = m < M ? *reinterpret_cast<const f32x4*>(Bb + (size_t)m * NJ + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[ps] = m < me ? *reinterpret_cast<const f32x4*>(Ab + (size_t)m * NI + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[ps] = m < me ? *reinterpret_cast<const f32x4*>(Bb + (size_t)m * NJ + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto lstore = [&]() {
@@ -135,24 +141,36 @@ __global__ __launch_bounds__(256, 4) void wino_gemm_tn_kernel(const float* __res
     };
     const int a_off = (lane >> 5) * LD + wi * 32 + (lane & 31);
     const int b_off = (lane >> 5) * LD + wj * 32 + (lane & 31);
-    gload(0);
+    gload(mb);
     lstore();
     __syncthreads();
-    for (int m0 = 0; m0 < M; m0 += 32) {
-        if (m0 + 32 < M) gload(m0 + 32);
+    for (int m0 = mb; m0 < me; m0 += 32) {
+        if (m0 + 32 < me) gload(m0 + 32);
 #pragma unroll
         for (int kk = 0; kk < 32; kk += 2)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[a_off + kk * LD], Bs[b_off + kk * LD], acc, 0, 0, 0);
         __syncthreads();
-        if (m0 + 32 < M) { lstore(); __syncthreads(); }
+        if (m0 + 32 < me) { lstore(); __syncthreads(); }
     }
-    float* Pb = P + (size_t)bin * NI * NJ;
+    float* Pb = P + ((size_t)split * WINO_BINS + bin) * NI * NJ;
     const int col = j0 + wj * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         Pb[(size_t)i * NJ + col] = acc[r];
     }
+}
+
+// splits of the weight-gradient reduction: at least ~1024 workgroups, chunks of at least 256 tiles, at most 8
+inline int wino_tn_splits(int M, int NI, int NJ) {
+    const int wgs = (NI / 64) * (NJ / 64) * WINO_BINS;
+    int s = (1024 + wgs - 1) / wgs;
+    if (s > 8) s = 8;
+    while (s > 1 && M / s < 256) --s;
+    return s < 1 ? 1 : s;
+}
+inline void launch_wino_gemm_tn(const float* A, const float* Bm, float* P, int M, int NI, int NJ, int nsplit, hipStream_t st) {
+    hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3((NI / 64) * (NJ / 64) * WINO_BINS * nsplit), dim3(256), 0, st, A, Bm, P, M, NI, NJ, nsplit);
 }
 
 // 64-row tiles: the 128-row instantiation (two MFMA tiles per wave sharing the B fragment, 3 workgroups per CU) measured

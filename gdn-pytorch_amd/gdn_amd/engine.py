@@ -23,6 +23,9 @@ _WINOGRAD = os.environ.get("GDN_WINOGRAD", "1") != "0"
 # train-mode BatchNorm fusion (A/B switch): scale/shift/ReLU of a ResidualBlock's first half applied in the consumer's
 # loader, BatchNorm-backward reductions emitted by the data-gradient epilogues
 _FUSE_TRAIN_BN = os.environ.get("GDN_FUSE_TRAIN_BN", "1") != "0"
+# per-site A/B switches of that fusion (measurement; all on by default unless a site measured slower)
+_FUSE = {k: os.environ.get("GDN_FUSE_" + k.upper(), d) != "0" for k, d in
+         (("fft_in", "1"), ("fft_dyb", "1"), ("wino_in", "1"), ("wino_bnb", "1"))}
 # fp32 4x4 stride-2 pad-1 Conv2d / ConvTranspose2d layers run as Winograd F(3x3,2x2) over the polyphase images
 # (csrc/conv_wino2.hip) when both channel counts reach this value (0 disables): the transforms move ~1.8x the
 # layer's activations (measured: a gain on every such layer of G, the smallest at 64 channels, tests/diag/wino2_time.py)
@@ -387,7 +390,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     # the transform-domain paths share one call shape: forward (+ saved state), backward from that state
     alt_fwd = op.fft_fwd if use_fft else op.wino_fwd if use_wino else op.wino2_fwd if use_wino2 else None
     alt_bwd = op.fft_bwd if use_fft else op.wino_bwd if use_wino else op.wino2_bwd if use_wino2 else None
-    bnb_slots = op.fft_bnb_slots if use_fft else op.wino_bnb_slots if use_wino else (lambda *a: 0)
+    bnb_slots = op.wino_bnb_slots if use_wino else (lambda *a: 0)      # (fft / wino2 epilogues do not emit them)
     state_kw = "spectrum" if use_fft else "state"
     bstate_kw = "xf" if use_fft else "state"
     use_fft_only = use_fft
@@ -395,7 +398,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     in_kw = {}
     xt = x                               # the tensor the conv kernels read
     if lazy:
-        if use_fft and not use_wino2 and _FUSE_TRAIN_BN:
+        if use_fft and not use_wino2 and _FUSE_TRAIN_BN and _FUSE["fft_in" if use_fft_only else "wino_in"]:
             in_kw = dict(in_affine=(x.co[0], x.co[1]), in_relu=x.relu)
             xt = x.y
         else:
@@ -452,7 +455,8 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
             if residual is not None:
                 ctx.add_grad(residual, da)
             dyb = None
-            if bn_training and use_fft_only and _FUSE_TRAIN_BN and da.is_contiguous() and da.dtype == torch.float32:
+            if (bn_training and use_fft_only and _FUSE_TRAIN_BN and _FUSE["fft_dyb"] and da.is_contiguous()
+                    and da.dtype == torch.float32):
                 # frequency-domain layer: dy has one reader (the dy transform), which applies pass 3 of the BatchNorm
                 # backward while loading -- dy is never written
                 kk = ops.bn_bwd_coeffs(da, y, co, relu, bn.weight.grad if not frozen else None,
@@ -475,7 +479,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                         raise GdnError("weight.grad is not tap-major")
                 if gv is not None or want_dx:
                     bnb = None
-                    if xin is not None and want_dx and xin.y.dtype == torch.float32:
+                    if xin is not None and want_dx and xin.y.dtype == torch.float32 and _FUSE["wino_bnb"]:
                         # x = [relu](BN_train(xin.y)) and this data gradient is its final gradient: emit the producer's
                         # BatchNorm-backward partial sums from the epilogue that writes dx
                         slots = bnb_slots(x.shape[0], x.shape[1], x.shape[2])
@@ -483,8 +487,10 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                             part = torch.empty((slots, 2, conv.in_channels), dtype=torch.float32, device=dy.device)
                             bnb = (xin.y, xin.co, xin.relu, part)
                     extra = {"dyb": dyb} if dyb is not None else {}
+                    if bnb is not None:
+                        extra["bnb"] = bnb
                     dx = alt_bwd(dy, w, in_hw, dw_tap=gv, need_dx=want_dx, **{bstate_kw: xf},
-                                 addsrc=ctx.pop_grad_as(x, ldt) if want_dx else None, bnb=bnb, **extra)
+                                 addsrc=ctx.pop_grad_as(x, ldt) if want_dx else None, **extra)
                     if want_dx:
                         ctx.grads[id(x)] = (x, dx)
                         if bnb is not None:

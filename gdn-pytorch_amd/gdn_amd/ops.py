@@ -222,20 +222,14 @@ class Conv:
         res = (y,) + ((st,) if stats else ()) + ((xf,) if spectrum else ())
         return res if len(res) > 1 else y
 
-    def fft_bnb_slots(self, B, H, W):
-        _, ref, _, _ = self.geom(B, H, W)
-        return int(lib.gdn_fftconv_bnb_slots(ref))
-
     def wino_bnb_slots(self, B, H, W):
         _, ref, _, _ = self.geom(B, H, W)
         return int(lib.gdn_winoconv_bnb_slots(ref))
 
-    def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None, bnb=None, dyb=None):
+    def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None, dyb=None):
         """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's saved state xf:
         input + weight spectra) from one transform of dy.  w_tap is the FORWARD tap-major weight [k*k, Cout, Cin]; it is
         only read when xf is None.
-        bnb = (y_raw, coeffs[4,Cin], relu, partial_out): dx is the gradient of [relu](BN_train(y_raw)); the epilogue also
-        writes that BatchNorm's backward partials (see gdn_fftconv_bwd).
         dyb = (y_raw, coeffs[4,Cout], kk[2,Cout], relu): `dy` is dout of THIS layer's train-mode BatchNorm; the dy transform
         applies scale*(dz - k1 - xhat*k2) while loading (kk from bn_bwd_coeffs)."""
         _chk(dy, "dy")
@@ -249,14 +243,12 @@ class Conv:
             raise GdnError("fft_bwd: dy shape %s does not match layer output" % (tuple(dy.shape),))
         dx = torch.empty((B, H, W, self.cin), dtype=torch.float32, device=dy.device) if need_dx else None
         ws = workspace(nb, dy.device, "fft")
-        by, bco, brelu, bpart = bnb if (bnb is not None and need_dx) else (None, None, False, None)
         yy, yco, ykk, yrelu = dyb if dyb is not None else (None, None, None, False)
 
         def call(phases, st):
             lib.gdn_fftconv_bwd(ref, _p(dy), _ld(dy), _p(w_tap), _p(xf), _p(dx),
                                 0 if dx is None else _ld(dx), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
-                                _p(dw_tap), _p(by), 0 if by is None else _ld(by), _p(bco), 1 if brelu else 0, _p(bpart),
-                                _p(yy), 0 if yy is None else _ld(yy), _p(yco), _p(ykk), 1 if yrelu else 0,
+                                _p(dw_tap), _p(yy), 0 if yy is None else _ld(yy), _p(yco), _p(ykk), 1 if yrelu else 0,
                                 phases, _p(ws), nb, st)
         if dw_tap is not None and need_dx and _FFT_OVERLAP:
             # the two chains only share the spectrum of dy and are each latency-bound: the weight-gradient chain runs on a
@@ -459,7 +451,7 @@ def bn_apply(y, scale, shift, relu, residual=None, out=None, out_dtype=None):
 
 def bn_bwd(dout, y, gamma, coeffs, relu, dgamma, dbeta, out_dtype=None, partial=None):
     """coeffs = [scale, shift, mean, invstd] from bn_finalize_train. Returns dy.
-    partial [slots,2,C]: the reduce pass was done by the epilogue that wrote dout (fft_bwd / wino_bwd `bnb`)."""
+    partial [slots,2,C]: the reduce pass was done by the epilogue that wrote dout (wino_bwd `bnb`)."""
     B, H, W, C = y.shape
     npix = B * H * W
     dy = torch.empty((B, H, W, C), dtype=out_dtype or y.dtype, device=y.device)

@@ -162,22 +162,15 @@ int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const f
  * caller may issue GDN_FFT_BWD_TRANSFORM on stream A, let stream B wait for it, issue GDN_FFT_BWD_DW
  * on B and GDN_FFT_BWD_DX on A (same arguments, same workspace) and join B into A: the two
  * latency-bound chains then overlap.  The library creates no stream or event itself.
- * bnb_* (nullable; replaces the reduce pass of gdn_bn_bwd, AE_model_unet.py:51,54,68): dx is the
- * gradient of z = [relu](BN_train(bnb_y)), bnb_y [B,H,W,Cin] with pitch ld_bnb being that BatchNorm's
- * input and bnb_co = {scale, shift, mean, invstd}[Cin]; the epilogue that writes dx (+ addsrc) also
- * writes bnb_partial[slot][2][Cin] = per-slot sum(dz), sum(dz*xhat), dz = dx*[z>0 if bnb_relu],
- * slots = gdn_fftconv_bnb_slots(g) (0: not available -- reflection-padded layers).
  * dyb_* (nullable; replaces pass 3 of gdn_bn_bwd for THIS layer's own BatchNorm): `dy` is dout, the
  * gradient of z = [relu](BN_train(dyb_y)) with dyb_y this layer's raw conv output, dyb_co = {scale, shift,
  * mean, invstd}[Cout] and dyb_kk = {k1, k2}[Cout] from gdn_bn_bwd_coeffs; the dy transform computes
  * dy = scale*(dz - k1 - xhat*k2) while loading, so dy itself is never written to memory. */
 enum { GDN_FFT_BWD_TRANSFORM = 1, GDN_FFT_BWD_DW = 2, GDN_FFT_BWD_DX = 4, GDN_FFT_BWD_ALL = 7 };
 size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g);
-int64_t gdn_fftconv_bnb_slots(const gdn_conv_geom* g);
 int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w,
                     const void* xf, float* dx, int32_t ldx, const float* addsrc, int32_t ld_add,
-                    float* dw, const float* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu,
-                    float* bnb_partial, const float* dyb_y, int32_t ld_dyb, const float* dyb_co,
+                    float* dw, const float* dyb_y, int32_t ld_dyb, const float* dyb_co,
                     const float* dyb_kk, int32_t dyb_relu, int32_t phases,
                     void* workspace, size_t workspace_bytes, void* stream);
 
@@ -199,7 +192,13 @@ int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const 
                      const float* in_scale, const float* in_shift, int32_t in_relu,
                      void* state_out, void* workspace, size_t workspace_bytes, void* stream);
 /* dx = dgrad (+ addsrc) when dx != NULL (needs w), dw[tap][Cout][Cin] = wgrad when dw != NULL
- * (needs state).  bnb_*: as for gdn_fftconv_bwd (slots: gdn_winoconv_bnb_slots). */
+ * (needs state).
+ * bnb_* (nullable; replaces the reduce pass of gdn_bn_bwd, AE_model_unet.py:51,54,68): dx is the gradient of
+ * z = [relu](BN_train(bnb_y)), bnb_y [B,H,W,Cin] with pitch ld_bnb being that BatchNorm's input and
+ * bnb_co = {scale, shift, mean, invstd}[Cin]; the output transform that writes dx (+ addsrc) also writes
+ * bnb_partial[slot][2][Cin] = per-slot sum(dz), sum(dz*xhat), dz = dx*[z>0 if bnb_relu], slots =
+ * gdn_winoconv_bnb_slots(g) (0: not available -- reflection-padded layers).  (The frequency-domain layers do
+ * not offer this: their inverse transforms are VALU-bound and the fused sums measured slower than the reduce pass.) */
 size_t gdn_winoconv_bwd_workspace_bytes(const gdn_conv_geom* g);
 int64_t gdn_winoconv_bnb_slots(const gdn_conv_geom* g);
 /* Measurement hook: only the 16 per-bin MFMA GEMMs of one forward, V [16][tiles][Cin] x U [16][Cout][Cin]

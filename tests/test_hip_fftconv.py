@@ -195,7 +195,7 @@ def test_fftconv_full_size_adjoint_and_direct(gpu, C, k, H, W):
 
 @pytest.mark.parametrize("path,k,C,B,H,W", [("fft", 9, 64, 2, 40, 70), ("fft", 5, 128, 1, 33, 47), ("wino", 3, 128, 2, 17, 30)])
 def test_input_affine_and_bn_backward_partials(gpu, path, k, C, B, H, W):
-    """The two train-mode BatchNorm fusions of the transform-domain layers:
+    """The train-mode BatchNorm fusions of the transform-domain layers:
     (1) in_affine: conv(relu(y1*scale + shift)) with the affine applied in the patch loader == conv of the materialised
         activation (zero padding stays zero);
     (2) bnb: the data-gradient epilogue's per-slot partials sum to sum(dz), sum(dz*xhat) of the BatchNorm backward, dz
@@ -220,7 +220,21 @@ def test_input_affine_and_bn_backward_partials(gpu, path, k, C, B, H, W):
     close(got2, fwd(ops.bn_apply(y1, scale, shift, False), w), rtol=1e-5, atol_scale=1e-6, what=path + " in_affine (no relu)")
     dy = torch.randn(B, H, W, C, generator=g).to(gpu)
     skip = torch.randn(B, H, W, C, generator=g).to(gpu)
-    slots = op.fft_bnb_slots(B, H, W) if path == "fft" else op.wino_bnb_slots(B, H, W)
+    if path == "fft":
+        # (3) dyb: pass 3 of THIS layer's BatchNorm backward applied by the dy transform == the materialised dy
+        dg, db, dgf, dbf = [torch.empty(C, device=gpu) for _ in range(4)]
+        dw0, dw1 = torch.empty_like(w), torch.empty_like(w)
+        y_raw, st, xf = op.fft_fwd(a, w, stats=True, spectrum=True)
+        for relu in (True, False):
+            dy_mat = ops.bn_bwd(dy, y_raw, scale, co, relu, dg, db)
+            ref_dx = op.fft_bwd(dy_mat, w, (H, W), xf=xf, dw_tap=dw0, addsrc=skip)
+            kk = ops.bn_bwd_coeffs(dy, y_raw, co, relu, dgf, dbf)
+            got_dx = op.fft_bwd(dy, w, (H, W), xf=xf, dw_tap=dw1, addsrc=skip, dyb=(y_raw, co, kk, relu))
+            close(got_dx, ref_dx, rtol=1e-4, atol_scale=1e-5, what="fft dyb dx relu=%s" % relu)
+            close(dw1, dw0, rtol=1e-4, atol_scale=1e-5, what="fft dyb dw relu=%s" % relu)
+            close(dgf, dg, rtol=1e-5, atol_scale=1e-6, what="dgamma"); close(dbf, db, rtol=1e-5, atol_scale=1e-6, what="dbeta")
+        return          # (the frequency-domain data gradient emits no BatchNorm partials: measured slower than the reduce pass)
+    slots = op.wino_bnb_slots(B, H, W)
     assert slots > 0
     for relu in (True, False):
         part = torch.full((slots, 2, C), float("nan"), device=gpu)

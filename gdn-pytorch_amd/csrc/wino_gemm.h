@@ -38,11 +38,16 @@ __global__ __launch_bounds__(256, BM == 64 ? 4 : 3) void wino_gemm_kernel(const 
     const float* Ab = A + (size_t)bin * M * K;
     const float* Bb = Bm + (size_t)bin * N * K;
     float* Cb = Cm + (size_t)bin * M * N;
-    f32x16 acc[RM];
+    // Two-level summation (as conv_igemm_f32): an MFMA accumulation is a strictly k-ordered fp32 fma chain, whose rounding
+    // grows with sqrt(K) -- K reaches 2048 on the stride-2 layers.  Chains of 128 terms (two k-steps) start from C = 0 and are
+    // folded into the running total.
+    f32x16 acc[RM], run[RM], zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 #pragma unroll
     for (int t = 0; t < RM; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; run[t][r] = 0.f; }
     const int lr = tid >> 3, lc = (tid & 7) * 4;          // 32 rows per pass, 8 lanes x 16 B = one 32-float chunk per row
     f32x4 ra[2 * RM][NV], rb[2][NV];
     auto gload = [&](int k0) {
@@ -76,6 +81,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 4 : 3) void wino_gemm_kernel(const 
     __syncthreads();
     for (int k0 = 0; k0 < K; k0 += KC) {
         if (k0 + KC < K) gload(k0 + KC);
+        const bool fresh = (k0 % 128) == 0;                   // first k-step of a 128-term chain
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -85,7 +91,19 @@ __global__ __launch_bounds__(256, BM == 64 ? 4 : 3) void wino_gemm_kernel(const 
                 for (int t = 0; t < RM; ++t) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(&As[a_off + t * 32 * LD + v * 32 + g4 * 4]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[t], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) {
+                        if (v == 0 && g4 == 0 && e == 0) {
+                            if (fresh) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) run[t][r] += acc[t][r];
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], zero16, 0, 0, 0);
+                            } else {
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[t], 0, 0, 0);
+                            }
+                        } else {
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[t], 0, 0, 0);
+                        }
+                    }
                 }
             }
         __syncthreads();
@@ -97,7 +115,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 4 : 3) void wino_gemm_kernel(const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 * RM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < M) Cb[(size_t)m * N + col] = acc[t][r];
+            if (m < M) Cb[(size_t)m * N + col] = run[t][r] + acc[t][r];
         }
 }
 

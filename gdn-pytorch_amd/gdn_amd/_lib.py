@@ -62,6 +62,10 @@ _SIGS = {
     "gdn_wino2conv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _P, _P, _sz, _P]),
     "gdn_wino2conv_bwd_workspace_bytes": (_sz, [_PG]),
     "gdn_wino2conv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _sz, _P]),
+    "gdn_conv_c1_stats_slots": (_i64, [_i32, _i32, _i32]),
+    "gdn_conv_c1_fwd": (c_int32, [_P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _P]),
+    "gdn_conv_c1_wgrad_workspace_bytes": (_sz, []),
+    "gdn_conv_c1_wgrad": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P, _P, _sz, _P]),
     "gdn_transpose_taps": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P]),
     "gdn_cast": (c_int32, [_P, _P, _i64, _i32, _P]),
     "gdn_weight_to_tapmajor": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P]),

@@ -30,6 +30,8 @@ _FUSE = {k: os.environ.get("GDN_FUSE_" + k.upper(), d) != "0" for k, d in
 # (csrc/conv_wino2.hip) when both channel counts reach this value (0 disables): the transforms move ~1.8x the
 # layer's activations (measured: a gain on every such layer of G, the smallest at 64 channels, tests/diag/wino2_time.py)
 _WINO2_MIN_C = int(os.environ.get("GDN_WINO2_MIN_C", "64"))
+# fp32 1 <-> 64 channel 9x9 layers (G's first convolution, the heads' backward) on csrc/conv_c1.hip (A/B switch)
+_C1 = os.environ.get("GDN_C1", "1") != "0"
 _GRAPH_EPOCH = 0
 
 
@@ -405,11 +407,16 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
             xt = x.dense(ctx.dtype)      # (the direct kernels' loaders go straight to LDS: materialise)
     xf = None
     keep_xf = use_fft and ctx.record and conv.weight.requires_grad
+    use_c1 = (_C1 and not use_fft and ldt == torch.float32 and x2 is None and not lazy and conv.in_channels == 1
+              and not isinstance(conv, torch.nn.ConvTranspose2d)
+              and ops.c1_ok(x, conv.out_channels, conv.kernel_size[0], conv.stride[0], reflect or conv.padding[0]))
     if bn.training:
         if use_fft:
             r = alt_fwd(xt, w, stats=True, **{state_kw: keep_xf}, **in_kw)
             y, st = r[0], r[1]
             xf = r[2] if keep_xf else None
+        elif use_c1:
+            y, st = ops.conv_c1_fwd(xt, w, reflect=bool(reflect), stats=True)
         else:
             y, st = op.fwd(xt, w, x2=x2, stats=True)
         count = y.shape[0] * y.shape[1] * y.shape[2]
@@ -426,11 +433,15 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
         # eval-mode BN folded into the conv epilogue: conv + scale/shift + ReLU (+ residual) in one pass
         if use_fft:
             y = a = alt_fwd(xt, w, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual, **in_kw)
+        elif use_c1:
+            y = a = ops.conv_c1_fwd(xt, w, reflect=bool(reflect), affine=(co[0], co[1]),
+                                    act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
         else:
             y = a = op.fwd(xt, w, x2=x2, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
     else:
         if not bn.training:
-            y = alt_fwd(xt, w, **in_kw) if use_fft else op.fwd(xt, w, x2=x2)
+            y = (alt_fwd(xt, w, **in_kw) if use_fft else ops.conv_c1_fwd(xt, w, reflect=bool(reflect)) if use_c1
+                 else op.fwd(xt, w, x2=x2))
         else:
             out_info = BnOut(y, co, relu)
         if (defer and out_info is not None and residual is None and _FUSE_TRAIN_BN and ldt == torch.float32
@@ -499,7 +510,10 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                     ctx.grads_done(bn.weight, bn.bias, conv.weight)
                 return
             if not frozen:
-                _wgrad_into(ctx, conv, xt, dy, x2)
+                if use_c1 and dy.is_contiguous():
+                    ops.conv_c1_wgrad(xt, dy, tap_view(conv.weight.grad, False), reflect=bool(reflect))
+                else:
+                    _wgrad_into(ctx, conv, xt, dy, x2)
                 ctx.grads_done(bn.weight, bn.bias, conv.weight)
             if want_dx:
                 wt = ops.transpose_taps(_w_tap(conv)[0], dtype=ldt)
@@ -530,11 +544,21 @@ def conv_head_tanh(ctx, x, conv):
             if do is None:
                 return
             dpre = ops.tanh_bwd(do.contiguous(), out)
+            # 64 -> 1 heads: both gradients are 1 <-> 64 channel correlations with the single-channel d(pre-tanh) as the
+            # staged image (csrc/conv_c1.hip); a Conv2d head flips the taps, a ConvTranspose2d head does not
+            c1 = (_C1 and x.dtype == torch.float32 and x.is_contiguous() and conv.out_channels == 1
+                  and ops.c1_ok(dpre, conv.in_channels, conv.kernel_size[0], conv.stride[0], conv.padding[0]))
             if conv.weight.requires_grad:
-                _wgrad_into(ctx, conv, x, dpre)
+                if c1:
+                    ops.conv_c1_wgrad(dpre, x, tap_view(conv.weight.grad, tr), flip=not tr)
+                else:
+                    _wgrad_into(ctx, conv, x, dpre)
                 ctx.grads_done(conv.weight)
-            wt = ops.transpose_taps(w)
-            dx = op.dgrad(dpre, wt, in_hw, addsrc=ctx.pop_grad_as(x, torch.float32))
+            if c1:
+                dx = ops.conv_c1_fwd(dpre, w, flip=not tr, addsrc=ctx.pop_grad_as(x, torch.float32))
+            else:
+                wt = ops.transpose_taps(w)
+                dx = op.dgrad(dpre, wt, in_hw, addsrc=ctx.pop_grad_as(x, torch.float32))
             ctx.grads[id(x)] = (x, dx)
         ctx.tape.append(bwd)
     return out

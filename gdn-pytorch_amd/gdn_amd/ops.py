@@ -389,6 +389,38 @@ class Conv:
                            _mask(x, dy), stream())
 
 
+def c1_ok(x1, n, k, stride, pad):
+    """The 1 <-> 64 channel 9x9 layers of csrc/conv_c1.hip: a dense fp32 single-channel image against 64 channels."""
+    return (x1.dtype == torch.float32 and x1.dim() == 4 and x1.shape[3] == 1 and x1.is_contiguous() and n == 64 and k == 9
+            and stride == 1 and pad == 4)
+
+
+def conv_c1_fwd(x1, w81, reflect=False, flip=False, stats=False, addsrc=None, affine=None, act=ACT_NONE):
+    """y[B,H,W,64] = sum_tap x1[p + tap - 4] * w81[tap][:]; x1 [B,H,W,1], w81 any tensor of 81*64 floats in [tap][64] order."""
+    _chk(x1, "x1"); _chk(w81, "w")
+    B, H, W, _ = x1.shape
+    if w81.numel() != 81 * 64 or not w81.is_contiguous():
+        raise GdnError("conv_c1_fwd: weights must be 81 x 64 contiguous floats")
+    y = torch.empty((B, H, W, 64), dtype=torch.float32, device=x1.device)
+    st = torch.empty((int(lib.gdn_conv_c1_stats_slots(B, H, W)), 2, 64), dtype=torch.float32, device=x1.device) if stats else None
+    lib.gdn_conv_c1_fwd(_p(x1), B, H, W, 64, 9, 4, 1 if reflect else 0, 1 if flip else 0, _p(w81), _p(y), 64, _p(addsrc),
+                        0 if addsrc is None else _ld(addsrc), _p(st), _p(affine[0]) if affine else None,
+                        _p(affine[1]) if affine else None, int(act), stream())
+    return (y, st) if stats else y
+
+
+def conv_c1_wgrad(x1, gw, dw81, reflect=False, flip=False):
+    """dw81[tap][:] = sum_p gw[p][:] * x1[p + tap - 4] (written at the flipped tap when flip); gw [B,H,W,64]."""
+    _chk(x1, "x1"); _chk(gw, "gw"); _chk(dw81, "dw")
+    B, H, W, _ = x1.shape
+    if dw81.numel() != 81 * 64 or not dw81.is_contiguous() or tuple(gw.shape) != (B, H, W, 64):
+        raise GdnError("conv_c1_wgrad: bad shapes")
+    nb = int(lib.gdn_conv_c1_wgrad_workspace_bytes())
+    ws = workspace(nb, x1.device, "wgrad")
+    lib.gdn_conv_c1_wgrad(_p(x1), _p(gw), _ld(gw), B, H, W, 64, 9, 4, 1 if reflect else 0, 1 if flip else 0, _p(dw81), _p(ws), nb,
+                          stream())
+
+
 def transpose_taps(w_tap, out=None, dtype=None):
     """[T, R, C] -> [T, C, R]; dtype (or out.dtype) may differ from w_tap's: fp32 master -> bf16 copy."""
     T, R, C = w_tap.shape

@@ -232,6 +232,23 @@ int gdn_wino2conv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, cons
                       float* dx, int32_t ldx, const float* addsrc, int32_t ld_add, float* dw,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* The 1 <-> 64 channel 9x9 stride-1 pad-4 layers on the matrix cores (G's first convolution AE_model_unet.py:496, the
+ * data and weight gradients of the 64 -> 1 heads :362 / :521), fp32.  x1 is a dense single-channel image [B,H,W].
+ *   gdn_conv_c1_fwd:   y[p][n] = sum_tap x1[p + tap - 4] * w[tap][n]   (N = 64; taps flipped when flip != 0; zero or reflection
+ *                      padding of x1); y / addsrc / stats / ep_scale / ep_shift / act as for gdn_conv_fwd (no tanh), slots =
+ *                      gdn_conv_c1_stats_slots.  The first convolution forward, and -- with x1 = d(pre-tanh) -- a head's data gradient.
+ *   gdn_conv_c1_wgrad: dw[tap][n] = sum_p gw[p][n] * x1[p + tap - 4]   (gw [B,H,W,64], pitch ldg; result written at the flipped
+ *                      tap when flip != 0).  The first convolution's weight gradient (x1 = input, gw = dy) and a head's
+ *                      (x1 = d(pre-tanh), gw = the head's input; flip for a Conv2d head, none for a ConvTranspose2d one). */
+int64_t gdn_conv_c1_stats_slots(int32_t B, int32_t H, int32_t W);
+int gdn_conv_c1_fwd(const float* x1, int32_t B, int32_t H, int32_t W, int32_t N, int32_t k, int32_t pad, int32_t reflect,
+                    int32_t flip, const float* w, float* y, int32_t ldy, const float* addsrc, int32_t ld_add,
+                    float* stats, const float* ep_scale, const float* ep_shift, int32_t act, void* stream);
+size_t gdn_conv_c1_wgrad_workspace_bytes(void);
+int gdn_conv_c1_wgrad(const float* x1, const float* gw, int32_t ldg, int32_t B, int32_t H, int32_t W, int32_t N, int32_t k,
+                      int32_t pad, int32_t reflect, int32_t flip, float* dw,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* bf16 weight gradient (BASELINE configs[2]): x and dy hold bfloat16, dw is fp32 (the master
  * gradient arena).  Same contract as gdn_conv_wgrad otherwise.  Needs Cx and Cout multiples of
  * 64, pixel pitches multiples of 8 and 16-byte aligned bases.  cfg: 0 automatic, 1/2 force the

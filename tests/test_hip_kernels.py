@@ -381,3 +381,38 @@ def test_conv_affine_relu_residual_epilogue(gpu, dtype, shape):
     close(nchw(y3.float()), torch.relu(conv) + res, what="conv+relu+residual", **tol)
     y4 = op.fwd(xd, wd, affine=affine, act=ops.ACT_RELU, tile_cfg=0x800)        # split-K off
     close(nchw(y4.float()), torch.relu(aff), what="conv+affine+relu single stage", **tol)
+
+
+@pytest.mark.parametrize("B,H,W,reflect,flip", [(2, 16, 64, True, False), (1, 13, 45, False, True), (3, 8, 32, False, False),
+                                                (1, 128, 416, True, False), (2, 5, 7, True, True)])
+def test_conv_c1_layers(gpu, B, H, W, reflect, flip):
+    """The 1 <-> 64 channel 9x9 kernels of csrc/conv_c1.hip against torch's CPU conv2d autograd: the first convolution of G
+    (Conv2d(1, 64, 9) after ReflectionPad2d(4), AE_model_unet.py:496), a head's data gradient (the same correlation, taps
+    flipped for a Conv2d head) and both weight gradients; ragged tiles, images smaller than a tile, BN partials, epilogue."""
+    from gdn_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + H * W)
+    x1 = torch.randn(B, 1, H, W, generator=g)
+    w = torch.randn(64, 1, 9, 9, generator=g) / 9.0
+    gy = torch.randn(B, 64, H, W, generator=g)
+    res = torch.randn(B, 64, H, W, generator=g)
+    xr, wr = x1.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    xp = F.pad(xr, (4, 4, 4, 4), mode="reflect") if reflect else F.pad(xr, (4, 4, 4, 4))
+    wf = torch.flip(wr, (2, 3)) if flip else wr
+    y_ref = F.conv2d(xp, wf)
+    y_ref.backward(gy)
+    x1d = x1.permute(0, 2, 3, 1).contiguous().to(gpu)                 # [B,H,W,1]
+    w81 = w.permute(2, 3, 0, 1).reshape(81, 64).contiguous().to(gpu)  # [tap][64]
+    assert ops.c1_ok(x1d, 64, 9, 1, 4)
+    y, st = ops.conv_c1_fwd(x1d, w81, reflect=reflect, flip=flip, stats=True)
+    close(nchw(y), y_ref, what="c1 fwd")
+    close(st[:, 0].sum(0), y_ref.detach().sum((0, 2, 3)), rtol=1e-3, atol_scale=1e-3, what="c1 stats sum")
+    close(st[:, 1].sum(0), (y_ref.detach() ** 2).sum((0, 2, 3)), what="c1 stats sumsq")
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    y2 = ops.conv_c1_fwd(x1d, w81, reflect=reflect, flip=flip, addsrc=nhwc(res).to(gpu), affine=(sc.to(gpu), sh.to(gpu)),
+                         act=ops.ACT_RELU)
+    close(nchw(y2), torch.relu(y_ref.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + res, what="c1 epilogue")
+    dw = torch.full((81, 64), 7.0, device=gpu)
+    ops.conv_c1_wgrad(x1d, nhwc(gy).to(gpu), dw, reflect=reflect, flip=flip)
+    close(dw, wr.grad.permute(2, 3, 0, 1).reshape(81, 64), what="c1 wgrad")
+    if not reflect and (H, W) == (8, 32):
+        close(y, ops.Conv(1, 64, 9, 1, 4).fwd(x1d, w81.view(81, 64, 1)), what="c1 fwd vs direct")

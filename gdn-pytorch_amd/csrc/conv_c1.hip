@@ -36,86 +36,93 @@ __device__ __forceinline__ float c1_fetch(const float* __restrict__ img, int H, 
     return (y >= 0 && y < H && x >= 0 && x < W) ? img[(size_t)y * W + x] : 0.f;
 }
 
-// y[p][n] = sum_tap x1[p + tap - pad] * w[tap][n]  (+ epilogue).  One workgroup = 8 x 32 output pixels x 64 channels;
-// wave w owns rows 2w, 2w+1 of the tile: 2 pixel tiles x 2 channel tiles of 32 x 32.
+// y[p][n] = sum_tap x1[p + tap - pad] * w[tap][n]  (+ epilogue).  A workgroup stages the 81 x 64 weights once ([ky][kx pad 10][64],
+// 23 KB) and walks 8 x 32 pixel tiles (persistent grid); wave w owns rows 2w, 2w+1 of a tile: 2 pixel tiles x 2 channel
+// tiles of 32 x 32.  stats slot = tile.
 __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ w, float* __restrict__ y,
                                                           int ldy, const float* __restrict__ addsrc, int ld_add,
                                                           float* __restrict__ stats, const float* __restrict__ ep_scale,
-                                                          const float* __restrict__ ep_shift, int act, C1Geom g) {
+                                                          const float* __restrict__ ep_shift, int act, C1Geom g, int tiles_x,
+                                                          int tiles_y) {
     __shared__ float patch[C1_PH * C1_PW];
     __shared__ float wl[C1_K * C1_KP * C1_N];
     __shared__ float red[4 * 2 * C1_N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
-    const int x0 = blockIdx.x * C1_TW, y0 = blockIdx.y * C1_TH, b = blockIdx.z;
-    const float* img = x1 + (size_t)b * g.H * g.W;
-    for (int i = tid; i < C1_PH * C1_PW; i += 256) {            // (column 40 only meets the zero-weight pad tap: keep it finite)
-        const int py = i / C1_PW, px = i % C1_PW;
-        patch[i] = px < C1_TW + C1_K - 1 ? c1_fetch(img, g.H, g.W, y0 + py - g.pad, x0 + px - g.pad, g.reflect, g.pad) : 0.f;
+    for (int i = tid; i < C1_K * C1_K * C1_N; i += 256) {           // source order: coalesced, no pad column
+        const int n = i & (C1_N - 1), tap = i >> 6, ky = tap / C1_K, kx = tap - ky * C1_K;
+        const int src = g.flip ? (C1_K * C1_K - 1 - tap) : tap;
+        wl[(ky * C1_KP + kx) * C1_N + n] = w[(size_t)src * C1_N + n];
     }
-    for (int i = tid; i < C1_K * C1_KP * C1_N; i += 256) {
-        const int n = i % C1_N, t = i / C1_N, kx = t % C1_KP, ky = t / C1_KP;
-        const int tap = g.flip ? (C1_K - 1 - ky) * C1_K + (C1_K - 1 - kx) : ky * C1_K + kx;
-        wl[i] = kx < C1_K ? w[(size_t)tap * C1_N + n] : 0.f;
-    }
-    __syncthreads();
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    for (int i = tid; i < C1_K * C1_N; i += 256) wl[((i >> 6) * C1_KP + C1_K) * C1_N + (i & (C1_N - 1))] = 0.f;   // pad tap kx = 9
     const float* pa = patch + (2 * wave) * C1_PW + l32 + h;        // + (mt + ky) * PW + 2j
     const float* pb = wl + h * C1_N + l32;                         // + (ky * KP + 2j) * N + nt * 32
-#pragma unroll
-    for (int ky = 0; ky < C1_K; ++ky)
-#pragma unroll
-        for (int j = 0; j < C1_KP / 2; ++j) {
-            const float a0 = pa[ky * C1_PW + 2 * j], a1 = pa[(ky + 1) * C1_PW + 2 * j];
-            const float b0 = pb[(ky * C1_KP + 2 * j) * C1_N], b1 = pb[(ky * C1_KP + 2 * j) * C1_N + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    const int ntiles = g.B * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int x0 = tx * C1_TW, y0 = ty * C1_TH;
+        const float* img = x1 + (size_t)b * g.H * g.W;
+        __syncthreads();                                           // previous tile's patch / red fully consumed
+        for (int i = tid; i < C1_PH * C1_PW; i += 256) {            // (column 40 only meets the zero-weight pad tap: keep it finite)
+            const int py = i / C1_PW, px = i - py * C1_PW;
+            patch[i] = px < C1_TW + C1_K - 1 ? c1_fetch(img, g.H, g.W, y0 + py - g.pad, x0 + px - g.pad, g.reflect, g.pad) : 0.f;
         }
-    // epilogue: acc[mt][nt][r] = pixel (row y0 + 2*wave + mt, column x0 + (r&3) + 8*(r>>2) + 4*h), channel nt*32 + l32
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+        __syncthreads();
+        f32x16 acc[2][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int oy = y0 + 2 * wave + mt;
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = nt * 32 + l32;
-            const float es = ep_scale ? ep_scale[n] : 1.f, et = ep_shift ? ep_shift[n] : 0.f;
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (oy < g.H && ox < g.W) {
-                    float val = acc[mt][nt][r];
-                    s1[nt] += val; s2[nt] += val * val;
-                    if (ep_scale) val = val * es + et;
-                    if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
-                    const size_t px = (size_t)(b * g.H + oy) * g.W + ox;
-                    if (addsrc) val += addsrc[px * ld_add + n];
-                    y[px * ldy + n] = val;
+                for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < C1_K; ++ky)
+#pragma unroll
+            for (int j = 0; j < C1_KP / 2; ++j) {
+                const float a0 = pa[ky * C1_PW + 2 * j], a1 = pa[(ky + 1) * C1_PW + 2 * j];
+                const float b0 = pb[(ky * C1_KP + 2 * j) * C1_N], b1 = pb[(ky * C1_KP + 2 * j) * C1_N + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        // epilogue: acc[mt][nt][r] = pixel (row y0 + 2*wave + mt, column x0 + (r&3) + 8*(r>>2) + 4*h), channel nt*32 + l32
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int oy = y0 + 2 * wave + mt;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = nt * 32 + l32;
+                const float es = ep_scale ? ep_scale[n] : 1.f, et = ep_shift ? ep_shift[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (oy < g.H && ox < g.W) {
+                        float val = acc[mt][nt][r];
+                        s1[nt] += val; s2[nt] += val * val;
+                        if (ep_scale) val = val * es + et;
+                        if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
+                        const size_t px = (size_t)(b * g.H + oy) * g.W + ox;
+                        if (addsrc) val += addsrc[px * ld_add + n];
+                        y[px * ldy + n] = val;
+                    }
                 }
             }
         }
-    }
-    if (stats) {
+        if (stats) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            s1[nt] += __shfl_xor(s1[nt], 32, 64);
-            s2[nt] += __shfl_xor(s2[nt], 32, 64);
-            if (h == 0) { red[(wave * 2 + 0) * C1_N + nt * 32 + l32] = s1[nt]; red[(wave * 2 + 1) * C1_N + nt * 32 + l32] = s2[nt]; }
-        }
-        __syncthreads();
-        if (tid < 2 * C1_N) {
-            const int which = tid / C1_N, n = tid % C1_N;
-            const float v = ((red[(0 * 2 + which) * C1_N + n] + red[(1 * 2 + which) * C1_N + n]) + red[(2 * 2 + which) * C1_N + n]) +
-                            red[(3 * 2 + which) * C1_N + n];
-            const size_t slot = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-            stats[(slot * 2 + which) * C1_N + n] = v;
+            for (int nt = 0; nt < 2; ++nt) {
+                s1[nt] += __shfl_xor(s1[nt], 32, 64);
+                s2[nt] += __shfl_xor(s2[nt], 32, 64);
+                if (h == 0) { red[(wave * 2 + 0) * C1_N + nt * 32 + l32] = s1[nt]; red[(wave * 2 + 1) * C1_N + nt * 32 + l32] = s2[nt]; }
+            }
+            __syncthreads();
+            if (tid < 2 * C1_N) {
+                const int which = tid / C1_N, n = tid % C1_N;
+                const float v = ((red[(0 * 2 + which) * C1_N + n] + red[(1 * 2 + which) * C1_N + n]) + red[(2 * 2 + which) * C1_N + n]) +
+                                red[(3 * 2 + which) * C1_N + n];
+                stats[((size_t)t * 2 + which) * C1_N + n] = v;
+            }
         }
     }
 }
@@ -144,25 +151,38 @@ __global__ __launch_bounds__(256, 2) void conv_c1_wgrad_kernel(const float* __re
         tapoff[mt] = tau < C1_K * C1_KP ? (tau / C1_KP) * C1_PW + tau % C1_KP : 0;
     }
     const int ntiles = g.B * tiles_y * tiles_x;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // software pipeline: the next tile's 128 x 64 gw values (8 x 16 B per thread) and patch values travel in registers while
+    // the MFMAs of the current tile run from LDS
+    f32x4 rg[8];
+    float rp[2];
+    auto fetch = [&](int t) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
         const int x0 = tx * C1_TW, y0 = ty * C1W_TH;
         const float* img = x1 + (size_t)b * g.H * g.W;
-        __syncthreads();                                     // previous tile fully consumed
-        for (int i = tid; i < C1W_PH * C1_PW; i += 256) {
-            const int py = i / C1_PW, px = i % C1_PW;
-            patch[i] = px < C1_TW + C1_K - 1 ? c1_fetch(img, g.H, g.W, y0 + py - g.pad, x0 + px - g.pad, g.reflect, g.pad) : 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = tid + e * 256, py = i / C1_PW, px = i - py * C1_PW;
+            rp[e] = (i < C1W_PH * C1_PW && px < C1_TW + C1_K - 1)
+                        ? c1_fetch(img, g.H, g.W, y0 + py - g.pad, x0 + px - g.pad, g.reflect, g.pad) : 0.f;
         }
-        // gw tile: 128 pixels x 64 channels, 16 B per thread and pass (pixels beyond the image read as zero)
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
             const int q = ps * 16 + (tid >> 4), c4 = (tid & 15) * 4;
             const int oy = y0 + q / C1_TW, ox = x0 + q % C1_TW;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (oy < g.H && ox < g.W) v = *reinterpret_cast<const f32x4*>(gw + ((size_t)(b * g.H + oy) * g.W + ox) * ldg + c4);
-            *reinterpret_cast<f32x4*>(&gt[q * C1_N + c4]) = v;
+            rg[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (oy < g.H && ox < g.W) rg[ps] = *reinterpret_cast<const f32x4*>(gw + ((size_t)(b * g.H + oy) * g.W + ox) * ldg + c4);
         }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();                                     // previous tile fully consumed
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (tid + e * 256 < C1W_PH * C1_PW) patch[tid + e * 256] = rp[e];
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) *reinterpret_cast<f32x4*>(&gt[(ps * 16 + (tid >> 4)) * C1_N + (tid & 15) * 4]) = rg[ps];
         __syncthreads();
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
         const float* pa = patch + wave * C1_PW + h;           // + tapoff + px
         const float* pb = gt + (wave * C1_TW + h) * C1_N + l32;   // + px * N + nt * 32
 #pragma unroll
@@ -213,16 +233,30 @@ __global__ __launch_bounds__(256, 2) void conv_c1_wgrad_kernel(const float* __re
     }
 }
 
-// dw[tap][n] = sum over workgroups of part[wg][ky * 10 + kx][n]  (fixed order; pad taps dropped; taps flipped when asked)
+// dw[tap][n] = sum over workgroups of part[wg][ky * 10 + kx][n]  (fixed order; pad taps dropped; taps flipped when asked).
+// One block per tap: thread (n, grp) sums the workgroups grp, grp + 4, ... with eight independent accumulators, the four
+// groups meet in LDS.
 __global__ __launch_bounds__(256) void conv_c1_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nwg, int flip) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= C1_K * C1_K * C1_N) return;
-    const int n = i % C1_N, tap = i / C1_N, ky = tap / C1_K, kx = tap % C1_K;
+    __shared__ float sh[4 * C1_N];
+    const int tap = blockIdx.x, ky = tap / C1_K, kx = tap % C1_K;
+    const int n = threadIdx.x & (C1_N - 1), grp = threadIdx.x >> 6;
     const float* src = part + (size_t)(ky * C1_KP + kx) * C1_N + n;
-    float s = 0.f;
-    for (int wg = 0; wg < nwg; ++wg) s += src[(size_t)wg * 96 * C1_N];
-    const int to = flip ? (C1_K * C1_K - 1 - tap) : tap;
-    dw[(size_t)to * C1_N + n] = s;
+    const size_t ws = (size_t)96 * C1_N;
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    int wg = grp;
+    for (; wg + 28 < nwg; wg += 32) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += src[(size_t)(wg + 4 * e) * ws];
+    }
+    for (; wg < nwg; wg += 4) a[0] += src[(size_t)wg * ws];
+    sh[grp * C1_N + n] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (grp == 0) {
+        const int to = flip ? (C1_K * C1_K - 1 - tap) : tap;
+        dw[(size_t)to * C1_N + n] = (sh[n] + sh[C1_N + n]) + (sh[2 * C1_N + n] + sh[3 * C1_N + n]);
+    }
 }
 
 bool c1_ok(int32_t B, int32_t H, int32_t W, int32_t N, int32_t k, int32_t pad, int32_t reflect) {
@@ -231,6 +265,7 @@ bool c1_ok(int32_t B, int32_t H, int32_t W, int32_t N, int32_t k, int32_t pad, i
     return true;
 }
 constexpr int C1_WGRAD_WGS = 1024;
+constexpr int C1_FWD_WGS = 1024;      // persistent forward grid: 4 workgroups per CU, the weights staged once each
 
 }  // namespace
 
@@ -245,8 +280,9 @@ extern "C" int gdn_conv_c1_fwd(const float* x1, int32_t B, int32_t H, int32_t W,
     if (!c1_ok(B, H, W, N, k, pad, reflect)) return GDN_ERR_UNSUPPORTED;
     if (!x1 || !w || !y || (!ep_scale) != (!ep_shift) || (act & GDN_ACT_TANH)) return GDN_ERR_BAD_ARG;
     const C1Geom g = {B, H, W, pad, reflect ? 1 : 0, flip ? 1 : 0};
-    hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3(cdiv(W, C1_TW), cdiv(H, C1_TH), B), dim3(256), 0, (hipStream_t)stream, x1, w, y, ldy,
-                       addsrc, ld_add, stats, ep_scale, ep_shift, act, g);
+    const int tiles_x = cdiv(W, C1_TW), tiles_y = cdiv(H, C1_TH), ntiles = B * tiles_x * tiles_y;
+    hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3(ntiles < C1_FWD_WGS ? ntiles : C1_FWD_WGS), dim3(256), 0, (hipStream_t)stream, x1, w, y,
+                       ldy, addsrc, ld_add, stats, ep_scale, ep_shift, act, g, tiles_x, tiles_y);
     return gdn_launch_status();
 }
 
@@ -265,7 +301,7 @@ extern "C" int gdn_conv_c1_wgrad(const float* x1, const float* gw, int32_t ldg, 
     const int nwg = ntiles < C1_WGRAD_WGS ? ntiles : C1_WGRAD_WGS;
     hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x1, gw, ldg, (float*)workspace, g, tiles_x,
                        tiles_y);
-    hipLaunchKernelGGL(conv_c1_wgrad_reduce_kernel, dim3(cdiv(C1_K * C1_K * C1_N, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(conv_c1_wgrad_reduce_kernel, dim3(C1_K * C1_K), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, dw, nwg, flip ? 1 : 0);
     return gdn_launch_status();
 }

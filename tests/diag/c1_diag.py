@@ -32,3 +32,30 @@ for (B, H, W) in ((1, 32, 64), (2, 128, 416)):
     opf.wgrad(dpre, g64, dwa)
     ops.conv_c1_wgrad(dpre, g64, dwb, reflect=True)
     print("   first conv wgrad: max|diff| %.3e, max|ref| %.3e" % (float((dwa - dwb).abs().max()), float(dwa.abs().max())))
+
+
+def timed(fn, reps=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+B, H, W = 20, 128, 416
+dpre = torch.randn(B, H, W, 1, device=gpu)
+x = torch.randn(B, H, W, 64, device=gpu)
+w = torch.randn(81, 1, 64, device=gpu) * 0.05
+dw = torch.empty_like(w)
+op = ops.Conv(64, 1, 9, 1, 4, transposed=True)
+wt = ops.transpose_taps(w)
+opf = ops.Conv(1, 64, 9, 1, 4, reflect=True)
+wf = torch.randn(81, 64, 1, device=gpu) * 0.1
+print("B=20 128x416 (us):  c1 fwd+stats %.0f (direct %.0f) | head dgrad c1 %.0f (direct %.0f) | wgrad c1 %.0f (direct thin %.0f)" % (
+    timed(lambda: ops.conv_c1_fwd(dpre, wf, reflect=True, stats=True)), timed(lambda: opf.fwd(dpre, wf, stats=True)),
+    timed(lambda: ops.conv_c1_fwd(dpre, w, flip=False)), timed(lambda: op.dgrad(dpre, wt, (H, W))),
+    timed(lambda: ops.conv_c1_wgrad(dpre, x, dw)), timed(lambda: op.wgrad(x, dpre, dw))))

@@ -483,7 +483,7 @@ def main():
                 "kernel": "wino_gemm_kernel: the 16 per-bin fp32 MFMA GEMMs [%d x 512] x [512 x 512] of the Winograd F(2x2,3x3) "
                           "3x3 s1 512->512 layer, B=%d 16x52 (level 3)" % (B * 8 * 26, B),
                 "bound": "mfma", "achieved": round(ag, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ag / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("r01_wino_gemm_pmc.json"),
+                "frac": round(ag / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("r02_wino_gemm_pmc.json"),
                 "gflop_per_launch": round(fl_g / 1e9, 2), "ms_per_launch": round(ms_g, 4),
                 "layer_forward": {"ms": round(ms_l, 4), "direct_conv_gflop": round(fl_l / 1e9, 2),
                                   "direct_equiv_tflops": round(fl_l / (ms_l * 1e-3) / 1e12, 2),

@@ -193,6 +193,7 @@ inline void launch_wino_gemm_tn(const float* A, const float* Bm, float* P, int M
 
 // 64-row tiles: the 128-row instantiation (two MFMA tiles per wave sharing the B fragment, 3 workgroups per CU) measured
 // the same at level 3 (0.392 vs 0.397 ms per forward) and 8 % slower at level 4
+// (and 7-23 % slower on the short-K GEMMs of the stride-2 layers, K = 128 / 256: 3.35 vs 3.14 ms over their eight forwards)
 void launch_wino_gemm(const float* A, const float* Bm, float* Cm, int M, int N, int K, hipStream_t st) {
     hipLaunchKernelGGL((wino_gemm_kernel<WINO_KC, 64>), dim3(cdiv(M, 64) * (N / 64) * WINO_BINS), dim3(256), 0, st, A, Bm, Cm, M, N, K);
 }

@@ -79,8 +79,14 @@ class Adam(torch.optim.Optimizer):
                 if len(ps) != len(ar.items):
                     loose.extend(ps)      # partial coverage: fall back to per-tensor launches
                     continue
+                if all(p.grad is None for p in ps):
+                    continue              # nothing ran backward for this model: skip it, like torch.optim.Adam
                 if any(p.grad is None for p in ps):
-                    raise GdnError("fused Adam: some parameters have no gradient; run backward first")
+                    # part of the model got no gradient this step (frozen sub-modules, an unused branch): torch.optim.Adam
+                    # skips those parameters, and so does the per-tensor path below -- the one-launch arena update would
+                    # apply weight decay and stale moments to them
+                    loose.extend(p for p in ps if p.grad is not None)
+                    continue
                 st = self._flat.get(id(ar))
                 if st is None:
                     st = {"m": ops.zeros((ar.numel,), ar.device), "v": ops.zeros((ar.numel,), ar.device), "step": 0}

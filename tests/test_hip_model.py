@@ -575,3 +575,29 @@ def test_rccl_single_rank_reducer_is_bitwise_identity(gpu, tmp_path):
     assert plain["losses"] == dist["losses"]
     for k, v in plain["sd"].items():
         assert torch.equal(v, dist["sd"][k]), k
+
+
+def test_adam_skips_parameters_without_gradient(gpu):
+    """A frozen sub-module inside a trained model: its parameters get no gradient (engine) and must not move (optimizer),
+    exactly like torch.optim.Adam; the rest takes the same step as a fully trainable model's would for those parameters."""
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import utils as U
+    from gdn_amd.optim import Adam
+    H, W = 32, 64
+    depth, rgb, sparse = [t.to(gpu) for t in O.synthetic_batch(1, H, W, seed=3)]
+    torch.manual_seed(2)
+    model = M.AutoEncoder_DtoD(input_dim=1, height=H, width=W).to(gpu).train()
+    model.res512_3.requires_grad_(False)
+    opt = Adam(model.parameters(), 1e-3, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    for _ in range(2):
+        out = model(depth, istrain=False)
+        loss, _, _ = U.dtod_loss(out, depth, sparse)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    for k, p in model.named_parameters():
+        if k.startswith("res512_3."):
+            assert torch.equal(p.detach(), before[k]), k
+        else:
+            assert not torch.equal(p.detach(), before[k]), k

@@ -112,6 +112,18 @@ def train_AE_DtoD(args, model, criterion_L2, criterion_L1, optimizer, dataset_lo
     return loss
 
 
+def _cat_batch(a, b):
+    """torch.cat((a, b), 0) for two dense [B,1,H,W] device tensors without a torch kernel (two pitched copies)."""
+    from . import ops
+    if a.shape[1] != 1 or a.dtype != torch.float32 or b.dtype != torch.float32 or a.shape != b.shape or a.shape[3] % 4:
+        return torch.cat((a, b), 0)
+    B, _, H, W = a.shape
+    out = torch.empty((2 * B, 1, H, W), dtype=torch.float32, device=a.device)
+    ops.copy_rows(a.contiguous(), out[:B])
+    ops.copy_rows(b.contiguous(), out[B:])
+    return out
+
+
 def guide_latent_loss(G, depths, outputs, faithful=False, latent_grad=False):
     """Latent loss of trainer.py:699-733: G's features of the ground truth vs. of the estimate.
 
@@ -129,13 +141,16 @@ def guide_latent_loss(G, depths, outputs, faithful=False, latent_grad=False):
             ft_tar = feats(depths)
         return U.latent_loss(feats(outputs), ft_tar)
     with torch.no_grad():
-        if faithful or not hasattr(G, "guide_features") or G.training:
+        if G.training:
             # (training-mode batch statistics would couple the two halves of a batched pass: keep them separate)
             ft_tar = feats(depths)
             ft = feats(outputs.detach())
         else:
+            # eval-mode guide: no cross-sample coupling, so the two forwards share ONE pass over the concatenated batch --
+            # element for element the same arithmetic, half the launches, the weight transforms computed once.  `faithful`
+            # still runs the whole network (decoder included) like the reference; otherwise the pass stops at the bottleneck.
             B = depths.shape[0]
-            both = G.guide_features(torch.cat((depths, outputs.detach()), 0))
+            both = feats(_cat_batch(depths, outputs.detach()))
             ft_tar = [f[:B] for f in both]
             ft = [f[B:] for f in both]
     return U.latent_loss(ft, ft_tar)

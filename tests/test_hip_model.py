@@ -601,3 +601,20 @@ def test_adam_skips_parameters_without_gradient(gpu):
             assert torch.equal(p.detach(), before[k]), k
         else:
             assert not torch.equal(p.detach(), before[k]), k
+
+
+def test_guide_batched_pass_is_bitwise_the_two_forwards(gpu):
+    """RtoD latent loss with the frozen eval-mode guide: one pass over cat(depths, outputs) gives BITWISE the features of the
+    reference's two separate forwards (faithful mode: full network; default: encoder only)."""
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import trainer as T
+    from gdn_amd import utils as U
+    torch.manual_seed(1)
+    G = M.AutoEncoder_DtoD(input_dim=1, height=64, width=96).to(gpu).eval()
+    depth, _, _ = [t.to(gpu) for t in O.synthetic_batch(3, 64, 96, seed=5)]
+    est = (depth + 0.2 * torch.randn_like(depth)).clamp(-1, 1)
+    with torch.no_grad():
+        two = U.latent_loss(G(est, istrain=True)[:4], G(depth, istrain=True)[:4])
+    for faithful in (True, False):
+        one = T.guide_latent_loss(G, depth, est, faithful=faithful)
+        assert torch.equal(one, two), (faithful, float(one), float(two))

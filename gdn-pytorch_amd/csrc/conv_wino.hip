@@ -106,7 +106,11 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
 
 // U = G g G^T.  swap = 0: U[bin][n][c] from w[tap][n][c] (forward);  swap = 1: U[bin][c][n] from the flipped taps
 // (data gradient: correlation of dy with w[n][c][2 - ty][2 - tx], output channel c)
-__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int N, int C, int swap) {
+// Uswap != NULL (forward of a layer that will run backward): the data gradient's set (taps flipped: bins permuted
+// (3,1,2,0) per axis; channel roles swapped) is written by the same launch from the same nine reads -- the weights do not
+// change between a step's forward and backward, so the backward needs no weight transform of its own.
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int N, int C, int swap,
+                                                           float* __restrict__ Uswap) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N * C) return;
     const int c = i % C, n = i / C;
@@ -128,12 +132,28 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     }
     float* dst = U + (swap ? (size_t)c * N + n : (size_t)n * C + c);
     const size_t bs = (size_t)N * C;
+    float u[4][4];
 #pragma unroll
     for (int i2 = 0; i2 < 4; ++i2) {
-        dst[0] = r[i2][0]; dst += bs; GDN_KEEP(dst);
-        dst[0] = 0.5f * (r[i2][0] + r[i2][1] + r[i2][2]); dst += bs; GDN_KEEP(dst);
-        dst[0] = 0.5f * (r[i2][0] - r[i2][1] + r[i2][2]); dst += bs; GDN_KEEP(dst);
-        dst[0] = r[i2][2]; dst += bs; GDN_KEEP(dst);
+        u[i2][0] = r[i2][0];
+        u[i2][1] = 0.5f * (r[i2][0] + r[i2][1] + r[i2][2]);
+        u[i2][2] = 0.5f * (r[i2][0] - r[i2][1] + r[i2][2]);
+        u[i2][3] = r[i2][2];
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) { dst[0] = u[i2][j2]; dst += bs; GDN_KEEP(dst); }
+    if (Uswap) {
+        // G flip(g) G^T = P (G g G^T) P with P the permutation (3,1,2,0): flipping the taps swaps rows 0 <-> 3 of G g
+        float* d2 = Uswap + (size_t)c * N + n;
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                const int pi = i2 == 0 ? 3 : (i2 == 3 ? 0 : i2), pj = j2 == 0 ? 3 : (j2 == 3 ? 0 : j2);
+                d2[0] = u[pi][pj]; d2 += bs; GDN_KEEP(d2);
+            }
     }
 }
 
@@ -260,10 +280,10 @@ inline int tn_splits(const WinoGeom& f) { return wino_tn_splits(f.M, f.N, f.C); 
 
 }  // namespace
 
-// saved state of one forward for its backward: the transformed input V
+// saved state of one forward for its backward: the transformed input V, then the data gradient's transformed weights
 extern "C" size_t gdn_winoconv_state_bytes(const gdn_conv_geom* g) {
     WinoGeom f;
-    return wino_geom(g, f) ? v_bytes(f) : 0;
+    return wino_geom(g, f) ? v_bytes(f) + u_bytes(f) : 0;
 }
 
 // workspace: V, U, Mo
@@ -294,9 +314,10 @@ extern "C" int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t 
     float* U = (float*)p; p += u_bytes(f);
     float* Mo = (float*)p;
     if (state_out) V = (float*)state_out;
+    float* Usw = state_out ? (float*)((char*)state_out + v_bytes(f)) : nullptr;
     hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(f.M, 4) << f.cq_shift), dim3(256), 0, st, x, ldx, V, f, in_scale, in_shift,
                        in_relu);
-    hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 0);
+    hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 0, Usw);
     launch_wino_gemm((const float*)V, (const float*)U, Mo, f.M, f.N, f.C, st);
     hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, (const float*)Mo, y, ldy, addsrc,
                        ld_add, stats, ep_scale, ep_shift, act, f, f.N, f.nq_shift, (const float*)nullptr, 0,
@@ -330,7 +351,7 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
     (void)hipGetLastError();
     WinoGeom f;
     if (!wino_geom(g, f)) return GDN_ERR_UNSUPPORTED;
-    if (!dy || (!dx && !dw) || (dx && !w) || (dw && !state)) return GDN_ERR_BAD_ARG;
+    if (!dy || (!dx && !dw) || (dx && !w && !state) || (dw && !state)) return GDN_ERR_BAD_ARG;
     if (bnb_y && (!dx || !bnb_co || !bnb_partial)) return GDN_ERR_BAD_ARG;
     if (bnb_y && f.reflect) return GDN_ERR_UNSUPPORTED;
     if (dx && f.reflect && ((ldx % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
@@ -364,8 +385,10 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
         }
         hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(fd.M, 4) << fd.cq_shift), dim3(256), 0, st, dy, ldy, Vd, fd,
                            (const float*)nullptr, (const float*)nullptr, 0);
-        hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 1);
-        launch_wino_gemm((const float*)Vd, (const float*)U, Eo, fd.M, f.C, f.N, st);
+        const float* Ud = U;
+        if (state) Ud = (const float*)((const char*)state + v_bytes(f));      // transformed by the forward's launch
+        else hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 1, (float*)nullptr);
+        launch_wino_gemm((const float*)Vd, Ud, Eo, fd.M, f.C, f.N, st);
         hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(fd.M, 4) << fd.nq_shift), dim3(256), 0, st, (const float*)Eo, out, ld_out,
                            f.reflect ? (const float*)nullptr : addsrc, ld_add, bnb_y ? bnb_partial : (float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, 0, fd, f.C, fd.nq_shift, bnb_y, ld_bnb, bnb_co, bnb_relu);

@@ -102,11 +102,11 @@ __device__ __forceinline__ void w2_store_u(float g00, float g01, float g10, floa
 __global__ __launch_bounds__(256) void w2_weights_a_kernel(const float* __restrict__ w, float* __restrict__ U, int Nout, int Cx, int swap) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Nout * Cx) return;
-    // consecutive threads walk the CONTIGUOUS index of the source so the 16 tap reads coalesce
-    const int sIdx = swap ? Nout : Cx, s = i % sIdx, r = i / sIdx;
-    const int n = swap ? s : r, c = swap ? r : s;
+    // consecutive threads walk c, the contiguous index of the OUTPUT: the 64 stores coalesce (the 16 tap reads are strided
+    // when swap, 4x fewer of them)
+    const int c = i % Cx, n = i / Cx;
     const size_t ts = (size_t)Nout * Cx;
-    const float* src = w + (size_t)r * sIdx + s;
+    const float* src = w + (swap ? (size_t)c * Nout + n : (size_t)n * Cx + c);
     float g[4][4];
 #pragma unroll
     for (int ty = 0; ty < 4; ++ty)
@@ -127,10 +127,9 @@ __global__ __launch_bounds__(256) void w2_weights_a_kernel(const float* __restri
 __global__ __launch_bounds__(256) void w2_weights_b_kernel(const float* __restrict__ w, float* __restrict__ U, int Nout, int Cd, int swap) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Nout * Cd) return;
-    const int sIdx = swap ? Nout : Cd, s = i % sIdx, r = i / sIdx;
-    const int n = swap ? s : r, cd = swap ? r : s;
+    const int cd = i % Cd, n = i / Cd;                       // cd: the contiguous index of the output
     const size_t ts = (size_t)Nout * Cd;
-    const float* src = w + (size_t)r * sIdx + s;
+    const float* src = w + (swap ? (size_t)cd * Nout + n : (size_t)n * Cd + cd);
     float g[4][4];
 #pragma unroll
     for (int ty = 0; ty < 4; ++ty)

@@ -182,7 +182,8 @@ int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const 
  * in_scale / in_shift / in_relu: as for gdn_fftconv_fwd (the producer's train-mode BatchNorm + ReLU
  * applied while the 4x4 patches are loaded).
  * state_out (nullable, gdn_winoconv_state_bytes) receives the transformed input, which
- * gdn_winoconv_bwd needs for the weight gradient.  Cin/64 and Cout/64 must be powers of two. */
+ * gdn_winoconv_bwd needs for the weight gradient, followed by the data gradient's transformed weights (written by the same
+ * weight-transform launch: the backward of that step then runs no weight transform).  Cin/64 and Cout/64 must be powers of two. */
 size_t gdn_winoconv_fwd_workspace_bytes(const gdn_conv_geom* g);
 size_t gdn_winoconv_state_bytes(const gdn_conv_geom* g);
 int64_t gdn_winoconv_stats_slots(const gdn_conv_geom* g);
@@ -191,8 +192,8 @@ int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const 
                      const float* ep_scale, const float* ep_shift, int32_t act,
                      const float* in_scale, const float* in_shift, int32_t in_relu,
                      void* state_out, void* workspace, size_t workspace_bytes, void* stream);
-/* dx = dgrad (+ addsrc) when dx != NULL (needs w), dw[tap][Cout][Cin] = wgrad when dw != NULL
- * (needs state).
+/* dx = dgrad (+ addsrc) when dx != NULL (needs state, or w when state is NULL), dw[tap][Cout][Cin] = wgrad when
+ * dw != NULL (needs state).
  * bnb_* (nullable; replaces the reduce pass of gdn_bn_bwd, AE_model_unet.py:51,54,68): dx is the gradient of
  * z = [relu](BN_train(bnb_y)), bnb_y [B,H,W,Cin] with pitch ld_bnb being that BatchNorm's input and
  * bnb_co = {scale, shift, mean, invstd}[Cin]; the output transform that writes dx (+ addsrc) also writes

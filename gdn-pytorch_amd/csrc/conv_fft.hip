@@ -24,10 +24,13 @@
 //   weight gradient  P[bin] = Df[bin]^T * Xf[bin] (reduction over tiles, MFMA), inverse DFT at the k*k taps only
 #include "common.h"
 
-#define FFT_N 32
-#define FFT_NK 17            // kx bins kept of a real row transform
-#define FFT_BINS (FFT_N * FFT_NK)
-static_assert(FFT_BINS % 8 == 0, "bins are dealt to the 8 XCDs");
+// Tile size NP (points per side): 32 for the 7x7 / 9x9 layers, 16 for the 5x5 (and 3x3) layers on >= 256 channels, whose weight
+// spectrum would otherwise outweigh the activations' (544 bins x 256 x 256 x 3 planes = 428 MB per layer; 113 MB at 144 bins)
+// and whose 32 x 104 images tile badly with T = 28 (56 x 112 computed for 32 x 104).  NK = NP/2 + 1 kx bins are kept of a
+// real row transform; bins = NP * NK is a multiple of 8 for both sizes (they are dealt to the 8 XCDs).
+#define FFT_NK_OF(NP) ((NP) / 2 + 1)
+#define FFT_BINS_OF(NP) ((NP) * FFT_NK_OF(NP))
+static_assert(FFT_BINS_OF(32) % 8 == 0 && FFT_BINS_OF(16) % 8 == 0, "bins are dealt to the 8 XCDs");
 // Index arithmetic is kept off the vector ALU (the transform kernels are VALU-bound; 64-bit divisions and per-element
 // 64-bit multiplies were most of their instructions): grids carry (channel chunk, tile), row and image instead of a
 // flat index, and every strided access walks a running pointer.  GDN_KEEP pins a running value so the unrolled loops do
@@ -52,17 +55,21 @@ __device__ __constant__ float kSin32[32] = {
     -0.92387953251128652f, -0.98078528040323032f, -1.0f, -0.98078528040323043f, -0.92387953251128663f,
     -0.83146961230254546f, -0.70710678118654768f, -0.55557023301960218f, -0.38268343236509039f, -0.19509032201612872f};
 
-// In-register radix-2 decimation-in-time FFT of 32 complex points.  SIGN = -1 forward, +1 inverse (unscaled).
-// The loops are fully unrolled and the twiddles are compile-time literals, so the trivial ones (1, -+i: 46 of the 80
-// butterflies) cost no multiplies and the (1 -+ i)/sqrt2 ones two.
-template <int SIGN>
-__device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
+// In-register radix-2 decimation-in-time FFT of NP (32 or 16) complex points.  SIGN = -1 forward, +1 inverse (unscaled).
+// The loops are fully unrolled and the twiddles are compile-time literals, so the trivial ones (1, -+i) cost no multiplies
+// and the (1 -+ i)/sqrt2 ones two.
+template <int NP, int SIGN>
+__device__ __forceinline__ void fftn(float (&re)[NP], float (&im)[NP]) {
+    static_assert(NP == 32 || NP == 16, "tile size");
+    constexpr int LOG = NP == 32 ? 5 : 4, SC = 32 / NP;
     constexpr float C32[9] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f,
                               0.55557023301960229f, 0.38268343236508984f, 0.19509032201612833f, 0.0f};
-    // bit reversal (5 bits): pure register renaming after unrolling
+    // bit reversal (LOG bits): pure register renaming after unrolling
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const int j = ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
+    for (int i = 0; i < NP; ++i) {
+        int j = 0;
+#pragma unroll
+        for (int b = 0; b < LOG; ++b) j |= ((i >> b) & 1) << (LOG - 1 - b);
         if (j > i) {
             const float tr = re[i], ti = im[i];
             re[i] = re[j]; im[i] = im[j];
@@ -70,13 +77,13 @@ __device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
         }
     }
 #pragma unroll
-    for (int s = 1; s <= 5; ++s) {
-        const int half = 1 << (s - 1), span = 1 << s, tstep = 32 >> s;
+    for (int s = 1; s <= LOG; ++s) {
+        const int half = 1 << (s - 1), span = 1 << s, tstep = NP >> s;
 #pragma unroll
-        for (int k = 0; k < 32; k += span) {
+        for (int k = 0; k < NP; k += span) {
 #pragma unroll
             for (int j = 0; j < half; ++j) {
-                const int q = j * tstep;                 // twiddle angle 2*pi*q/32, q in [0, 16)
+                const int q = j * tstep * SC;            // twiddle angle 2*pi*q/32, q in [0, 16)
                 const int a = k + j, b = a + half;
                 float xr, xi;
                 if (q == 0) {
@@ -100,6 +107,7 @@ __device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
 }
 
 struct FftGeom {
+    int np, bins;                // tile size (32 / 16), kept bins = np * (np/2 + 1)
     int B, H, W, C, N;           // input [B,H,W,C], output channels N
     int k, pad, T, tiles_y, tiles_x, M;      // M = B * tiles_y * tiles_x
     int reflect;                             // input border: 0 zeros, 1 reflection (ReflectionPad2d(pad) + conv)
@@ -112,9 +120,10 @@ struct FftGeom {
 //   data gradient  e = d * conj(Wc)  :  m1 = P0 (dr + di), m2 = P1 di, m3 = P2 dr;   er = m1 + m2, ei = m1 - m3
 // so both directions read the same buffer and the weights are transformed once per step.
 // thread = (n, c) with its K*K taps in registers; block = one ky; column transform first, then the 17 kx bins.
-template <int K>
+template <int K, int NP>
 __global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restrict__ w /* [k*k][N][C] */, float* __restrict__ Wf,
                                                           int N, int C, int flip) {
+    constexpr int NK = FFT_NK_OF(NP), SC = 32 / NP;
     const int ky = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N * C) return;
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restric
     for (int tx = 0; tx < K; ++tx) { ur[tx] = 0.f; ui[tx] = 0.f; }
 #pragma unroll
     for (int ty = 0; ty < K; ++ty) {
-        const int ph = (ky * ty) & 31;
+        const int ph = ((ky * ty) & (NP - 1)) * SC;
         const float cs = kCos32[ph], sn = kSin32[ph];
 #pragma unroll
         for (int tx = 0; tx < K; ++tx) {
@@ -136,17 +145,17 @@ __global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restric
     }
     const size_t plane = (size_t)N * C;
 #pragma unroll
-    for (int kx = 0; kx < FFT_NK; ++kx) {
+    for (int kx = 0; kx < NK; ++kx) {
         float wr = 0.f, wi = 0.f;
 #pragma unroll
         for (int tx = 0; tx < K; ++tx) {
-            const int ph = (kx * tx) & 31;
+            const int ph = ((kx * tx) & (NP - 1)) * SC;
             const float cs = kCos32[ph], sn = kSin32[ph];
             wr += ur[tx] * cs + ui[tx] * sn;       // (ur + i ui)(cs - i sn)
             wi += ui[tx] * cs - ur[tx] * sn;
         }
         const float wci = -wi;                     // conjugate
-        float* dst = Wf + (size_t)(ky * FFT_NK + kx) * 3 * plane + (size_t)n * C + c;
+        float* dst = Wf + (size_t)(ky * NK + kx) * 3 * plane + (size_t)n * C + c;
         dst[0] = wr;
         dst[plane] = wci - wr;
         dst[2 * plane] = wr + wci;
@@ -257,25 +266,27 @@ __global__ __launch_bounds__(256, 4) void cgemm_bins_kernel(const float* __restr
 
 // icols: thread = (tile, kx, channel n): inverse FFT32 along ky, rows u < nrows kept.
 // grid: x = (tile / 4) * (C / 64) + channel chunk, y = kx; block = 4 tiles x 64 channels
+template <int NP>
 __global__ __launch_bounds__(256) void ifft_cols_kernel(const float2* __restrict__ Yf, float2* __restrict__ S, int C, int M, int nrows,
                                                         int cq_shift) {
+    constexpr int NK = FFT_NK_OF(NP);
     const int t = (blockIdx.x >> cq_shift) * 4 + (threadIdx.x >> 6);
     if (t >= M) return;
     const int c = (blockIdx.x & ((1 << cq_shift) - 1)) * 64 + (threadIdx.x & 63), kx = blockIdx.y;
-    float re[32], im[32];
+    float re[NP], im[NP];
     const float2* src = Yf + ((size_t)kx * M + t) * C + c;
-    const size_t sk = (size_t)FFT_NK * M * C;
+    const size_t sk = (size_t)NK * M * C;
 #pragma unroll
-    for (int ky = 0; ky < 32; ++ky) {
+    for (int ky = 0; ky < NP; ++ky) {
         const float2 v = *src;
         re[ky] = v.x; im[ky] = v.y;
         src += sk; GDN_KEEP(src);
     }
-    fft32<1>(re, im);
-    float2* dst = S + (((size_t)t * FFT_N) * FFT_NK + kx) * C + c;
-    const int su = FFT_NK * C;
+    fftn<NP, 1>(re, im);
+    float2* dst = S + (((size_t)t * NP) * NK + kx) * C + c;
+    const int su = NK * C;
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
+    for (int u = 0; u < NP; ++u) {
         if (u < nrows) *dst = make_float2(re[u], im[u]);
         dst += su; GDN_KEEP(dst);
     }
@@ -288,7 +299,8 @@ __global__ __launch_bounds__(256) void ifft_cols_kernel(const float2* __restrict
 // nsplit > 1: the reduction over the M tiles is cut into nsplit chunks (one workgroup each, partial spectra [split][bin][n][c]
 // summed in fixed order by the tap kernel): with 64 channels there are only 544 (bin, tile) workgroups otherwise -- two per CU.
 __global__ __launch_bounds__(256, 4) void cgemm_tn_bins_kernel(const float* __restrict__ D, const float* __restrict__ X,
-                                                            float* __restrict__ dWf, int M, int N, int C, int nsplit) {
+                                                            float* __restrict__ dWf, int M, int N, int C, int nsplit,
+                                                            int nbins) {
     constexpr int LD = 128;                              // 64 complex per row
     __shared__ __attribute__((aligned(16))) float Ds[16 * LD], Xs[16 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wi = wave >> 1, wj = wave & 1;
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(256, 4) void cgemm_tn_bins_kernel(const float* __re
         __syncthreads();
         if (m0 + 16 < me) { lstore(); __syncthreads(); }
     }
-    float2* Pb = reinterpret_cast<float2*>(dWf) + ((size_t)split * FFT_BINS + bin) * N * C;
+    float2* Pb = reinterpret_cast<float2*>(dWf) + ((size_t)split * nbins + bin) * N * C;
     const int col = j0 + wj * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -363,13 +375,14 @@ __global__ __launch_bounds__(256) void fft_sum_splits_kernel(float* __restrict__
     }
 }
 
-template <int K>
+template <int K, int NP>
 __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C) {
+    constexpr int NK = FFT_NK_OF(NP), SC = 32 / NP;
     __shared__ float red[3][K * K][64];
     const int pl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + pl;             // N*C is a multiple of 64
     const int c = i % C, n = i / C;
-    const int kx0 = grp == 0 ? 0 : 1 + grp * 4, kx1 = grp == 3 ? FFT_NK : 5 + grp * 4;     // 0-4, 5-8, 9-12, 13-16
+    const int kx0 = (grp * NK) / 4, kx1 = ((grp + 1) * NK) / 4;     // the NK kx bins in four groups
     float acc[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
@@ -380,20 +393,20 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
 #pragma unroll
         for (int ty = 0; ty < K; ++ty) { gr[ty] = 0.f; gi[ty] = 0.f; }
 #pragma unroll 8
-        for (int ky = 0; ky < FFT_N; ++ky) {
-            const float2 v = F[(size_t)(ky * FFT_NK + kx) * bs];
+        for (int ky = 0; ky < NP; ++ky) {
+            const float2 v = F[(size_t)(ky * NK + kx) * bs];
 #pragma unroll
             for (int ty = 0; ty < K; ++ty) {
-                const int ph = (ky * ty) & 31;
+                const int ph = ((ky * ty) & (NP - 1)) * SC;
                 const float cs = kCos32[ph], sn = kSin32[ph];
                 gr[ty] += v.x * cs - v.y * sn;
                 gi[ty] += v.x * sn + v.y * cs;
             }
         }
-        const float alpha = (kx == 0 || kx == 16) ? 1.f : 2.f;
+        const float alpha = (kx == 0 || kx == NP / 2) ? 1.f : 2.f;
 #pragma unroll
         for (int tx = 0; tx < K; ++tx) {
-            const int ph = (kx * tx) & 31;
+            const int ph = ((kx * tx) & (NP - 1)) * SC;
             const float cs = kCos32[ph] * alpha, sn = kSin32[ph] * alpha;
 #pragma unroll
             for (int ty = 0; ty < K; ++ty) acc[ty * K + tx] += gr[ty] * cs - gi[ty] * sn;
@@ -407,19 +420,21 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
     if (grp == 0) {
 #pragma unroll
         for (int t = 0; t < K * K; ++t)
-            dw[((size_t)t * N + n) * C + c] = (((acc[t] + red[0][t][pl]) + red[1][t][pl]) + red[2][t][pl]) * (1.0f / 1024.0f);
+            dw[((size_t)t * N + n) * C + c] = (((acc[t] + red[0][t][pl]) + red[1][t][pl]) + red[2][t][pl]) * (1.0f / (NP * NP));
     }
 }
 
 // Data gradient, overlap-add: tile (ty, tx) of dy contributes a full 32x32 patch of dx at offset -pad.  The (at most two)
 // tile rows that reach an image row are summed in the frequency domain before the row transform; along x the patches of
 // even and odd tiles are written by two launches (parity): the first writer of a column stores (+ addsrc), the second adds.
+template <int NP>
 __global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __restrict__ S, float* __restrict__ dx, int lddx,
                                                                 const float* __restrict__ addsrc, int ld_add, FftGeom g,
                                                                 int parity, int Ho, int Wo, int off, int cq_shift) {
     // output image Ho x Wo; patch row j of tile row ty lands on output row ty*T - off + j  (off = pad for a zero-padded
     // layer: dx itself; off = 0 for a reflection-padded one: the padded-domain gradient, folded afterwards)
     // grid: x = (tile-of-this-parity / 4) * (C / 64) + channel chunk, y = output row, z = image; block = 4 tiles x 64 channels
+    constexpr int NK = FFT_NK_OF(NP);
     const int C = g.C, T = g.T;
     const int ntx = (g.tiles_x + 1 - parity) / 2;         // tiles of this parity per row
     const int txl = (blockIdx.x >> cq_shift) * 4 + (threadIdx.x >> 6);
@@ -428,34 +443,34 @@ __global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __
     const int tx = txl * 2 + parity, iy = blockIdx.y, b = blockIdx.z;
     const int q = iy + off;
     const int ty_a = q / T, j_a = q - ty_a * T;
-    float re[32], im[32];
+    float re[NP], im[NP];
 #pragma unroll
-    for (int kx = 0; kx < FFT_NK; ++kx) { re[kx] = 0.f; im[kx] = 0.f; }
+    for (int kx = 0; kx < NK; ++kx) { re[kx] = 0.f; im[kx] = 0.f; }
     if (ty_a < g.tiles_y) {
         const int t = (b * g.tiles_y + ty_a) * g.tiles_x + tx;
-        const float2* src = S + (((size_t)t * FFT_N + j_a) * FFT_NK) * C + c;
+        const float2* src = S + (((size_t)t * NP + j_a) * NK) * C + c;
 #pragma unroll
-        for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = *src; re[kx] = v.x; im[kx] = v.y; src += C; GDN_KEEP(src); }
+        for (int kx = 0; kx < NK; ++kx) { const float2 v = *src; re[kx] = v.x; im[kx] = v.y; src += C; GDN_KEEP(src); }
     }
-    if (ty_a >= 1 && j_a + T < FFT_N) {
+    if (ty_a >= 1 && j_a + T < NP) {
         const int t = (b * g.tiles_y + ty_a - 1) * g.tiles_x + tx;
-        const float2* src = S + (((size_t)t * FFT_N + j_a + T) * FFT_NK) * C + c;
+        const float2* src = S + (((size_t)t * NP + j_a + T) * NK) * C + c;
 #pragma unroll
-        for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = *src; re[kx] += v.x; im[kx] += v.y; src += C; GDN_KEEP(src); }
+        for (int kx = 0; kx < NK; ++kx) { const float2 v = *src; re[kx] += v.x; im[kx] += v.y; src += C; GDN_KEEP(src); }
     }
 #pragma unroll
-    for (int kx = FFT_NK; kx < 32; ++kx) { re[kx] = re[32 - kx]; im[kx] = -im[32 - kx]; }
-    fft32<1>(re, im);
+    for (int kx = NK; kx < NP; ++kx) { re[kx] = re[NP - kx]; im[kx] = -im[NP - kx]; }
+    fftn<NP, 1>(re, im);
     const int ix0 = tx * T - off;
     float* dst = dx + ((size_t)(b * Ho + iy) * Wo + ix0) * lddx + c;               // may point before the row: only
     const float* ad = addsrc ? addsrc + ((size_t)(b * Ho + iy) * Wo + ix0) * ld_add + c : nullptr;   // dereferenced in range
     const bool has_next = tx + 1 < g.tiles_x;
     const int km1 = g.k - 1;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
+    for (int j = 0; j < NP; ++j) {
         const int ix = ix0 + j;
         if (ix >= 0 && ix < Wo) {
-            const float val = re[j] * (1.0f / 1024.0f);
+            const float val = re[j] * (1.0f / (NP * NP));
             // odd tiles: columns shared with the even neighbours were stored by the first launch
             const bool second = parity == 1 && (j < km1 || (j >= T && has_next));
             if (second) *dst += val;
@@ -496,7 +511,7 @@ __global__ __launch_bounds__(256) void fft_reflect_fold_kernel(const float* __re
 
 // ---- single-pass 2-D transforms: one workgroup = one tile x 16 channels, rows and columns meet in LDS (68 KB) ----
 #define FFT_CG 16
-#define FFT_LDS_ELEMS (FFT_N * FFT_NK * FFT_CG)
+#define FFT_LDS_ELEMS_OF(NP) ((NP) * FFT_NK_OF(NP) * FFT_CG)
 
 // forward: patch (halo = 1: rows/cols start at -pad, full 32; halo = 0: the T x T tile, zero padded) -> Xf[bin][tile][C]
 // two waves per SIMD: at four (128 VGPRs) the two 32-point transforms spill 44 dwords per lane and the kernel is 15 % slower
@@ -507,12 +522,14 @@ __global__ __launch_bounds__(256) void fft_reflect_fold_kernel(const float* __re
 // the tile transformed is this layer's dy = scale*(dz - k1 - xhat*k2), dz = dout*[z>0] (pass 3 of the BatchNorm backward,
 // AE_model_unet.py:51,54) computed on load from bnb_co = {scale, shift, mean, invstd}[C] and bnb_kk = {k1, k2}[C]: dy is
 // never written to memory.
-__global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ Xf,
+template <int NP>
+__global__ __launch_bounds__(NP * FFT_CG, NP == 32 ? 2 : 4) void fft2d_fwd_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ Xf,
                                                         FftGeom g, int halo, const float* __restrict__ in_scale,
                                                         const float* __restrict__ in_shift, int in_relu,
                                                         const float* __restrict__ bnb_y, int ld_bnb,
                                                         const float* __restrict__ bnb_co, const float* __restrict__ bnb_kk) {
-    __shared__ float2 lds[FFT_LDS_ELEMS];
+    constexpr int NK = FFT_NK_OF(NP);
+    __shared__ float2 lds[FFT_LDS_ELEMS_OF(NP)];
     // XCD-aware order: XCD j (= blockIdx & 7) owns the contiguous tile range [j, j+1) * ceil(M/8) and runs the channel
     // groups of one tile back to back, so the half cache lines the groups share and the halo rows / columns neighbouring
     // tiles share are served by that XCD's L2 instead of being fetched once per XCD
@@ -521,12 +538,12 @@ __global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restri
     const int t = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3) / ngrp;
     if (t >= g.M) return;
     const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
-    float re[32], im[32];
+    float re[NP], im[NP];
     {
         const int a = tid >> 4;
         const int iy = ty * g.T + a - (halo ? g.pad : 0);
         const int ix0 = tx * g.T - (halo ? g.pad : 0);
-        const int nvalid = halo ? FFT_N : g.T;
+        const int nvalid = halo ? NP : g.T;
         // reflection border (halo patches only): rows / columns -pad..-1 and H..H+pad-1 mirror the image; anything
         // further out only feeds outputs beyond the image and reads as zero
         const int lim = (halo && g.reflect) ? g.pad : 0;
@@ -540,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restri
         const float lo = in_relu ? 0.f : -3.402823466e38f;
         if (!bnb_y) {
 #pragma unroll
-            for (int bb = 0; bb < 32; ++bb) {
+            for (int bb = 0; bb < NP; ++bb) {
                 const int ix = ix0 + bb;
                 const bool ok = row_ok && bb < nvalid && ix >= -lim && ix < g.W + lim;
                 const bool inside = ix >= 0 && ix < g.W;
@@ -560,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restri
             const int yrow = (row_ok ? iy : 0) * g.W * ld_bnb + c;
             int off_y = ix0 * ld_bnb;
 #pragma unroll
-            for (int bb = 0; bb < 32; ++bb) {
+            for (int bb = 0; bb < NP; ++bb) {
                 const int ix = ix0 + bb;
                 const bool ok = row_ok && bb < nvalid && ix >= 0 && ix < g.W;
                 float v = 0.f;
@@ -575,78 +592,83 @@ __global__ __launch_bounds__(512, 2) void fft2d_fwd_kernel(const float* __restri
                 off_y += ld_bnb; GDN_KEEP(off_y);
             }
         }
-        fft32<-1>(re, im);
+        fftn<NP, -1>(re, im);
 #pragma unroll
-        for (int kx = 0; kx < FFT_NK; ++kx) lds[(a * FFT_NK + kx) * FFT_CG + c] = make_float2(re[kx], im[kx]);
+        for (int kx = 0; kx < NK; ++kx) lds[(a * NK + kx) * FFT_CG + c] = make_float2(re[kx], im[kx]);
     }
     __syncthreads();
-    if (tid < FFT_NK * FFT_CG) {
+    if (tid < NK * FFT_CG) {
         const int kx = tid >> 4;
 #pragma unroll
-        for (int a = 0; a < 32; ++a) { const float2 v = lds[(a * FFT_NK + kx) * FFT_CG + c]; re[a] = v.x; im[a] = v.y; }
-        fft32<-1>(re, im);
+        for (int a = 0; a < NP; ++a) { const float2 v = lds[(a * NK + kx) * FFT_CG + c]; re[a] = v.x; im[a] = v.y; }
+        fftn<NP, -1>(re, im);
         float2* dst = Xf + ((size_t)kx * g.M + t) * g.C + cg + c;
-        const size_t sk = (size_t)FFT_NK * g.M * g.C;
+        const size_t sk = (size_t)NK * g.M * g.C;
 #pragma unroll
-        for (int ky = 0; ky < 32; ++ky) { *dst = make_float2(re[ky], im[ky]); dst += sk; GDN_KEEP(dst); }
+        for (int ky = 0; ky < NP; ++ky) { *dst = make_float2(re[ky], im[ky]); dst += sk; GDN_KEEP(dst); }
     }
 }
 
 // inverse, first half shared by both consumers: Yf[bin][tile][C] -> lds[u][kx][c] (inverse along ky)
+template <int NP>
 __device__ __forceinline__ void ifft2d_cols_to_lds(const float2* __restrict__ Yf, float2* lds, int C, int M, int t, int cg,
-                                                   float (&re)[32], float (&im)[32]) {
+                                                   float (&re)[NP], float (&im)[NP]) {
+    constexpr int NK = FFT_NK_OF(NP);
     const int tid = threadIdx.x, c = tid & 15;
-    if (tid < FFT_NK * FFT_CG) {
+    if (tid < NK * FFT_CG) {
         const int kx = tid >> 4;
         const float2* src = Yf + ((size_t)kx * M + t) * C + cg + c;
-        const size_t sk = (size_t)FFT_NK * M * C;
+        const size_t sk = (size_t)NK * M * C;
 #pragma unroll
-        for (int ky = 0; ky < 32; ++ky) {
+        for (int ky = 0; ky < NP; ++ky) {
             const float2 v = *src;
             re[ky] = v.x; im[ky] = v.y;
             src += sk; GDN_KEEP(src);
         }
-        fft32<1>(re, im);
+        fftn<NP, 1>(re, im);
 #pragma unroll
-        for (int u = 0; u < 32; ++u) lds[(u * FFT_NK + kx) * FFT_CG + c] = make_float2(re[u], im[u]);
+        for (int u = 0; u < NP; ++u) lds[(u * NK + kx) * FFT_CG + c] = make_float2(re[u], im[u]);
     }
     __syncthreads();
 }
 
-__device__ __forceinline__ void ifft_row_from_lds(const float2* lds, int u, int c, float (&re)[32], float (&im)[32]) {
+template <int NP>
+__device__ __forceinline__ void ifft_row_from_lds(const float2* lds, int u, int c, float (&re)[NP], float (&im)[NP]) {
+    constexpr int NK = FFT_NK_OF(NP);
 #pragma unroll
-    for (int kx = 0; kx < FFT_NK; ++kx) { const float2 v = lds[(u * FFT_NK + kx) * FFT_CG + c]; re[kx] = v.x; im[kx] = v.y; }
+    for (int kx = 0; kx < NK; ++kx) { const float2 v = lds[(u * NK + kx) * FFT_CG + c]; re[kx] = v.x; im[kx] = v.y; }
 #pragma unroll
-    for (int kx = FFT_NK; kx < 32; ++kx) { re[kx] = re[32 - kx]; im[kx] = -im[32 - kx]; }
-    fft32<1>(re, im);
+    for (int kx = NK; kx < NP; ++kx) { re[kx] = re[NP - kx]; im[kx] = -im[NP - kx]; }
+    fftn<NP, 1>(re, im);
 }
 
 // forward convolution output: valid T x T outputs of the tile, epilogue, BatchNorm partials (stats slot = tile)
-__global__ __launch_bounds__(512, 4) void ifft2d_valid_kernel(const float2* __restrict__ Yf, float* __restrict__ y, int ldy,
+template <int NP>
+__global__ __launch_bounds__(NP * FFT_CG, NP == 32 ? 4 : 8) void ifft2d_valid_kernel(const float2* __restrict__ Yf, float* __restrict__ y, int ldy,
                                                            const float* __restrict__ addsrc, int ld_add,
                                                            float* __restrict__ stats, const float* __restrict__ ep_scale,
                                                            const float* __restrict__ ep_shift, int act, FftGeom g) {
-    __shared__ float2 lds[FFT_LDS_ELEMS];
+    __shared__ float2 lds[FFT_LDS_ELEMS_OF(NP)];
     const int ngrp = g.N / FFT_CG, tpx = (g.M + 7) / 8;          // XCD-aware order as in fft2d_fwd_kernel
     const int tid = threadIdx.x, c = tid & 15, cg = ((blockIdx.x >> 3) % ngrp) * FFT_CG, T = g.T;
     const int t = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3) / ngrp;
     if (t >= g.M) return;
     const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
-    float re[32], im[32];
-    ifft2d_cols_to_lds(Yf, lds, g.N, g.M, t, cg, re, im);
+    float re[NP], im[NP];
+    ifft2d_cols_to_lds<NP>(Yf, lds, g.N, g.M, t, cg, re, im);
     const int u = tid >> 4, oy = ty * T + u;
     float s1 = 0.f, s2 = 0.f;
     if (u < T && oy < g.H) {
-        ifft_row_from_lds(lds, u, c, re, im);
+        ifft_row_from_lds<NP>(lds, u, c, re, im);
         const int ox0 = tx * T;
         float* dst = y + ((size_t)(b * g.H + oy) * g.W + ox0) * ldy + cg + c;
         const float* ad = addsrc ? addsrc + ((size_t)(b * g.H + oy) * g.W + ox0) * ld_add + cg + c : nullptr;
         if (!ep_scale && act == 0 && !ad) {
             // training forward (raw conv output + BatchNorm partials): nothing but the scale, the sums and the store
 #pragma unroll
-            for (int v = 0; v < 32; ++v) {
+            for (int v = 0; v < NP; ++v) {
                 if (v < T && ox0 + v < g.W) {
-                    const float val = re[v] * (1.0f / 1024.0f);
+                    const float val = re[v] * (1.0f / (NP * NP));
                     s1 += val; s2 += val * val;
                     *dst = val;
                 }
@@ -657,9 +679,9 @@ __global__ __launch_bounds__(512, 4) void ifft2d_valid_kernel(const float2* __re
             const float es = ep_scale[cg + c], et = ep_shift[cg + c];
             const float lo = (act & GDN_ACT_RELU) ? 0.f : -3.402823466e38f;
 #pragma unroll
-            for (int v = 0; v < 32; ++v) {
+            for (int v = 0; v < NP; ++v) {
                 if (v < T && ox0 + v < g.W) {
-                    const float raw = re[v] * (1.0f / 1024.0f);
+                    const float raw = re[v] * (1.0f / (NP * NP));
                     s1 += raw; s2 += raw * raw;
                     float val = fmaxf(raw * es + et, lo);
                     if (ad) val += *ad;
@@ -671,9 +693,9 @@ __global__ __launch_bounds__(512, 4) void ifft2d_valid_kernel(const float2* __re
         } else {
             const float es = ep_scale ? ep_scale[cg + c] : 1.f, et = ep_shift ? ep_shift[cg + c] : 0.f;
 #pragma unroll
-            for (int v = 0; v < 32; ++v) {
+            for (int v = 0; v < NP; ++v) {
                 if (v < T && ox0 + v < g.W) {
-                    float val = re[v] * (1.0f / 1024.0f);
+                    float val = re[v] * (1.0f / (NP * NP));
                     s1 += val; s2 += val * val;
                     if (ep_scale) val = val * es + et;
                     if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
@@ -693,7 +715,7 @@ __global__ __launch_bounds__(512, 4) void ifft2d_valid_kernel(const float2* __re
         __syncthreads();
         if (tid < FFT_CG) {
             float a1 = 0.f, a2 = 0.f;
-            for (int j = 0; j < 32; ++j) { a1 += red[(j * FFT_CG + tid) * 2]; a2 += red[(j * FFT_CG + tid) * 2 + 1]; }
+            for (int j = 0; j < NP; ++j) { a1 += red[(j * FFT_CG + tid) * 2]; a2 += red[(j * FFT_CG + tid) * 2 + 1]; }
             stats[((size_t)t * 2 + 0) * g.N + cg + tid] = a1;
             stats[((size_t)t * 2 + 1) * g.N + cg + tid] = a2;
         }
@@ -706,7 +728,11 @@ bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
     if (g->pad_mode == 1 && (g->pad >= g->H || g->pad >= g->W)) return false;
     if ((g->Cin % 64) || (g->Cout % 64) || g->Cin > 256 || g->Cout > 256) return false;
     f.B = g->B; f.H = g->H; f.W = g->W; f.C = g->Cin; f.N = g->Cout; f.k = g->k; f.pad = g->pad;
-    f.T = FFT_N - g->k + 1;
+    // 16-point tiles for small windows on wide layers (5x5 on 256 channels: the weight spectrum is 4x smaller, the 32 x 104
+    // level tiles without waste, the per-bin GEMMs have M = 540 rows instead of 160: measured -31 % on the forward GEMM)
+    f.np = (g->k <= 5 && (g->Cin >= 256 || g->Cout >= 256)) ? 16 : 32;
+    f.bins = FFT_BINS_OF(f.np);
+    f.T = f.np - g->k + 1;
     f.tiles_y = cdiv(g->H, f.T); f.tiles_x = cdiv(g->W, f.T);
     f.M = g->B * f.tiles_y * f.tiles_x;
     f.reflect = g->pad_mode == 1;
@@ -718,7 +744,7 @@ inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 // splits of the weight-gradient reduction: enough workgroups for ~4 per CU, chunks of at least 64 tiles
 inline int tn_splits(const FftGeom& f) {
-    const int wgs = (f.N / 64) * (f.C / 64) * FFT_BINS;
+    const int wgs = (f.N / 64) * (f.C / 64) * f.bins;
     int s = (4096 + wgs - 1) / wgs;
     if (s > 4) s = 4;
     while (s > 1 && f.M / s < 64) --s;
@@ -726,7 +752,7 @@ inline int tn_splits(const FftGeom& f) {
 }
 // weight-spectrum / weight-gradient-product region of the backward workspace
 inline size_t wf_region_bytes(const FftGeom& f) {
-    const size_t planes = (size_t)FFT_BINS * 3 * f.C * f.N * 4, prod = (size_t)tn_splits(f) * FFT_BINS * 2 * f.C * f.N * 4;
+    const size_t planes = (size_t)f.bins * 3 * f.C * f.N * 4, prod = (size_t)tn_splits(f) * f.bins * 2 * f.C * f.N * 4;
     return al256(planes > prod ? planes : prod);
 }
 
@@ -736,8 +762,8 @@ inline size_t wf_region_bytes(const FftGeom& f) {
 extern "C" size_t gdn_fftconv_fwd_workspace_bytes(const gdn_conv_geom* g) {
     FftGeom f;
     if (!fft_geom(g, f)) return 0;
-    return al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)f.M * FFT_BINS * f.N * 8) +
-           al256((size_t)FFT_BINS * 3 * f.C * f.N * 4);
+    return al256((size_t)f.M * f.bins * f.C * 8) + al256((size_t)f.M * f.bins * f.N * 8) +
+           al256((size_t)f.bins * 3 * f.C * f.N * 4);
 }
 
 extern "C" int64_t gdn_fftconv_stats_slots(const gdn_conv_geom* g) {
@@ -750,18 +776,36 @@ extern "C" int64_t gdn_fftconv_stats_slots(const gdn_conv_geom* g) {
 extern "C" size_t gdn_fftconv_spectrum_bytes(const gdn_conv_geom* g) {
     FftGeom f;
     if (!fft_geom(g, f)) return 0;
-    return al256((size_t)f.M * FFT_BINS * f.C * 8) + al256((size_t)FFT_BINS * 3 * f.C * f.N * 4);
+    return al256((size_t)f.M * f.bins * f.C * 8) + al256((size_t)f.bins * 3 * f.C * f.N * 4);
 }
 
 namespace {
-void launch_weights(const FftGeom& f, const float* w, float* Wf, hipStream_t st) {
-    const dim3 gr(cdiv(f.N * f.C, 256), FFT_N);
+template <int NP>
+void launch_weights_np(const FftGeom& f, const float* w, float* Wf, hipStream_t st) {
+    const dim3 gr(cdiv(f.N * f.C, 256), NP);
     switch (f.k) {
-        case 3: hipLaunchKernelGGL(fft_weights_kernel<3>, gr, dim3(256), 0, st, w, Wf, f.N, f.C, f.flip); break;
-        case 5: hipLaunchKernelGGL(fft_weights_kernel<5>, gr, dim3(256), 0, st, w, Wf, f.N, f.C, f.flip); break;
-        case 7: hipLaunchKernelGGL(fft_weights_kernel<7>, gr, dim3(256), 0, st, w, Wf, f.N, f.C, f.flip); break;
-        default: hipLaunchKernelGGL(fft_weights_kernel<9>, gr, dim3(256), 0, st, w, Wf, f.N, f.C, f.flip); break;
+        case 3: hipLaunchKernelGGL((fft_weights_kernel<3, NP>), gr, dim3(256), 0, st, w, Wf, f.N, f.C, f.flip); break;
+        case 5: hipLaunchKernelGGL((fft_weights_kernel<5, NP>), gr, dim3(256), 0, st, w, Wf, f.N, f.C, f.flip); break;
+        case 7: hipLaunchKernelGGL((fft_weights_kernel<7, NP>), gr, dim3(256), 0, st, w, Wf, f.N, f.C, f.flip); break;
+        default: hipLaunchKernelGGL((fft_weights_kernel<9, NP>), gr, dim3(256), 0, st, w, Wf, f.N, f.C, f.flip); break;
     }
+}
+void launch_weights(const FftGeom& f, const float* w, float* Wf, hipStream_t st) {
+    if (f.np == 16) launch_weights_np<16>(f, w, Wf, st);
+    else launch_weights_np<32>(f, w, Wf, st);
+}
+
+// the transform kernels, dispatched on the tile size
+void launch_fft2d_fwd(const FftGeom& f, int chans, const float* x, int ldx, float2* Xf, int halo, const float* in_scale,
+                      const float* in_shift, int in_relu, const float* bnb_y, int ld_bnb, const float* bnb_co, const float* bnb_kk,
+                      hipStream_t st) {
+    const dim3 gr(chans / FFT_CG * 8 * cdiv(f.M, 8));
+    if (f.np == 16)
+        hipLaunchKernelGGL(fft2d_fwd_kernel<16>, gr, dim3(16 * FFT_CG), 0, st, x, ldx, Xf, f, halo, in_scale, in_shift, in_relu, bnb_y,
+                           ld_bnb, bnb_co, bnb_kk);
+    else
+        hipLaunchKernelGGL(fft2d_fwd_kernel<32>, gr, dim3(32 * FFT_CG), 0, st, x, ldx, Xf, f, halo, in_scale, in_shift, in_relu, bnb_y,
+                           ld_bnb, bnb_co, bnb_kk);
 }
 }  // namespace
 
@@ -776,20 +820,24 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
     if (!workspace || workspace_bytes < gdn_fftconv_fwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* p = (char*)workspace;
-    float2* Xf = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.C * 8);
-    float2* Yf = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.N * 8);
+    float2* Xf = (float2*)p; p += al256((size_t)f.M * f.bins * f.C * 8);
+    float2* Yf = (float2*)p; p += al256((size_t)f.M * f.bins * f.N * 8);
     float* Wf = (float*)p;
     if (xf_out) {
         Xf = (float2*)xf_out;
-        Wf = (float*)((char*)xf_out + al256((size_t)f.M * FFT_BINS * f.C * 8));
+        Wf = (float*)((char*)xf_out + al256((size_t)f.M * f.bins * f.C * 8));
     }
-    hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.C / FFT_CG * 8 * cdiv(f.M, 8)), dim3(512), 0, st, x, ldx, Xf, f, 1, in_scale,
-                       in_shift, in_relu, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr);
+    launch_fft2d_fwd(f, f.C, x, ldx, Xf, 1, in_scale, in_shift, in_relu, nullptr, 0, nullptr, nullptr, st);
     launch_weights(f, w, Wf, st);
-    hipLaunchKernelGGL(cgemm_bins_kernel<false>, dim3(cdiv(f.M, 64) * (f.N / 64) * FFT_BINS), dim3(256), 0, st,
+    hipLaunchKernelGGL(cgemm_bins_kernel<false>, dim3(cdiv(f.M, 64) * (f.N / 64) * f.bins), dim3(256), 0, st,
                        (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, f.N, f.C);
-    hipLaunchKernelGGL(ifft2d_valid_kernel, dim3(f.N / FFT_CG * 8 * cdiv(f.M, 8)), dim3(512), 0, st, (const float2*)Yf, y, ldy, addsrc,
-                       ld_add, stats, ep_scale, ep_shift, act, f);
+    const dim3 gv(f.N / FFT_CG * 8 * cdiv(f.M, 8));
+    if (f.np == 16)
+        hipLaunchKernelGGL(ifft2d_valid_kernel<16>, gv, dim3(16 * FFT_CG), 0, st, (const float2*)Yf, y, ldy, addsrc, ld_add, stats,
+                           ep_scale, ep_shift, act, f);
+    else
+        hipLaunchKernelGGL(ifft2d_valid_kernel<32>, gv, dim3(32 * FFT_CG), 0, st, (const float2*)Yf, y, ldy, addsrc, ld_add, stats,
+                           ep_scale, ep_shift, act, f);
     return gdn_launch_status();
 }
 
@@ -800,8 +848,8 @@ extern "C" size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     if (f.flip) return 0;                  // stride-1 ConvTranspose2d: forward (inference) only
     const size_t cm = f.C > f.N ? f.C : f.N;
     const size_t padded = f.reflect ? al256((size_t)f.B * (f.H + 2 * f.pad) * (f.W + 2 * f.pad) * f.C * 4) : 0;
-    return al256((size_t)f.M * FFT_N * FFT_NK * cm * 8) + al256((size_t)f.M * FFT_BINS * f.N * 8) +
-           al256((size_t)f.M * FFT_BINS * f.C * 8) + wf_region_bytes(f) + padded;
+    return al256((size_t)f.M * f.bins * cm * 8) + al256((size_t)f.M * f.bins * f.N * 8) +
+           al256((size_t)f.M * f.bins * f.C * 8) + wf_region_bytes(f) + padded;
 }
 
 extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w, const void* xf,
@@ -820,9 +868,9 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     hipStream_t st = (hipStream_t)stream;
     const size_t cm = f.C > f.N ? f.C : f.N;
     char* p = (char*)workspace;
-    float2* R = (float2*)p; p += al256((size_t)f.M * FFT_N * FFT_NK * cm * 8);
-    float2* Df = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.N * 8);
-    float2* Ef = (float2*)p; p += al256((size_t)f.M * FFT_BINS * f.C * 8);
+    float2* R = (float2*)p; p += al256((size_t)f.M * f.bins * cm * 8);
+    float2* Df = (float2*)p; p += al256((size_t)f.M * f.bins * f.N * 8);
+    float2* Ef = (float2*)p; p += al256((size_t)f.M * f.bins * f.C * 8);
     float* Wf = (float*)p; p += wf_region_bytes(f);   // weight-gradient products P (per split), or the weight spectrum when the forward saved none
     float* dxp = (float*)p;          // reflection layers: gradient over the padded domain
     auto blocks = [](int64_t n) { const int64_t b = cdiv64(n, 256); return (unsigned)(b < 65536 * 8 ? b : 65536 * 8); };
@@ -831,8 +879,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         FftGeom fd = f;
         fd.C = f.N;
         fd.reflect = 0;
-        hipLaunchKernelGGL(fft2d_fwd_kernel, dim3(f.N / FFT_CG * 8 * cdiv(f.M, 8)), dim3(512), 0, st, dy, ldy, Df, fd, 0,
-                           (const float*)nullptr, (const float*)nullptr, dyb_relu, dyb_y, ld_dyb, dyb_co, dyb_kk);
+        launch_fft2d_fwd(fd, f.N, dy, ldy, Df, 0, nullptr, nullptr, dyb_relu, dyb_y, ld_dyb, dyb_co, dyb_kk, st);
     }
     // The weight-gradient chain (reduction GEMM + tap transform) and the data-gradient chain only share Df and use disjoint
     // parts of the workspace, so a caller may run them as separate calls on two streams of its own (phases; the library
@@ -840,14 +887,15 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     if (dw && (phases & GDN_FFT_BWD_DW)) {
         float* P = Wf;
         const int ns = tn_splits(f);
-        hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * FFT_BINS * ns), dim3(256), 0, st,
-                           (const float*)Df, (const float*)xf, P, f.M, f.N, f.C, ns);
+        hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * f.bins * ns), dim3(256), 0, st,
+                           (const float*)Df, (const float*)xf, P, f.M, f.N, f.C, ns, f.bins);
         if (ns > 1) {
-            const int64_t n4 = (int64_t)FFT_BINS * f.N * f.C * 2 / 4;
+            const int64_t n4 = (int64_t)f.bins * f.N * f.C * 2 / 4;
             hipLaunchKernelGGL(fft_sum_splits_kernel, dim3(blocks(n4)), dim3(256), 0, st, P, n4, ns);
         }
 #define GDN_TAPS(KK) case KK: \
-            hipLaunchKernelGGL(fft_wgrad_taps_kernel<KK>, dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
+            if (f.np == 16) hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 16>), dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
+            else hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 32>), dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
             break;
         switch (f.k) {
             GDN_TAPS(3) GDN_TAPS(5) GDN_TAPS(7) GDN_TAPS(9)
@@ -855,26 +903,33 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
 #undef GDN_TAPS
     }
     if (dx && (phases & GDN_FFT_BWD_DX)) {
-        const float* Wsaved = xf ? (const float*)((const char*)xf + al256((size_t)f.M * FFT_BINS * f.C * 8)) : nullptr;
+        const float* Wsaved = xf ? (const float*)((const char*)xf + al256((size_t)f.M * f.bins * f.C * 8)) : nullptr;
         if (!Wsaved) launch_weights(f, w, Wf, st);
-        hipLaunchKernelGGL(cgemm_bins_kernel<true>, dim3(cdiv(f.M, 64) * (f.C / 64) * FFT_BINS), dim3(256), 0, st,
+        hipLaunchKernelGGL(cgemm_bins_kernel<true>, dim3(cdiv(f.M, 64) * (f.C / 64) * f.bins), dim3(256), 0, st,
                            (const float*)Df, Wsaved ? Wsaved : (const float*)Wf, (float*)Ef, f.M, f.C, f.N);
         // inverse along ky into S, then rows: the tile rows that reach an image row are summed in the frequency domain
         int cq_shift = 0;
         while ((64 << cq_shift) < f.C) ++cq_shift;           // C / 64 is 1, 2 or 4
-        hipLaunchKernelGGL(ifft_cols_kernel, dim3(cdiv(f.M, 4) << cq_shift, FFT_NK), dim3(256), 0, st, (const float2*)Ef, R, f.C, f.M,
-                           FFT_N, cq_shift);
+        if (f.np == 16)
+            hipLaunchKernelGGL(ifft_cols_kernel<16>, dim3(cdiv(f.M, 4) << cq_shift, FFT_NK_OF(16)), dim3(256), 0, st, (const float2*)Ef, R,
+                               f.C, f.M, 16, cq_shift);
+        else
+            hipLaunchKernelGGL(ifft_cols_kernel<32>, dim3(cdiv(f.M, 4) << cq_shift, FFT_NK_OF(32)), dim3(256), 0, st, (const float2*)Ef, R,
+                               f.C, f.M, 32, cq_shift);
         const int Ho = f.reflect ? f.H + 2 * f.pad : f.H, Wo = f.reflect ? f.W + 2 * f.pad : f.W;
         for (int parity = 0; parity < 2; ++parity) {
             const int ntx = (f.tiles_x + 1 - parity) / 2;
             if (ntx == 0) continue;
             const dim3 gr(cdiv(ntx, 4) << cq_shift, Ho, f.B);
-            if (f.reflect)
-                hipLaunchKernelGGL(ifft_rows_overlap_kernel, gr, dim3(256), 0, st,
-                                   (const float2*)R, dxp, f.C, (const float*)nullptr, 0, f, parity, Ho, Wo, 0, cq_shift);
+            float* o = f.reflect ? dxp : dx;
+            const int ldo = f.reflect ? f.C : ldx, off = f.reflect ? 0 : f.pad;
+            const float* ad = f.reflect ? (const float*)nullptr : addsrc;
+            if (f.np == 16)
+                hipLaunchKernelGGL(ifft_rows_overlap_kernel<16>, gr, dim3(256), 0, st, (const float2*)R, o, ldo, ad, ld_add, f, parity, Ho,
+                                   Wo, off, cq_shift);
             else
-                hipLaunchKernelGGL(ifft_rows_overlap_kernel, gr, dim3(256), 0, st,
-                                   (const float2*)R, dx, ldx, addsrc, ld_add, f, parity, Ho, Wo, f.pad, cq_shift);
+                hipLaunchKernelGGL(ifft_rows_overlap_kernel<32>, gr, dim3(256), 0, st, (const float2*)R, o, ldo, ad, ld_add, f, parity, Ho,
+                                   Wo, off, cq_shift);
         }
         if (f.reflect)
             hipLaunchKernelGGL(fft_reflect_fold_kernel, dim3(blocks((int64_t)f.B * f.H * f.W * (f.C / 4))), dim3(256), 0, st,
@@ -882,3 +937,4 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     }
     return gdn_launch_status();
 }
+

@@ -19,6 +19,11 @@ CASES = [
     (128, 64, 3, 2, 30, 31),
     (64, 64, 9, 1, 9, 12),           # image smaller than one tile
     (64, 64, 9, 1, 24, 48),          # exactly tile-aligned
+    # 16-point tiles (k <= 5 on >= 256 channels): T = 12 / 14
+    (256, 256, 5, 2, 13, 29),        # ragged edges
+    (256, 128, 5, 1, 12, 24),        # exactly tile-aligned, Cin != Cout
+    (64, 256, 5, 1, 7, 5),           # image smaller than one tile
+    (256, 256, 3, 1, 30, 17),        # 3x3 window (T = 14)
 ]
 
 

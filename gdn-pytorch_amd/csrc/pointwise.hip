@@ -2,6 +2,7 @@
 // apply / backward, x2 bilinear up-sampling, layout transforms, fused Adam.
 // All are 16-byte-per-lane streaming kernels (NHWC, channel count % 4 == 0).
 #include "common.h"
+#include "up2x.h"
 
 namespace {
 
@@ -253,21 +254,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(
 }
 
 // ------------------------------------------------------------------- upsample
-__device__ __forceinline__ void up_src(int o, int in, int align, float& l1, int& i0, int& i1) {
-    float src;
-    if (align) {
-        const float sc = in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f;
-        src = sc * o;
-    } else {
-        src = 0.5f * (o + 0.5f) - 0.5f;
-        if (src < 0.f) src = 0.f;
-    }
-    i0 = (int)src;
-    if (i0 > in - 1) i0 = in - 1;
-    i1 = i0 + (i0 < in - 1 ? 1 : 0);
-    l1 = src - i0;
-}
-
 // grid.y = output row (b, oy), grid.x covers the Wo * C/4 quads of that row: no per-thread division
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                              int B, int H, int W, int C, int align, int dt, int sh) {

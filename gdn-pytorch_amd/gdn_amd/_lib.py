@@ -45,17 +45,17 @@ _SIGS = {
     "gdn_fftconv_fwd_workspace_bytes": (_sz, [_PG]),
     "gdn_fftconv_spectrum_bytes": (_sz, [_PG]),
     "gdn_fftconv_stats_slots": (_i64, [_PG]),
-    "gdn_fftconv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _P, _P, _i32, _P, _P, _sz, _P]),
+    "gdn_fftconv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _P, _P, _i32, _i32, _P, _P, _sz, _P]),
     "gdn_fftconv_bwd_workspace_bytes": (_sz, [_PG]),
-    "gdn_fftconv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _P, _i32, _P, _i32, _P, _P, _i32, _P, _P, _i32, _i32, _P, _sz, _P]),
+    "gdn_fftconv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _P, _i32, _P, _i32, _P, _P, _i32, _P, _P, _i32, _i32, _i32, _P, _sz, _P]),
     "gdn_winoconv_fwd_workspace_bytes": (_sz, [_PG]),
     "gdn_winoconv_state_bytes": (_sz, [_PG]),
     "gdn_winoconv_stats_slots": (_i64, [_PG]),
-    "gdn_winoconv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _P, _P, _i32, _P, _P, _sz, _P]),
+    "gdn_winoconv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _P, _P, _i32, _i32, _P, _P, _sz, _P]),
     "gdn_winoconv_bwd_workspace_bytes": (_sz, [_PG]),
     "gdn_winoconv_bnb_slots": (_i64, [_PG]),
     "gdn_winoconv_gemm": (c_int32, [_PG, _P, _P, _P, _P]),
-    "gdn_winoconv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _P, _i32, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _sz, _P]),
+    "gdn_winoconv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _P, _i32, _P, _i32, _P, _P, _i32, _P, _i32, _P, _i32, _P, _sz, _P]),
     "gdn_wino2conv_fwd_workspace_bytes": (_sz, [_PG]),
     "gdn_wino2conv_state_bytes": (_sz, [_PG]),
     "gdn_wino2conv_stats_slots": (_i64, [_PG]),

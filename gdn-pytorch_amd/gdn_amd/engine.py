@@ -32,6 +32,9 @@ _FUSE = {k: os.environ.get("GDN_FUSE_" + k.upper(), d) != "0" for k, d in
 _WINO2_MIN_C = int(os.environ.get("GDN_WINO2_MIN_C", "64"))
 # fp32 1 <-> 64 channel 9x9 layers (G's first convolution, the heads' backward) on csrc/conv_c1.hip (A/B switch)
 _C1 = os.environ.get("GDN_C1", "1") != "0"
+# x2 bilinear upsampling folded into the consumer convolution's loader and its backward's fold pass (north_star "bilinear-interp
+# ... fused"; csrc/up2x.h): A/B switch
+_FUSE_UP2X = os.environ.get("GDN_FUSE_UP2X", "1") != "0"
 _GRAPH_EPOCH = 0
 
 
@@ -300,6 +303,31 @@ class BnOut:
         return self._dense
 
 
+class Up2x:
+    """Deferred x2 bilinear upsampling of `src` (F.interpolate(scale_factor=2, mode='bilinear'), AE_model_unet.py:336-359):
+    the one consumer -- a ConvBlock -- interpolates while its transform kernel gathers the patches and its backward's fold
+    pass applies the adjoint, so the upsampled tensor (4x src) and its gradient are never written.  A consumer whose path
+    has no such loader calls dense(ctx): the stand-alone kernels, with their tape entry."""
+
+    def __init__(self, src, align_corners):
+        self.src, self.align = src, bool(align_corners)
+        B, H, W, C = src.shape
+        self.shape, self.dtype = torch.Size((B, 2 * H, 2 * W, C)), src.dtype
+        self.mode = 2 if align_corners else 1          # in_up2x / dx_up2x of the C ABI
+
+    def dense(self, ctx):
+        x, align = self.src, self.align
+        y = ops.upsample2x(x, align)
+        if ctx.record:
+            def bwd():
+                dy = ctx.pop_grad(y)
+                if dy is None:
+                    return
+                ctx.add_grad(x, ops.upsample2x_bwd(_dense(dy), align))
+            ctx.tape.append(bwd)
+        return y
+
+
 def _conv_op(mod, reflect):
     op = getattr(mod, "_gdn_op", None)
     if op is None:
@@ -372,6 +400,19 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     fp32 one without a residual."""
     op = _conv_op(conv, reflect)
     ldt = _layer_dtype(ctx, conv)
+    up = None
+    if isinstance(x, Up2x):
+        # deferred x2 upsampling: the frequency-domain / Winograd F(2x2,3x3) loaders interpolate on the fly; training needs
+        # the fold pass of a reflection-padded layer for the adjoint.  Everything else gets the materialised tensor.
+        k, s_ = conv.kernel_size[0], conv.stride[0]
+        B_, H_, W_ = x.shape[0], x.shape[1], x.shape[2]
+        fusable = (ldt == torch.float32 and x2 is None and s_ == 1 and (not ctx.record or reflect)
+                   and ((_FFT_MIN_K > 0 and k >= _FFT_MIN_K and op.fft_ok(B_, H_, W_, backward=ctx.record))
+                        or (_WINOGRAD and k == 3 and op.wino_ok(B_, H_, W_))))
+        if fusable:
+            up = x
+        else:
+            x = x.dense(ctx)
     xin = ctx.claim(x)                   # BnOut of the train-mode BatchNorm that produced x, if we are its first consumer
     lazy = isinstance(x, BnOut)
     if x2 is not None:
@@ -399,6 +440,11 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     use_fft = use_fft or use_wino or use_wino2
     in_kw = {}
     xt = x                               # the tensor the conv kernels read
+    if up is not None:
+        if not (use_fft and not use_wino2):
+            raise GdnError("internal: deferred upsampling reached a layer without a fused loader")
+        in_kw = dict(up2x=up.mode)
+        xt = up.src
     if lazy:
         if use_fft and not use_wino2 and _FUSE_TRAIN_BN and _FUSE["fft_in" if use_fft_only else "wino_in"]:
             in_kw = dict(in_affine=(x.co[0], x.co[1]), in_relu=x.relu)
@@ -500,10 +546,14 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                     extra = {"dyb": dyb} if dyb is not None else {}
                     if bnb is not None:
                         extra["bnb"] = bnb
+                    gx = x                                  # the tensor whose gradient this layer's dx is
+                    if up is not None:
+                        extra["up2x"] = up.mode             # ... the low-resolution source of the deferred upsampling
+                        gx = up.src
                     dx = alt_bwd(dy, w, in_hw, dw_tap=gv, need_dx=want_dx, **{bstate_kw: xf},
-                                 addsrc=ctx.pop_grad_as(x, ldt) if want_dx else None, **extra)
+                                 addsrc=ctx.pop_grad_as(gx, ldt) if want_dx else None, **extra)
                     if want_dx:
-                        ctx.grads[id(x)] = (x, dx)
+                        ctx.grads[id(gx)] = (gx, dx)
                         if bnb is not None:
                             xin.partial = bnb[3]
                 if not frozen:
@@ -576,16 +626,14 @@ def conv_plain(ctx, x, conv, x2=None):
 
 
 def upsample(ctx, x, align_corners=False):
+    """F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=...).  fp32: returned DEFERRED (Up2x) -- the consumer
+    ConvBlock's loader interpolates; see conv_bn_act."""
     ctx.claim(x)
-    y = ops.upsample2x(x, align_corners)
-    if ctx.record:
-        def bwd():
-            dy = ctx.pop_grad(y)
-            if dy is None:
-                return
-            ctx.add_grad(x, ops.upsample2x_bwd(_dense(dy), align_corners))
-        ctx.tape.append(bwd)
-    return y
+    if isinstance(x, BnOut):
+        x = x.dense(ctx.dtype)
+    if _FUSE_UP2X and ctx.dtype == torch.float32 and x.dtype == torch.float32 and x.is_contiguous():
+        return Up2x(x, align_corners)
+    return Up2x(x, align_corners).dense(ctx)
 
 
 # ----------------------------------------------------------------------------

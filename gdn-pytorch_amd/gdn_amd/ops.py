@@ -198,12 +198,15 @@ class Conv:
         return int(lib.gdn_fftconv_stats_slots(ref))
 
     def fft_fwd(self, x, w_tap, stats=False, addsrc=None, spectrum=False, out=None, stats_out=None, affine=None,
-                act=ACT_NONE, in_affine=None, in_relu=False):
+                act=ACT_NONE, in_affine=None, in_relu=False, up2x=0):
         """y = conv(x) (+ addsrc) through the frequency domain; returns y, then the BatchNorm partials when `stats`,
         then the input spectrum (opaque uint8 buffer for fft_bwd) when `spectrum`.
-        in_affine = (scale, shift): x is a raw conv output and the layer input is [relu](x*scale + shift), applied on load."""
+        in_affine = (scale, shift): x is a raw conv output and the layer input is [relu](x*scale + shift), applied on load.
+        up2x (1: align_corners False, 2: True): x is the low-resolution tensor, upsampled x2 (bilinear) on load."""
         _chk(x, "x"); _chk(w_tap, "w")
         B, H, W, C1 = x.shape
+        if up2x:
+            H, W = 2 * H, 2 * W
         _, ref, Ho, Wo = self.geom(B, H, W)
         nb = int(lib.gdn_fftconv_fwd_workspace_bytes(ref))
         if nb == 0 or C1 != self.cin:
@@ -218,7 +221,7 @@ class Conv:
         lib.gdn_fftconv_fwd(ref, _p(x), _ld(x), _p(w_tap), _p(y), _ld(y), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
                             _p(st), _p(affine[0]) if affine else None, _p(affine[1]) if affine else None, int(act),
                             _p(in_affine[0]) if in_affine else None, _p(in_affine[1]) if in_affine else None,
-                            1 if in_relu else 0, _p(xf), _p(ws), nb, stream())
+                            1 if in_relu else 0, int(up2x), _p(xf), _p(ws), nb, stream())
         res = (y,) + ((st,) if stats else ()) + ((xf,) if spectrum else ())
         return res if len(res) > 1 else y
 
@@ -226,12 +229,14 @@ class Conv:
         _, ref, _, _ = self.geom(B, H, W)
         return int(lib.gdn_winoconv_bnb_slots(ref))
 
-    def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None, dyb=None):
+    def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None, dyb=None, up2x=0):
         """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's saved state xf:
         input + weight spectra) from one transform of dy.  w_tap is the FORWARD tap-major weight [k*k, Cout, Cin]; it is
         only read when xf is None.
         dyb = (y_raw, coeffs[4,Cout], kk[2,Cout], relu): `dy` is dout of THIS layer's train-mode BatchNorm; the dy transform
-        applies scale*(dz - k1 - xhat*k2) while loading (kk from bn_bwd_coeffs)."""
+        applies scale*(dz - k1 - xhat*k2) while loading (kk from bn_bwd_coeffs).
+        up2x: the forward upsampled a low-resolution x on load; dx (and addsrc) are that tensor's gradient [B,H/2,W/2,Cin]
+        (in_hw stays the convolution's input extent)."""
         _chk(dy, "dy")
         B = dy.shape[0]
         H, W = in_hw
@@ -241,7 +246,8 @@ class Conv:
             raise GdnError("fftconv: unsupported layer k=%d stride=%d" % (self.k, self.stride))
         if tuple(dy.shape[1:]) != (Ho, Wo, self.cout):
             raise GdnError("fft_bwd: dy shape %s does not match layer output" % (tuple(dy.shape),))
-        dx = torch.empty((B, H, W, self.cin), dtype=torch.float32, device=dy.device) if need_dx else None
+        dx = torch.empty((B, H // 2, W // 2, self.cin) if up2x else (B, H, W, self.cin), dtype=torch.float32,
+                         device=dy.device) if need_dx else None
         ws = workspace(nb, dy.device, "fft")
         yy, yco, ykk, yrelu = dyb if dyb is not None else (None, None, None, False)
 
@@ -249,7 +255,7 @@ class Conv:
             lib.gdn_fftconv_bwd(ref, _p(dy), _ld(dy), _p(w_tap), _p(xf), _p(dx),
                                 0 if dx is None else _ld(dx), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
                                 _p(dw_tap), _p(yy), 0 if yy is None else _ld(yy), _p(yco), _p(ykk), 1 if yrelu else 0,
-                                phases, _p(ws), nb, st)
+                                int(up2x), phases, _p(ws), nb, st)
         if dw_tap is not None and need_dx and _FFT_OVERLAP:
             # the two chains only share the spectrum of dy and are each latency-bound: the weight-gradient chain runs on a
             # second stream of OURS next to the data-gradient chain (fork after the transform, join before returning)
@@ -270,11 +276,13 @@ class Conv:
         return int(lib.gdn_winoconv_state_bytes(ref)) > 0
 
     def wino_fwd(self, x, w_tap, stats=False, addsrc=None, state=False, affine=None, act=ACT_NONE, in_affine=None,
-                 in_relu=False):
+                 in_relu=False, up2x=0):
         """y = conv3x3(x) (+ epilogue) by Winograd F(2x2,3x3); returns y, then the BatchNorm partials when `stats`, then
-        the transformed input (opaque buffer for wino_bwd) when `state`."""
+        the transformed input (opaque buffer for wino_bwd) when `state`.  up2x: as for fft_fwd."""
         _chk(x, "x"); _chk(w_tap, "w")
         B, H, W, C1 = x.shape
+        if up2x:
+            H, W = 2 * H, 2 * W
         _, ref, Ho, Wo = self.geom(B, H, W)
         nb = int(lib.gdn_winoconv_fwd_workspace_bytes(ref))
         if nb == 0 or C1 != self.cin:
@@ -287,7 +295,7 @@ class Conv:
         lib.gdn_winoconv_fwd(ref, _p(x), _ld(x), _p(w_tap), _p(y), _ld(y), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
                              _p(st), _p(affine[0]) if affine else None, _p(affine[1]) if affine else None, int(act),
                              _p(in_affine[0]) if in_affine else None, _p(in_affine[1]) if in_affine else None,
-                             1 if in_relu else 0, _p(sv), _p(ws), nb, stream())
+                             1 if in_relu else 0, int(up2x), _p(sv), _p(ws), nb, stream())
         res = (y,) + ((st,) if stats else ()) + ((sv,) if state else ())
         return res if len(res) > 1 else y
 
@@ -296,7 +304,7 @@ class Conv:
         _, ref, _, _ = self.geom(B, H, W)
         lib.gdn_winoconv_gemm(ref, _p(V), _p(U), _p(Mo), stream())
 
-    def wino_bwd(self, dy, w_tap, in_hw, state=None, dw_tap=None, need_dx=True, addsrc=None, bnb=None):
+    def wino_bwd(self, dy, w_tap, in_hw, state=None, dw_tap=None, need_dx=True, addsrc=None, bnb=None, up2x=0):
         """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's `state`).
         w_tap is the FORWARD tap-major weight [9, Cout, Cin]."""
         _chk(dy, "dy")
@@ -308,12 +316,13 @@ class Conv:
             raise GdnError("winoconv: unsupported layer k=%d stride=%d" % (self.k, self.stride))
         if tuple(dy.shape[1:]) != (Ho, Wo, self.cout):
             raise GdnError("wino_bwd: dy shape %s does not match layer output" % (tuple(dy.shape),))
-        dx = torch.empty((B, H, W, self.cin), dtype=torch.float32, device=dy.device) if need_dx else None
+        dx = torch.empty((B, H // 2, W // 2, self.cin) if up2x else (B, H, W, self.cin), dtype=torch.float32,
+                         device=dy.device) if need_dx else None
         ws = workspace(nb, dy.device, "fft")
         by, bco, brelu, bpart = bnb if (bnb is not None and need_dx) else (None, None, False, None)
         lib.gdn_winoconv_bwd(ref, _p(dy), _ld(dy), _p(w_tap), _p(state), _p(dx), 0 if dx is None else _ld(dx), _p(addsrc),
                              0 if addsrc is None else _ld(addsrc), _p(dw_tap), _p(by), 0 if by is None else _ld(by), _p(bco),
-                             1 if brelu else 0, _p(bpart), _p(ws), nb, stream())
+                             1 if brelu else 0, _p(bpart), int(up2x), _p(ws), nb, stream())
         return dx
 
     # ---- Winograd F(3x3,2x2) path (csrc/conv_wino2.hip): 4x4 stride-2 pad-1 Conv2d / ConvTranspose2d, fp32, 64..512 channels ----

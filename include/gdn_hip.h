@@ -142,6 +142,12 @@ int gdn_conv_wgrad(const gdn_conv_geom* g, const void* x, int32_t ldx, int32_t C
  * convolution and the layer input is [relu](x*in_scale[c] + in_shift[c]) -- the producer's train-mode
  * BatchNorm (+ReLU) applied while the patch is loaded, so `a = relu(bn1(conv1 x))` of a ResidualBlock
  * (AE_model_unet.py:49-54) is never written to memory.  Padding stays zero.
+ * in_up2x (0 = off, 1 = align_corners False, 2 = True; not together with in_scale): x is the LOW-resolution
+ * tensor [B][H/2][W/2][Cin] and the layer input is its x2 bilinear upsampling (F.interpolate(scale_factor=2,
+ * mode='bilinear') + ConvBlock, AE_model_unet.py:336-359; the legacy decoder :214-230), interpolated from the four
+ * neighbours of every element while the patch is loaded -- border rule (zeros / reflection) first, on the upsampled
+ * coordinates -- so the upsampled tensor is never written to memory.  g->H, g->W stay the convolution's (upsampled, even)
+ * input extent.
  * xf_out (nullable, gdn_fftconv_spectrum_bytes) receives the input and weight spectra, which
  * gdn_fftconv_bwd reuses (weight gradient; data gradient without a second weight transform).
  * GDN_ERR_UNSUPPORTED for other geometries; transposed (stride-1) layers are forward-only
@@ -152,7 +158,7 @@ int64_t gdn_fftconv_stats_slots(const gdn_conv_geom* g);
 int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w,
                     float* y, int32_t ldy, const float* addsrc, int32_t ld_add, float* stats,
                     const float* ep_scale, const float* ep_shift, int32_t act,
-                    const float* in_scale, const float* in_shift, int32_t in_relu,
+                    const float* in_scale, const float* in_shift, int32_t in_relu, int32_t in_up2x,
                     void* xf_out, void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the same layer from one transform of dy: dx = dgrad (+ addsrc) when dx != NULL,
  * dw[tap][Cout][Cin] = wgrad when dw != NULL (needs xf, the state saved by the forward; with
@@ -165,13 +171,16 @@ int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const f
  * dyb_* (nullable; replaces pass 3 of gdn_bn_bwd for THIS layer's own BatchNorm): `dy` is dout, the
  * gradient of z = [relu](BN_train(dyb_y)) with dyb_y this layer's raw conv output, dyb_co = {scale, shift,
  * mean, invstd}[Cout] and dyb_kk = {k1, k2}[Cout] from gdn_bn_bwd_coeffs; the dy transform computes
- * dy = scale*(dz - k1 - xhat*k2) while loading, so dy itself is never written to memory. */
+ * dy = scale*(dz - k1 - xhat*k2) while loading, so dy itself is never written to memory.
+ * dx_up2x (as in_up2x of the forward; reflection-padded layers only, else GDN_ERR_UNSUPPORTED): dx, addsrc are
+ * [B][H/2][W/2][Cin], the gradient of the LOW-resolution tensor the forward upsampled on load -- the pass that folds the
+ * padded-domain gradient back onto the image also applies the adjoint of the interpolation (gather form, deterministic). */
 enum { GDN_FFT_BWD_TRANSFORM = 1, GDN_FFT_BWD_DW = 2, GDN_FFT_BWD_DX = 4, GDN_FFT_BWD_ALL = 7 };
 size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g);
 int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w,
                     const void* xf, float* dx, int32_t ldx, const float* addsrc, int32_t ld_add,
                     float* dw, const float* dyb_y, int32_t ld_dyb, const float* dyb_co,
-                    const float* dyb_kk, int32_t dyb_relu, int32_t phases,
+                    const float* dyb_kk, int32_t dyb_relu, int32_t dx_up2x, int32_t phases,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* Winograd F(2x2,3x3) convolution for the 3x3 stride-1 layers (zero or reflection padding 1) on
@@ -180,7 +189,8 @@ int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const 
  * multiplies than the direct kernel, transforms that only add and halve.  Same contract as
  * gdn_conv_fwd for y / addsrc / stats / ep_scale / ep_shift / act (slots: gdn_winoconv_stats_slots).
  * in_scale / in_shift / in_relu: as for gdn_fftconv_fwd (the producer's train-mode BatchNorm + ReLU
- * applied while the 4x4 patches are loaded).
+ * applied while the 4x4 patches are loaded).  in_up2x: as for gdn_fftconv_fwd (x2 bilinear upsampling of a
+ * low-resolution x while the 4x4 patches are loaded: R's upconv0 / upconv1).
  * state_out (nullable, gdn_winoconv_state_bytes) receives the transformed input, which
  * gdn_winoconv_bwd needs for the weight gradient, followed by the data gradient's transformed weights (written by the same
  * weight-transform launch: the backward of that step then runs no weight transform).  Cin/64 and Cout/64 must be powers of two. */
@@ -190,7 +200,7 @@ int64_t gdn_winoconv_stats_slots(const gdn_conv_geom* g);
 int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const float* w,
                      float* y, int32_t ldy, const float* addsrc, int32_t ld_add, float* stats,
                      const float* ep_scale, const float* ep_shift, int32_t act,
-                     const float* in_scale, const float* in_shift, int32_t in_relu,
+                     const float* in_scale, const float* in_shift, int32_t in_relu, int32_t in_up2x,
                      void* state_out, void* workspace, size_t workspace_bytes, void* stream);
 /* dx = dgrad (+ addsrc) when dx != NULL (needs state, or w when state is NULL), dw[tap][Cout][Cin] = wgrad when
  * dw != NULL (needs state).
@@ -199,7 +209,8 @@ int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const 
  * bnb_co = {scale, shift, mean, invstd}[Cin]; the output transform that writes dx (+ addsrc) also writes
  * bnb_partial[slot][2][Cin] = per-slot sum(dz), sum(dz*xhat), dz = dx*[z>0 if bnb_relu], slots =
  * gdn_winoconv_bnb_slots(g) (0: not available -- reflection-padded layers).  (The frequency-domain layers do
- * not offer this: their inverse transforms are VALU-bound and the fused sums measured slower than the reduce pass.) */
+ * not offer this: their inverse transforms are VALU-bound and the fused sums measured slower than the reduce pass.)
+ * dx_up2x: as for gdn_fftconv_bwd (reflection-padded layers: dx is the gradient of the low-resolution tensor). */
 size_t gdn_winoconv_bwd_workspace_bytes(const gdn_conv_geom* g);
 int64_t gdn_winoconv_bnb_slots(const gdn_conv_geom* g);
 /* Measurement hook: only the 16 per-bin MFMA GEMMs of one forward, V [16][tiles][Cin] x U [16][Cout][Cin]
@@ -208,7 +219,7 @@ int gdn_winoconv_gemm(const gdn_conv_geom* g, const float* V, const float* U, fl
 int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w,
                      const void* state, float* dx, int32_t ldx, const float* addsrc, int32_t ld_add,
                      float* dw, const float* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu,
-                     float* bnb_partial, void* workspace, size_t workspace_bytes, void* stream);
+                     float* bnb_partial, int32_t dx_up2x, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Winograd F(3x3,2x2) for the 4x4 stride-2 pad-1 layers of G (ConvBlock(k4,s2,p1) AE_model_unet.py:497-500 with
  * ReflectionPad2d(1) or zero padding; ConvTBlock = ConvTranspose2d(k4,s2,p1) :517-520), fp32: the layer is a 2x2

@@ -1,0 +1,137 @@
+"""GPU parity tests for the x2 bilinear upsampling folded into its consumer convolution (csrc/up2x.h): the arithmetic of
+R's decoder `upconv(F.interpolate(x, scale_factor=2, mode='bilinear'))` (AE_model_unet.py:336-359) -- interpolate,
+ReflectionPad2d(k//2), Conv2d -- and of the legacy decoder's align_corners=True + ConvTranspose2d (:214-230), against
+torch on the CPU.  Tolerance: 1e-3 relative (the fp32 bar); measured errors are ~1e-6.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_hip_kernels import close, nchw, nhwc, tapmajor
+
+pytestmark = pytest.mark.gpu
+
+# (Cin, Cout, k, B, Hlow, Wlow): the frequency-domain layers (k >= 5, 32- and 16-point tiles) and the Winograd F(2x2,3x3) ones
+CASES = [
+    (128, 64, 7, 2, 13, 21),
+    (256, 128, 5, 1, 16, 26),
+    (256, 256, 5, 1, 6, 9),          # 16-point tiles
+    (64, 64, 9, 1, 8, 8),
+    (512, 256, 3, 1, 8, 13),
+    (64, 128, 3, 2, 5, 3),
+]
+
+
+def _ref(x, w, k, reflect, align):
+    up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=align)
+    if reflect:
+        return F.conv2d(F.pad(up, (k // 2,) * 4, mode="reflect"), w)
+    return F.conv2d(up, w, None, 1, k // 2)
+
+
+@pytest.mark.parametrize("case", CASES, ids=["c%d_%d_k%d_%dx%dx%d" % c for c in CASES])
+def test_upsample_folded_into_reflect_conv(gpu, case):
+    from gdn_amd import ops
+    ci, co, k, B, Hl, Wl = case
+    H, W = 2 * Hl, 2 * Wl
+    g = torch.Generator().manual_seed(77 + k + Hl)
+    x = torch.randn(B, ci, Hl, Wl, generator=g)
+    w = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    gy = torch.randn(B, co, H, W, generator=g)
+    gres = torch.randn(B, ci, Hl, Wl, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = _ref(xr, wr, k, True, False)
+    y_ref.backward(gy)
+    op = ops.Conv(ci, co, k, 1, k // 2, reflect=True)
+    fwd, bwd, kw, bkw = ((op.wino_fwd, op.wino_bwd, "state", "state") if k == 3 else
+                         (op.fft_fwd, op.fft_bwd, "spectrum", "xf"))
+    xd, wd = nhwc(x).to(gpu), tapmajor(w, False).to(gpu)
+    y, st, state = fwd(xd, wd, stats=True, up2x=1, **{kw: True})
+    close(nchw(y), y_ref, what="fwd")
+    close(st[:, 0].sum(0), y_ref.detach().sum((0, 2, 3)), rtol=1e-3, atol_scale=1e-3, what="stats sum")
+    # the same layer on the materialised tensor (stand-alone kernel): same arithmetic, rounding-level difference
+    y_mat = fwd(ops.upsample2x(xd, False), wd)
+    close(y, y_mat, rtol=1e-5, what="fused vs materialised")
+    # backward: dx is the gradient of the LOW-resolution tensor (+ an incoming gradient), dw from the saved state
+    dw = torch.full_like(wd, 3.0)
+    dx = bwd(nhwc(gy).to(gpu), wd, (H, W), dw_tap=dw, addsrc=nhwc(gres).to(gpu), up2x=1, **{bkw: state})
+    assert tuple(dx.shape) == (B, Hl, Wl, ci)
+    close(nchw(dx), xr.grad + gres, what="dgrad through the upsampling")
+    close(dw, tapmajor(wr.grad, False), what="wgrad")
+    dx_only = bwd(nhwc(gy).to(gpu), wd, (H, W), up2x=1)
+    close(nchw(dx_only), xr.grad, what="dgrad only")
+
+
+@pytest.mark.parametrize("align", [False, True])
+@pytest.mark.parametrize("k", [3, 7])
+def test_upsample_folded_into_zero_padded_conv_forward(gpu, k, align):
+    """Inference (legacy decoder): zero padding, both align_corners conventions; eval-BN epilogue on top."""
+    from gdn_amd import ops
+    ci, co, B, Hl, Wl = 64, 128, 2, 9, 14
+    g = torch.Generator().manual_seed(5 + k)
+    x = torch.randn(B, ci, Hl, Wl, generator=g)
+    w = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    sc, sh = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g)
+    y_ref = torch.relu(_ref(x, w, k, False, align) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    op = ops.Conv(ci, co, k, 1, k // 2)
+    fwd = op.wino_fwd if k == 3 else op.fft_fwd
+    y = fwd(nhwc(x).to(gpu), tapmajor(w, False).to(gpu), affine=(sc.to(gpu), sh.to(gpu)), act=ops.ACT_RELU,
+            up2x=2 if align else 1)
+    close(nchw(y), y_ref, what="fwd")
+
+
+def test_upsample_fold_argument_checks(gpu):
+    from gdn_amd import ops
+    from gdn_amd._lib import GdnError
+    x = torch.randn(1, 8, 8, 64, device=gpu)
+    w = torch.randn(49, 64, 64, device=gpu)
+    sc = torch.ones(64, device=gpu)
+    with pytest.raises(GdnError):            # not together with a deferred BatchNorm
+        ops.Conv(64, 64, 7, 1, 3, reflect=True).fft_fwd(x, w, in_affine=(sc, sc), up2x=1)
+    with pytest.raises(GdnError):            # the adjoint rides the fold pass of a reflection layer only
+        ops.Conv(64, 64, 7, 1, 3).fft_bwd(torch.randn(1, 16, 16, 64, device=gpu), w, (16, 16), up2x=1)
+    with pytest.raises(GdnError):
+        ops.Conv(64, 64, 3, 1, 1).wino_bwd(torch.randn(1, 16, 16, 64, device=gpu), torch.randn(9, 64, 64, device=gpu),
+                                           (16, 16), up2x=1)
+
+
+def test_rtod_network_fused_equals_standalone_upsample(gpu, monkeypatch):
+    """R forward + backward: with the fusion on no stand-alone upsample kernel runs, the outputs agree to rounding, and the
+    parameter gradients differ from the stand-alone path's by no more than a 1e-6 relative perturbation of the upsampled
+    tensors does (a random-init R with batch 2 amplifies rounding noise in its train-mode BatchNorm backward ~1e3-fold:
+    tests/diag/up2x_diag.py; the strict per-kernel comparisons are the tests above)."""
+    import gdn_amd.engine as E
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import ops
+    calls = {"n": 0, "eps": 0.0}
+    real = ops.upsample2x
+    gen = torch.Generator(device=gpu).manual_seed(1)
+
+    def counted(x, align=False):
+        calls["n"] += 1
+        y = real(x, align)
+        if calls["eps"]:
+            y = y * (1 + calls["eps"] * torch.randn(y.shape, device=y.device, generator=gen))
+        return y
+    monkeypatch.setattr(ops, "upsample2x", counted)
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(3)).to(gpu)
+
+    def run(fused, eps):
+        monkeypatch.setattr(E, "_FUSE_UP2X", fused)
+        calls["n"], calls["eps"] = 0, eps
+        torch.manual_seed(0)
+        net = M.AutoEncoder_2(height=64, width=96).to(gpu).train()
+        feats = net(x, istrain=True)
+        (feats[-1].square().mean() + 1e-3 * feats[2].square().mean()).backward()
+        assert calls["n"] == (0 if fused else 4)
+        r = {n: p.grad.detach().double().clone() for n, p in net.named_parameters() if p.grad is not None}
+        return r, [f.detach().clone() for f in feats]
+    (g_ref, f_ref), (g_noise, _), (g_fused, f_fused) = run(False, 0.0), run(False, 1e-6), run(True, 0.0)
+    for i, (a, b) in enumerate(zip(f_fused, f_ref)):
+        close(a, b, rtol=1e-4, atol_scale=1e-5, what="feature %d fused vs stand-alone" % i)
+    assert g_ref.keys() == g_fused.keys() and len(g_ref) > 100
+    typical = sorted(float(v.norm()) for v in g_ref.values())[len(g_ref) // 2]
+    for n, b in g_ref.items():
+        den = float(b.norm()) + 5e-2 * typical
+        d_fused, d_noise = float((g_fused[n] - b).norm()) / den, float((g_noise[n] - b).norm()) / den
+        assert d_fused <= 5 * d_noise + 2e-5, "%s: fused %.2e vs 1e-6-noise yardstick %.2e" % (n, d_fused, d_noise)

@@ -324,13 +324,20 @@ def other_configs(dev, B, depth, rgb, sparse):
     steps each, so every number of DESIGN.md 5 is driver-run rather than a builder's claim.  N = 1, rank 0 only."""
     import gc
     out = {}
-    for key, mode, dtype in (("rtod_fp32", "RtoD", "fp32"), ("rtod_bf16", "RtoD", "bf16"), ("dtod_bf16", "DtoD", "bf16")):
+    for key, mode, dtype, fast in (("rtod_fp32", "RtoD", "fp32", False), ("rtod_bf16", "RtoD", "bf16", False),
+                                   ("dtod_bf16", "DtoD", "bf16", False),
+                                   # what `GDN_main.py --mode RtoD` runs by default: the guide's four features from ONE batched
+                                   # encoder-only pass (bit-identical to the reference's two full forwards, whose decoder output
+                                   # is discarded -- trainer.guide_latent_loss); the lines above run the guide like the reference
+                                   ("rtod_fp32_encoder_only_guide", "RtoD", "fp32", True),
+                                   ("rtod_bf16_encoder_only_guide", "RtoD", "bf16", True)):
         try:
             torch.manual_seed(0)
-            step, _ = make_train_step(mode, dtype, dev, (depth, rgb, sparse))
+            step, _ = make_train_step(mode, dtype, dev, (depth, rgb, sparse), fast_guide=fast)
             ms, _ = timed(step, 6, 3)
-            out[key] = {"workload": "%s training step, batch %d, 128x416, %s%s" % (
-                mode, B, dtype, ", BASELINE configs[2]" if key == "rtod_bf16" else ""),
+            out[key] = {"workload": "%s training step, batch %d, 128x416, %s%s%s" % (
+                mode, B, dtype, ", BASELINE configs[2]" if key == "rtod_bf16" else "",
+                ", guide features from one encoder-only pass (trainer default; same values)" if fast else ""),
                 "ms_per_step": round(ms, 3), "value": round(B / ms * 1e3, 2), "unit": "images/s", "steps": 6, "warmup": 3}
             del step
         except Exception as e:  # noqa: BLE001

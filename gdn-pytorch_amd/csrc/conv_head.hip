@@ -1,22 +1,24 @@
 // 1-channel output head: Conv2d(64->1, k9, p4) (AE_model_unet.py:300,130) and
 // ConvTranspose2d(64->1, k9, s1, p4) (:521) + tanh, for gfx950.
 //
-// With one output channel the MFMA has nothing to amortise (an N=1 GEMM wastes
-// 31/32 of a 32x32 tile), so this is a register-blocked VALU kernel: a workgroup
-// owns a 16x64 pixel tile, stages the (16+8)x(64+8) input patch in LDS four
-// channels at a time (one float4 per pixel, column-swizzled so that the 16-byte
-// reads of neighbouring threads are contiguous), and each thread produces 4
-// horizontally adjacent pixels: per filter row it reads 12 float4 from LDS and
-// issues 9 taps x 4 pixels x 4 channels = 144 FMAs.  Weights are wave-uniform
-// (scalar loads).  HBM traffic: the input once (272 MB at B=20) + 4 B per pixel out.
-// Mixed-precision path: x may hold bf16 (weights and the depth map stay fp32).
+// With one output channel the MFMA has nothing to amortise (an N=1 GEMM wastes 31/32 of a 32x32 tile), so this is a
+// register-blocked VALU kernel on gfx950's packed fp32 pipe: a workgroup owns a 32x64 pixel tile, stages the
+// (32+8)x(64+8) input patch in LDS four channels at a time (one float4 per pixel, column-swizzled so that the 16-byte
+// reads of neighbouring threads are contiguous), and each thread produces a 2x4 pixel block: every patch row it reads (12
+// float4) feeds the filter row of BOTH output rows that touch it (10 row reads for 2x4x81x4 MACs: 15 LDS reads per pixel and
+// channel group instead of 27), and the four channels of a tap are two v_pk_fma_f32 on an (even, odd) accumulator pair
+// instead of four v_fma.  Weights are wave-uniform (scalar loads).  HBM traffic: the input once (272 MB at B=20) + 4 B
+// per pixel out.  Mixed-precision path: x may hold bf16 (weights and the depth map stay fp32).
 #include "common.h"
 
 namespace {
 
-#define HD_TH 16
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define HD_TH 32
 #define HD_TW 64
 #define HD_PX 4
+#define HD_PY 2
 
 template <int K>
 __global__ __launch_bounds__(256) void conv_head_kernel(const void* __restrict__ x, int ldx, const float* __restrict__ w,
@@ -33,7 +35,11 @@ __global__ __launch_bounds__(256) void conv_head_kernel(const void* __restrict__
     const int y0 = tiy * HD_TH, x0 = tix * HD_TW;
     const size_t xb = (size_t)b * H * W * ldx;
 
-    float acc[HD_PX] = {0.f, 0.f, 0.f, 0.f};
+    v2f acc[HD_PY][HD_PX];
+#pragma unroll
+    for (int r = 0; r < HD_PY; ++r)
+#pragma unroll
+        for (int p = 0; p < HD_PX; ++p) acc[r][p] = v2f{0.f, 0.f};
     for (int c0 = 0; c0 < C; c0 += 4) {
         __syncthreads();
         for (int idx = tid; idx < PH * PW; idx += 256) {
@@ -46,33 +52,39 @@ __global__ __launch_bounds__(256) void conv_head_kernel(const void* __restrict__
         }
         __syncthreads();
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
+        for (int iy = 0; iy < K + HD_PY - 1; ++iy) {            // patch row 2 ty + iy feeds output row r with ky = iy - r
             f32x4 xv[HD_PX + K - 1];
-            const int rowb = (ty + ky) * 4;
+            const int rowb = (ty * HD_PY + iy) * 4;
 #pragma unroll
             for (int j = 0; j < HD_PX + K - 1; ++j) xv[j] = patch[(rowb + (j & 3)) * PWQ + tx + (j >> 2)];
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const int tap = flip ? (K - 1 - ky) * K + (K - 1 - kx) : ky * K + kx;
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)tap * C + c0);   // wave-uniform
+            for (int r = 0; r < HD_PY; ++r) {
+                const int ky = iy - r;
+                if (ky < 0 || ky >= K) continue;
 #pragma unroll
-                for (int p = 0; p < HD_PX; ++p) {
-                    const f32x4 a = xv[p + kx];
-                    acc[p] = fmaf(a[0], wv[0], acc[p]);
-                    acc[p] = fmaf(a[1], wv[1], acc[p]);
-                    acc[p] = fmaf(a[2], wv[2], acc[p]);
-                    acc[p] = fmaf(a[3], wv[3], acc[p]);
+                for (int kx = 0; kx < K; ++kx) {
+                    const int tap = flip ? (K - 1 - ky) * K + (K - 1 - kx) : ky * K + kx;
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)tap * C + c0);   // wave-uniform
+                    const v2f w01 = v2f{wv[0], wv[1]}, w23 = v2f{wv[2], wv[3]};
+#pragma unroll
+                    for (int p = 0; p < HD_PX; ++p) {
+                        const f32x4 a = xv[p + kx];
+                        acc[r][p] += v2f{a[0], a[1]} * w01;
+                        acc[r][p] += v2f{a[2], a[3]} * w23;
+                    }
                 }
             }
         }
     }
-    const int oy = y0 + ty;
-    if (oy < H) {
+#pragma unroll
+    for (int r = 0; r < HD_PY; ++r) {
+        const int oy = y0 + ty * HD_PY + r;
+        if (oy >= H) continue;
 #pragma unroll
         for (int p = 0; p < HD_PX; ++p) {
             const int ox = x0 + tx * HD_PX + p;
             if (ox < W) {
-                float v = acc[p];
+                float v = acc[r][p].x + acc[r][p].y;
                 if (act == GDN_ACT_TANH) v = tanhf(v);
                 y[((size_t)b * H + oy) * W + ox] = v;
             }

@@ -227,6 +227,9 @@ def infer_main(args):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    flush_c_stdio()
+    if world > 1:
+        torch.distributed.barrier()
     if rank == 0:
         ms = dt / args.steps * 1e3
         rec = {"metric": "inference images/sec at 256x832 batch=64 (legacy AutoEncoder forward)",
@@ -240,8 +243,9 @@ def infer_main(args):
                           "direct_conv_equiv_note": "throughput label: direct-convolution FLOPs / time (fp32 k>=5 layers run in "
                                                     "the frequency domain, 3x3 as Winograd); not a utilisation",
                           "out_checksum": round(float(o.double().abs().mean().item()), 6)}}
+        flush_c_stdio()
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
@@ -306,6 +310,17 @@ def make_train_step(mode, dtype, dev, batch, fast_guide=False, latent_grad=False
         return step_fn(depth, rgb, sparse)
 
     return step, graphed
+
+
+def flush_c_stdio():
+    """RCCL prints its version banner to C stdout, which is block-buffered when stdout is a pipe or a file and would
+    otherwise be flushed at exit -- AFTER the JSON line.  Flushing it here keeps the JSON line the last line of stdout."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
 
 
 def timed(step, steps, warmup):
@@ -447,6 +462,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    flush_c_stdio()                  # every rank: library banners out before rank 0 prints the result line
+    barrier()
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -508,8 +525,9 @@ def main():
             rec["other_configs"] = other_configs(dev, B, depth, rgb, sparse)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(B)
+        flush_c_stdio()
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -371,3 +371,25 @@ def test_bench_contract_two_ranks(gpu):
         assert k in rec, k
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["config"]["global_batch"] == 8 and "cpu_baseline" not in rec
+
+
+def test_bench_json_line_is_last_on_stdout_with_rccl(gpu):
+    """With RCCL initialised (a forced 1-rank group: the same code path as N > 1) the library prints its version banner to C
+    stdout, block-buffered when stdout is a pipe; bench.py flushes it before the result line, so the LAST line of stdout is
+    the JSON record the driver reads."""
+    import json
+    import os
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = dict(os.environ, GDN_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-roofline", "--no-cpu-baseline", "--no-other-configs"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    rec = json.loads(lines[-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0
+    assert sum(ln.startswith("{") for ln in lines) == 1

@@ -1,5 +1,4 @@
 """Depth metrics on the HIP path (drop-in for the reference's calculate_error.py:10-103)."""
-import torch
 
 from . import ops
 from ._lib import GdnError

@@ -28,8 +28,8 @@ def _check_norm(norm):
 def _norm_layer(norm, c):
     """nn.BatchNorm2d, or the reference's nn.InstanceNorm2d(c, affine=True, track_running_stats=True) (:73, :91, :147-155).
     With tracked running statistics an InstanceNorm in eval() normalises with the running mean/var exactly like an
-    eval-mode BatchNorm, which is what the HIP path executes; per-instance statistics (train mode) are not implemented
-    and raise at the first forward (engine.conv_bn_act)."""
+    eval-mode BatchNorm, which is what the HIP path executes; in train mode the standalone ConvBlock / ConvTBlock use
+    per-instance statistics (engine._conv_instnorm_train: the BatchNorm kernels on one image at a time)."""
     if norm == 'Batch':
         return nn.BatchNorm2d(c, affine=True, track_running_stats=True)
     return nn.InstanceNorm2d(c, affine=True, track_running_stats=True)

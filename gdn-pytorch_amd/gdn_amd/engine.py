@@ -391,6 +391,62 @@ def _eval_coeffs(bn):
     return c[1]
 
 
+def _conv_instnorm_train(ctx, x, conv, inorm, relu, op, w, reflect, need_dx):
+    """Conv -> train-mode InstanceNorm2d(affine=True, track_running_stats=True) -> [ReLU]: the standalone
+    ConvBlock / ConvTBlock(norm='Instance') of the reference (AE_model_unet.py:70-75, :88-92; R and G never build one).
+    Per-instance statistics are batch statistics of a batch of one, so the BatchNorm kernels run once per image on that
+    image's slice: the convolution writes image b's output with its sum / sum-of-squares partials, finalize (momentum 1 into
+    scratch buffers) yields that image's coefficients, mean and unbiased variance, apply / backward use them; the running
+    statistics take the batch mean of the per-instance values (what F.instance_norm does).  A rarely used path: direct
+    kernels, B small launches."""
+    B, H, W, _ = x.shape
+    C = conv.out_channels
+    mom = 0.1 if inorm.momentum is None else inorm.momentum
+    ys, cos, outs = [], [], []
+    rm = torch.zeros((B, C), dtype=torch.float32, device=x.device)
+    rv = torch.ones((B, C), dtype=torch.float32, device=x.device)
+    for b in range(B):
+        yb, st = op.fwd(x[b:b + 1], w, stats=True)
+        co = ops.bn_finalize_train(st, yb.shape[1] * yb.shape[2], inorm.weight.data, inorm.bias.data, rm[b], rv[b], 1.0, inorm.eps)
+        ys.append(yb)
+        cos.append(co)
+        outs.append(ops.bn_apply(yb, co[0], co[1], relu, None, out_dtype=ctx.dtype))
+    if inorm.track_running_stats:
+        inorm.running_mean.mul_(1.0 - mom).add_(rm.mean(0), alpha=mom)
+        inorm.running_var.mul_(1.0 - mom).add_(rv.mean(0), alpha=mom)
+        # (torch's InstanceNorm2d leaves num_batches_tracked untouched: F.instance_norm does not take it)
+        inorm._gdn_stats_ver = getattr(inorm, "_gdn_stats_ver", 0) + 1
+    a = torch.cat(outs, 0)
+    if ctx.record:
+        in_hw = (H, W)
+
+        def bwd():
+            da = ctx.pop_grad(a)
+            if da is None:
+                return
+            da = _dense(da)
+            frozen = not (conv.weight.requires_grad or inorm.weight.requires_grad or inorm.bias.requires_grad)
+            dg = torch.zeros(C, dtype=torch.float32, device=da.device)
+            db = torch.zeros(C, dtype=torch.float32, device=da.device)
+            dys = []
+            for b in range(B):
+                dgb, dbb = torch.empty_like(dg), torch.empty_like(db)
+                dys.append(ops.bn_bwd(da[b:b + 1], ys[b], inorm.weight.data, cos[b], relu, dgb, dbb))
+                dg += dgb
+                db += dbb
+            dy = torch.cat(dys, 0)
+            if not frozen:
+                inorm.weight.grad.copy_(dg)
+                inorm.bias.grad.copy_(db)
+                _wgrad_into(ctx, conv, x, dy)
+                ctx.grads_done(inorm.weight, inorm.bias, conv.weight)
+            if need_dx and ctx.wants_dx(x):
+                wt = ops.transpose_taps(_w_tap(conv)[0], dtype=torch.float32)
+                ctx.grads[id(x)] = (x, op.dgrad(dy, wt, in_hw, addsrc=ctx.pop_grad_as(x, torch.float32)))
+        ctx.tape.append(bwd)
+    return a
+
+
 def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_dx=True, defer=False):
     """[relu](BN(conv(cat(x, x2)))) (+ residual): ConvBlock / ResidualBlock halves / ConvTBlock.
 
@@ -421,8 +477,9 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
         raise GdnError("layer %d->%d computes in %s but its input is %s" % (conv.in_channels, conv.out_channels, ldt, x.dtype))
     w, tr = _w_for(ctx, conv, ldt)
     if bn.training and isinstance(bn, torch.nn.InstanceNorm2d):
-        raise NotImplementedError("train-mode InstanceNorm (per-instance statistics) is not implemented on the HIP path; "
-                                  "model.eval() normalises with the tracked running statistics like the reference does")
+        if lazy or up is not None or x2 is not None or residual is not None or ldt != torch.float32:
+            raise GdnError("train-mode InstanceNorm is implemented for the standalone fp32 ConvBlock / ConvTBlock only")
+        return _conv_instnorm_train(ctx, x, conv, bn, relu, op, w, reflect, need_dx)
     use_fft = (_FFT_MIN_K > 0 and ldt == torch.float32 and x2 is None and conv.kernel_size[0] >= _FFT_MIN_K
                and conv.stride[0] == 1 and op.fft_ok(x.shape[0], x.shape[1], x.shape[2], backward=ctx.record))
     use_wino = (not use_fft and _WINOGRAD and ldt == torch.float32 and x2 is None

@@ -315,10 +315,58 @@ def test_legacy_instance_norm_eval(gpu):
     blk = blk.to(gpu).eval()
     with torch.no_grad():
         close(blk(rgb.to(gpu)), refb, what="ConvBlock(norm='Instance') eval")
-    blk.train()
-    with pytest.raises(NotImplementedError):
-        blk(rgb.to(gpu))
     assert x3_torch.shape == (2, 64, H, W)
+
+
+@pytest.mark.parametrize("kind", ["ConvBlock", "ConvTBlock"])
+def test_standalone_instance_norm_blocks_train(gpu, kind):
+    """ConvBlock / ConvTBlock(norm='Instance') in train mode (AE_model_unet.py:70-75, :88-92): per-instance statistics,
+    affine, tracked running statistics (batch mean of the per-instance mean / unbiased variance), backward -- against the same
+    layers executed by torch on the CPU."""
+    import copy
+    import gdn_amd.AE_model_unet as M
+    import torch.nn as nn
+    torch.manual_seed(11)
+    if kind == "ConvBlock":
+        blk = M.ConvBlock(64, 128, kernel_size=3, stride=2, padding=1, norm='Instance')
+        ref = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(64, 128, 3, 2, padding=0, bias=False),
+                            nn.InstanceNorm2d(128, affine=True, track_running_stats=True), nn.ReLU())
+        conv_i, norm_i = 1, 2
+    else:
+        blk = M.ConvTBlock(64, 64, kernel_size=4, stride=2, padding=1, norm='Instance')
+        ref = nn.Sequential(nn.ConvTranspose2d(64, 64, 4, 2, 1, bias=False),
+                            nn.InstanceNorm2d(64, affine=True, track_running_stats=True), nn.ReLU())
+        conv_i, norm_i = 0, 1
+    nb, nr = blk.main[norm_i], ref[norm_i]
+    with torch.no_grad():
+        nb.weight.uniform_(0.5, 1.5); nb.bias.normal_(0, 0.2)
+        nb.running_mean.normal_(0, 0.2); nb.running_var.uniform_(0.5, 1.5)
+        ref[conv_i].weight.copy_(blk.main[conv_i].weight)
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            getattr(nr, k).copy_(getattr(nb, k))
+    x = torch.randn(3, 64, 12, 20, generator=torch.Generator().manual_seed(5))
+    gy_seed = torch.Generator().manual_seed(6)
+    xr = x.clone().requires_grad_(True)
+    ref.train()
+    yr = ref(xr)
+    gy = torch.randn(yr.shape, generator=gy_seed)
+    yr.backward(gy)
+    blk = blk.to(gpu).train()
+    xg = x.to(gpu).requires_grad_(True)
+    yg = blk(xg)
+    close(yg, yr, what="train-mode output")
+    yg.backward(gy.to(gpu))
+    close(xg.grad, xr.grad, what="input gradient")
+    close(blk.main[conv_i].weight.grad, ref[conv_i].weight.grad, what="conv weight gradient")
+    close(nb.weight.grad, nr.weight.grad, what="gamma gradient")
+    close(nb.bias.grad, nr.bias.grad, what="beta gradient")
+    close(nb.running_mean, nr.running_mean, what="running mean")
+    close(nb.running_var, nr.running_var, what="running var")
+    assert int(nb.num_batches_tracked) == int(nr.num_batches_tracked)
+    # and eval() afterwards uses the updated running statistics
+    blk.eval(); ref.eval()
+    with torch.no_grad():
+        close(blk(x.to(gpu)), ref(x), what="eval after the update")
 
 
 def test_depth_extract_cli(gpu, tmp_path):

@@ -23,6 +23,7 @@
 //                    ordered launches (even tiles store, odd tiles add) -- deterministic, no atomics
 //   weight gradient  P[bin] = Df[bin]^T * Xf[bin] (reduction over tiles, MFMA), inverse DFT at the k*k taps only
 #include "common.h"
+#include <cstdlib>
 #include "up2x.h"
 
 // Tile size NP (points per side): 32 for the 7x7 / 9x9 layers, 16 for the 5x5 (and 3x3) layers on >= 256 channels, whose weight
@@ -31,7 +32,7 @@
 // real row transform; bins = NP * NK is a multiple of 8 for both sizes (they are dealt to the 8 XCDs).
 #define FFT_NK_OF(NP) ((NP) / 2 + 1)
 #define FFT_BINS_OF(NP) ((NP) * FFT_NK_OF(NP))
-static_assert(FFT_BINS_OF(32) % 8 == 0 && FFT_BINS_OF(16) % 8 == 0, "bins are dealt to the 8 XCDs");
+static_assert(FFT_BINS_OF(32) % 8 == 0 && FFT_BINS_OF(16) % 8 == 0 && FFT_BINS_OF(40) % 8 == 0, "bins are dealt to the 8 XCDs");
 // Index arithmetic is kept off the vector ALU (the transform kernels are VALU-bound; 64-bit divisions and per-element
 // 64-bit multiplies were most of their instructions): grids carry (channel chunk, tile), row and image instead of a
 // flat index, and every strided access walks a running pointer.  GDN_KEEP pins a running value so the unrolled loops do
@@ -60,9 +61,9 @@ __device__ __constant__ float kSin32[32] = {
 // The loops are fully unrolled and the twiddles are compile-time literals, so the trivial ones (1, -+i) cost no multiplies
 // and the (1 -+ i)/sqrt2 ones two.
 template <int NP, int SIGN>
-__device__ __forceinline__ void fftn(float (&re)[NP], float (&im)[NP]) {
-    static_assert(NP == 32 || NP == 16, "tile size");
-    constexpr int LOG = NP == 32 ? 5 : 4, SC = 32 / NP;
+__device__ __forceinline__ void fft_pow2(float (&re)[NP], float (&im)[NP]) {
+    static_assert(NP == 32 || NP == 16 || NP == 8, "power-of-two transform");
+    constexpr int LOG = NP == 32 ? 5 : NP == 16 ? 4 : 3, SC = 32 / NP;
     constexpr float C32[9] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f,
                               0.55557023301960229f, 0.38268343236508984f, 0.19509032201612833f, 0.0f};
     // bit reversal (LOG bits): pure register renaming after unrolling
@@ -107,6 +108,87 @@ __device__ __forceinline__ void fftn(float (&re)[NP], float (&im)[NP]) {
     }
 }
 
+// cos/sin(2*pi*j/40), j = 0..39 (40-point tiles)
+__device__ __constant__ float kCos40[40] = {
+    1.0f, 0.98768834059513777f, 0.95105651629515353f, 0.89100652418836790f, 0.80901699437494745f, 0.70710678118654757f,
+    0.58778525229247314f, 0.45399049973954680f, 0.30901699437494745f, 0.15643446504023092f, 0.0f, -0.15643446504023081f,
+    -0.30901699437494734f, -0.45399049973954669f, -0.58778525229247303f, -0.70710678118654746f, -0.80901699437494734f,
+    -0.89100652418836779f, -0.95105651629515353f, -0.98768834059513766f, -1.0f, -0.98768834059513777f, -0.95105651629515364f,
+    -0.89100652418836812f, -0.80901699437494756f, -0.70710678118654768f, -0.58778525229247325f, -0.45399049973954692f,
+    -0.30901699437494756f, -0.15643446504023104f, 0.0f, 0.15643446504023067f, 0.30901699437494723f, 0.45399049973954664f,
+    0.58778525229247292f, 0.70710678118654735f, 0.80901699437494734f, 0.89100652418836779f, 0.95105651629515353f,
+    0.98768834059513766f};
+__device__ __constant__ float kSin40[40] = {
+    0.0f, 0.15643446504023087f, 0.30901699437494740f, 0.45399049973954675f, 0.58778525229247314f, 0.70710678118654746f,
+    0.80901699437494745f, 0.89100652418836790f, 0.95105651629515353f, 0.98768834059513777f, 1.0f, 0.98768834059513777f,
+    0.95105651629515364f, 0.89100652418836790f, 0.80901699437494745f, 0.70710678118654757f, 0.58778525229247325f,
+    0.45399049973954686f, 0.30901699437494751f, 0.15643446504023098f, 0.0f, -0.15643446504023073f, -0.30901699437494728f,
+    -0.45399049973954625f, -0.58778525229247303f, -0.70710678118654746f, -0.80901699437494734f, -0.89100652418836779f,
+    -0.95105651629515353f, -0.98768834059513766f, -1.0f, -0.98768834059513777f, -0.95105651629515364f, -0.89100652418836812f,
+    -0.80901699437494756f, -0.70710678118654768f, -0.58778525229247336f, -0.45399049973954697f, -0.30901699437494762f,
+    -0.15643446504023112f};
+
+// 40-point transform = 5 x 8 Cooley-Tukey: five 8-point transforms over x[5 n1 + n2], twiddles W40^(n2 k1), then eight
+// 5-point transforms (the symmetric form: two cosine and two sine combinations) to X[k1 + 8 k2].  40-point tiles carry 32
+// valid outputs of a 9x9 layer: 128 x 416 is exactly 4 x 13 of them (26 % fewer points than 6 x 18 tiles of 32).
+template <int SIGN>
+__device__ __forceinline__ void fft40(float (&re)[40], float (&im)[40]) {
+    constexpr float CS40[11] = {1.0f, 0.98768834059513777f, 0.95105651629515353f, 0.89100652418836790f, 0.80901699437494745f,
+                                0.70710678118654757f, 0.58778525229247314f, 0.45399049973954680f, 0.30901699437494745f,
+                                0.15643446504023092f, 0.0f};        // cos(2 pi j / 40), j = 0..10 (sin = the mirror)
+    float yr[5][8], yi[5][8];
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) {
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) { yr[n2][n1] = re[5 * n1 + n2]; yi[n2][n1] = im[5 * n1 + n2]; }
+        fft_pow2<8, SIGN>(yr[n2], yi[n2]);
+        if (n2 > 0) {
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) {
+                const int q = n2 * k1;                      // angle 2 pi q / 40, q <= 28
+                // cos / sin by quadrant from the first-quadrant table
+                const int qq = q % 40;
+                const float c = qq <= 10 ? CS40[qq] : qq <= 20 ? -CS40[20 - qq] : qq <= 30 ? -CS40[qq - 20] : CS40[40 - qq];
+                const float sn = qq <= 10 ? CS40[10 - qq] : qq <= 20 ? CS40[qq - 10] : qq <= 30 ? -CS40[30 - qq] : -CS40[qq - 30];
+                const float wr = c, wi = SIGN * sn;
+                const float tr = yr[n2][k1] * wr - yi[n2][k1] * wi, ti = yr[n2][k1] * wi + yi[n2][k1] * wr;
+                yr[n2][k1] = tr; yi[n2][k1] = ti;
+            }
+        }
+    }
+    constexpr float C1 = 0.30901699437494745f, C2 = -0.80901699437494745f;     // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr float S1 = 0.95105651629515353f, S2 = 0.58778525229247314f;      // sin(2 pi / 5), sin(4 pi / 5)
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+        const float t1r = yr[1][k1] + yr[4][k1], t1i = yi[1][k1] + yi[4][k1];
+        const float t2r = yr[2][k1] + yr[3][k1], t2i = yi[2][k1] + yi[3][k1];
+        const float t3r = yr[1][k1] - yr[4][k1], t3i = yi[1][k1] - yi[4][k1];
+        const float t4r = yr[2][k1] - yr[3][k1], t4i = yi[2][k1] - yi[3][k1];
+        const float a1r = yr[0][k1] + C1 * t1r + C2 * t2r, a1i = yi[0][k1] + C1 * t1i + C2 * t2i;
+        const float a2r = yr[0][k1] + C2 * t1r + C1 * t2r, a2i = yi[0][k1] + C2 * t1i + C1 * t2i;
+        const float b1r = S1 * t3r + S2 * t4r, b1i = S1 * t3i + S2 * t4i;
+        const float b2r = S2 * t3r - S1 * t4r, b2i = S2 * t3i - S1 * t4i;
+        re[k1] = yr[0][k1] + t1r + t2r;        im[k1] = yi[0][k1] + t1i + t2i;
+        // X[k1 + 8 k2] = a +- SIGN * i * b,  i * (br + i bi) = -bi + i br
+        re[k1 + 8] = a1r - SIGN * b1i;         im[k1 + 8] = a1i + SIGN * b1r;
+        re[k1 + 32] = a1r + SIGN * b1i;        im[k1 + 32] = a1i - SIGN * b1r;
+        re[k1 + 16] = a2r - SIGN * b2i;        im[k1 + 16] = a2i + SIGN * b2r;
+        re[k1 + 24] = a2r + SIGN * b2i;        im[k1 + 24] = a2i - SIGN * b2r;
+    }
+}
+
+template <int NP, int SIGN>
+__device__ __forceinline__ void fftn(float (&re)[NP], float (&im)[NP]) {
+    if constexpr (NP == 40) fft40<SIGN>(re, im);
+    else fft_pow2<NP, SIGN>(re, im);
+}
+
+// twiddle cos / sin(2 pi idx / NP) for a non-negative index product (wave-uniform: scalar loads)
+template <int NP>
+__device__ __forceinline__ float tw_cos(int idx) { return NP == 40 ? kCos40[idx % 40] : kCos32[(idx & (NP - 1)) * (32 / (NP == 40 ? 32 : NP))]; }
+template <int NP>
+__device__ __forceinline__ float tw_sin(int idx) { return NP == 40 ? kSin40[idx % 40] : kSin32[(idx & (NP - 1)) * (32 / (NP == 40 ? 32 : NP))]; }
+
 struct FftGeom {
     int np, bins;                // tile size (32 / 16), kept bins = np * (np/2 + 1)
     int B, H, W, C, N;           // input [B,H,W,C], output channels N
@@ -124,7 +206,7 @@ struct FftGeom {
 template <int K, int NP>
 __global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restrict__ w /* [k*k][N][C] */, float* __restrict__ Wf,
                                                           int N, int C, int flip) {
-    constexpr int NK = FFT_NK_OF(NP), SC = 32 / NP;
+    constexpr int NK = FFT_NK_OF(NP);
     const int ky = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N * C) return;
@@ -134,8 +216,7 @@ __global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restric
     for (int tx = 0; tx < K; ++tx) { ur[tx] = 0.f; ui[tx] = 0.f; }
 #pragma unroll
     for (int ty = 0; ty < K; ++ty) {
-        const int ph = ((ky * ty) & (NP - 1)) * SC;
-        const float cs = kCos32[ph], sn = kSin32[ph];
+        const float cs = tw_cos<NP>(ky * ty), sn = tw_sin<NP>(ky * ty);
 #pragma unroll
         for (int tx = 0; tx < K; ++tx) {
             const int tap = flip ? (K - 1 - ty) * K + (K - 1 - tx) : ty * K + tx;
@@ -150,8 +231,7 @@ __global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restric
         float wr = 0.f, wi = 0.f;
 #pragma unroll
         for (int tx = 0; tx < K; ++tx) {
-            const int ph = ((kx * tx) & (NP - 1)) * SC;
-            const float cs = kCos32[ph], sn = kSin32[ph];
+            const float cs = tw_cos<NP>(kx * tx), sn = tw_sin<NP>(kx * tx);
             wr += ur[tx] * cs + ui[tx] * sn;       // (ur + i ui)(cs - i sn)
             wi += ui[tx] * cs - ur[tx] * sn;
         }
@@ -268,7 +348,7 @@ __global__ __launch_bounds__(256, 4) void cgemm_bins_kernel(const float* __restr
 // icols: thread = (tile, kx, channel n): inverse FFT32 along ky, rows u < nrows kept.
 // grid: x = (tile / 4) * (C / 64) + channel chunk, y = kx; block = 4 tiles x 64 channels
 template <int NP>
-__global__ __launch_bounds__(256) void ifft_cols_kernel(const float2* __restrict__ Yf, float2* __restrict__ S, int C, int M, int nrows,
+__global__ __launch_bounds__(256, NP == 40 ? 2 : 1) void ifft_cols_kernel(const float2* __restrict__ Yf, float2* __restrict__ S, int C, int M, int nrows,
                                                         int cq_shift) {
     constexpr int NK = FFT_NK_OF(NP);
     const int t = (blockIdx.x >> cq_shift) * 4 + (threadIdx.x >> 6);
@@ -378,7 +458,7 @@ __global__ __launch_bounds__(256) void fft_sum_splits_kernel(float* __restrict__
 
 template <int K, int NP>
 __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C) {
-    constexpr int NK = FFT_NK_OF(NP), SC = 32 / NP;
+    constexpr int NK = FFT_NK_OF(NP);
     __shared__ float red[3][K * K][64];
     const int pl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + pl;             // N*C is a multiple of 64
@@ -398,8 +478,7 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
             const float2 v = F[(size_t)(ky * NK + kx) * bs];
 #pragma unroll
             for (int ty = 0; ty < K; ++ty) {
-                const int ph = ((ky * ty) & (NP - 1)) * SC;
-                const float cs = kCos32[ph], sn = kSin32[ph];
+                const float cs = tw_cos<NP>(ky * ty), sn = tw_sin<NP>(ky * ty);
                 gr[ty] += v.x * cs - v.y * sn;
                 gi[ty] += v.x * sn + v.y * cs;
             }
@@ -407,8 +486,7 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
         const float alpha = (kx == 0 || kx == NP / 2) ? 1.f : 2.f;
 #pragma unroll
         for (int tx = 0; tx < K; ++tx) {
-            const int ph = ((kx * tx) & (NP - 1)) * SC;
-            const float cs = kCos32[ph] * alpha, sn = kSin32[ph] * alpha;
+            const float cs = tw_cos<NP>(kx * tx) * alpha, sn = tw_sin<NP>(kx * tx) * alpha;
 #pragma unroll
             for (int ty = 0; ty < K; ++ty) acc[ty * K + tx] += gr[ty] * cs - gi[ty] * sn;
         }
@@ -511,8 +589,9 @@ __global__ __launch_bounds__(256) void fft_reflect_fold_kernel(const float* __re
 }
 
 // ---- single-pass 2-D transforms: one workgroup = one tile x 16 channels, rows and columns meet in LDS (68 KB) ----
-#define FFT_CG 16
-#define FFT_LDS_ELEMS_OF(NP) ((NP) * FFT_NK_OF(NP) * FFT_CG)
+// channels per workgroup: 16, or 8 for the 40-point tiles (40 x 21 x 8 complex = 53.8 KB: three workgroups per CU)
+#define FFT_CG_OF(NP) ((NP) == 40 ? 16 : 16)
+#define FFT_LDS_ELEMS_OF(NP) ((NP) * FFT_NK_OF(NP) * FFT_CG_OF(NP))
 
 // forward: patch (halo = 1: rows/cols start at -pad, full 32; halo = 0: the T x T tile, zero padded) -> Xf[bin][tile][C]
 // two waves per SIMD: at four (128 VGPRs) the two 32-point transforms spill 44 dwords per lane and the kernel is 15 % slower
@@ -524,25 +603,25 @@ __global__ __launch_bounds__(256) void fft_reflect_fold_kernel(const float* __re
 // AE_model_unet.py:51,54) computed on load from bnb_co = {scale, shift, mean, invstd}[C] and bnb_kk = {k1, k2}[C]: dy is
 // never written to memory.
 template <int NP>
-__global__ __launch_bounds__(NP * FFT_CG, NP == 32 ? 2 : 4) void fft2d_fwd_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ Xf,
+__global__ __launch_bounds__(NP * FFT_CG_OF(NP), NP == 16 ? 4 : 2) void fft2d_fwd_kernel(const float* __restrict__ x, int ldx, float2* __restrict__ Xf,
                                                         FftGeom g, int halo, const float* __restrict__ in_scale,
                                                         const float* __restrict__ in_shift, int in_relu,
                                                         const float* __restrict__ bnb_y, int ld_bnb,
                                                         const float* __restrict__ bnb_co, const float* __restrict__ bnb_kk,
                                                         int up2x) {
-    constexpr int NK = FFT_NK_OF(NP);
+    constexpr int NK = FFT_NK_OF(NP), CG = FFT_CG_OF(NP), CGS = CG == 8 ? 3 : 4;
     __shared__ float2 lds[FFT_LDS_ELEMS_OF(NP)];
     // XCD-aware order: XCD j (= blockIdx & 7) owns the contiguous tile range [j, j+1) * ceil(M/8) and runs the channel
     // groups of one tile back to back, so the half cache lines the groups share and the halo rows / columns neighbouring
     // tiles share are served by that XCD's L2 instead of being fetched once per XCD
-    const int ngrp = g.C / FFT_CG, tpx = (g.M + 7) / 8;
-    const int tid = threadIdx.x, c = tid & 15, cg = ((blockIdx.x >> 3) % ngrp) * FFT_CG;
+    const int ngrp = g.C / CG, tpx = (g.M + 7) / 8;
+    const int tid = threadIdx.x, c = tid & (CG - 1), cg = ((blockIdx.x >> 3) % ngrp) * CG;
     const int t = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3) / ngrp;
     if (t >= g.M) return;
     const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
     float re[NP], im[NP];
     {
-        const int a = tid >> 4;
+        const int a = tid >> CGS;
         const int iy = ty * g.T + a - (halo ? g.pad : 0);
         const int ix0 = tx * g.T - (halo ? g.pad : 0);
         const int nvalid = halo ? NP : g.T;
@@ -620,13 +699,13 @@ __global__ __launch_bounds__(NP * FFT_CG, NP == 32 ? 2 : 4) void fft2d_fwd_kerne
         }
         fftn<NP, -1>(re, im);
 #pragma unroll
-        for (int kx = 0; kx < NK; ++kx) lds[(a * NK + kx) * FFT_CG + c] = make_float2(re[kx], im[kx]);
+        for (int kx = 0; kx < NK; ++kx) lds[(a * NK + kx) * CG + c] = make_float2(re[kx], im[kx]);
     }
     __syncthreads();
-    if (tid < NK * FFT_CG) {
-        const int kx = tid >> 4;
+    if (tid < NK * CG) {
+        const int kx = tid >> CGS;
 #pragma unroll
-        for (int a = 0; a < NP; ++a) { const float2 v = lds[(a * NK + kx) * FFT_CG + c]; re[a] = v.x; im[a] = v.y; }
+        for (int a = 0; a < NP; ++a) { const float2 v = lds[(a * NK + kx) * CG + c]; re[a] = v.x; im[a] = v.y; }
         fftn<NP, -1>(re, im);
         float2* dst = Xf + ((size_t)kx * g.M + t) * g.C + cg + c;
         const size_t sk = (size_t)NK * g.M * g.C;
@@ -639,10 +718,10 @@ __global__ __launch_bounds__(NP * FFT_CG, NP == 32 ? 2 : 4) void fft2d_fwd_kerne
 template <int NP>
 __device__ __forceinline__ void ifft2d_cols_to_lds(const float2* __restrict__ Yf, float2* lds, int C, int M, int t, int cg,
                                                    float (&re)[NP], float (&im)[NP]) {
-    constexpr int NK = FFT_NK_OF(NP);
-    const int tid = threadIdx.x, c = tid & 15;
-    if (tid < NK * FFT_CG) {
-        const int kx = tid >> 4;
+    constexpr int NK = FFT_NK_OF(NP), CG = FFT_CG_OF(NP), CGS = CG == 8 ? 3 : 4;
+    const int tid = threadIdx.x, c = tid & (CG - 1);
+    if (tid < NK * CG) {
+        const int kx = tid >> CGS;
         const float2* src = Yf + ((size_t)kx * M + t) * C + cg + c;
         const size_t sk = (size_t)NK * M * C;
 #pragma unroll
@@ -653,16 +732,16 @@ __device__ __forceinline__ void ifft2d_cols_to_lds(const float2* __restrict__ Yf
         }
         fftn<NP, 1>(re, im);
 #pragma unroll
-        for (int u = 0; u < NP; ++u) lds[(u * NK + kx) * FFT_CG + c] = make_float2(re[u], im[u]);
+        for (int u = 0; u < NP; ++u) lds[(u * NK + kx) * CG + c] = make_float2(re[u], im[u]);
     }
     __syncthreads();
 }
 
 template <int NP>
 __device__ __forceinline__ void ifft_row_from_lds(const float2* lds, int u, int c, float (&re)[NP], float (&im)[NP]) {
-    constexpr int NK = FFT_NK_OF(NP);
+    constexpr int NK = FFT_NK_OF(NP), CG = FFT_CG_OF(NP), CGS = CG == 8 ? 3 : 4;
 #pragma unroll
-    for (int kx = 0; kx < NK; ++kx) { const float2 v = lds[(u * NK + kx) * FFT_CG + c]; re[kx] = v.x; im[kx] = v.y; }
+    for (int kx = 0; kx < NK; ++kx) { const float2 v = lds[(u * NK + kx) * CG + c]; re[kx] = v.x; im[kx] = v.y; }
 #pragma unroll
     for (int kx = NK; kx < NP; ++kx) { re[kx] = re[NP - kx]; im[kx] = -im[NP - kx]; }
     fftn<NP, 1>(re, im);
@@ -670,19 +749,20 @@ __device__ __forceinline__ void ifft_row_from_lds(const float2* lds, int u, int 
 
 // forward convolution output: valid T x T outputs of the tile, epilogue, BatchNorm partials (stats slot = tile)
 template <int NP>
-__global__ __launch_bounds__(NP * FFT_CG, NP == 32 ? 4 : 8) void ifft2d_valid_kernel(const float2* __restrict__ Yf, float* __restrict__ y, int ldy,
+__global__ __launch_bounds__(NP * FFT_CG_OF(NP), NP == 16 ? 8 : NP == 32 ? 4 : 2) void ifft2d_valid_kernel(const float2* __restrict__ Yf, float* __restrict__ y, int ldy,
                                                            const float* __restrict__ addsrc, int ld_add,
                                                            float* __restrict__ stats, const float* __restrict__ ep_scale,
                                                            const float* __restrict__ ep_shift, int act, FftGeom g) {
+    constexpr int CG = FFT_CG_OF(NP), CGS = CG == 8 ? 3 : 4;
     __shared__ float2 lds[FFT_LDS_ELEMS_OF(NP)];
-    const int ngrp = g.N / FFT_CG, tpx = (g.M + 7) / 8;          // XCD-aware order as in fft2d_fwd_kernel
-    const int tid = threadIdx.x, c = tid & 15, cg = ((blockIdx.x >> 3) % ngrp) * FFT_CG, T = g.T;
+    const int ngrp = g.N / CG, tpx = (g.M + 7) / 8;          // XCD-aware order as in fft2d_fwd_kernel
+    const int tid = threadIdx.x, c = tid & (CG - 1), cg = ((blockIdx.x >> 3) % ngrp) * CG, T = g.T;
     const int t = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3) / ngrp;
     if (t >= g.M) return;
     const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
     float re[NP], im[NP];
     ifft2d_cols_to_lds<NP>(Yf, lds, g.N, g.M, t, cg, re, im);
-    const int u = tid >> 4, oy = ty * T + u;
+    const int u = tid >> CGS, oy = ty * T + u;
     float s1 = 0.f, s2 = 0.f;
     if (u < T && oy < g.H) {
         ifft_row_from_lds<NP>(lds, u, c, re, im);
@@ -739,9 +819,9 @@ __global__ __launch_bounds__(NP * FFT_CG, NP == 32 ? 4 : 8) void ifft2d_valid_ke
         float* red = reinterpret_cast<float*>(lds);
         red[tid * 2] = s1; red[tid * 2 + 1] = s2;
         __syncthreads();
-        if (tid < FFT_CG) {
+        if (tid < CG) {
             float a1 = 0.f, a2 = 0.f;
-            for (int j = 0; j < NP; ++j) { a1 += red[(j * FFT_CG + tid) * 2]; a2 += red[(j * FFT_CG + tid) * 2 + 1]; }
+            for (int j = 0; j < NP; ++j) { a1 += red[(j * CG + tid) * 2]; a2 += red[(j * CG + tid) * 2 + 1]; }
             stats[((size_t)t * 2 + 0) * g.N + cg + tid] = a1;
             stats[((size_t)t * 2 + 1) * g.N + cg + tid] = a2;
         }
@@ -762,6 +842,18 @@ bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
         const int t32 = 33 - g->k;
         const long m32 = (long)g->B * cdiv(g->H, t32) * cdiv(g->W, t32);
         f.np = (g->k <= 5 && 3L * g->Cout > 2 * m32) ? 16 : 32;
+        // 40-point tiles for a TRAINED layer (GDN_HINT_TRAIN) where they cut the transformed points by at least a fifth -- the
+        // 9x9 layers at 128 x 416: T = 32 tiles the image exactly, 4 x 13 x 1600 points against 6 x 18 x 1024 -- and the weight
+        // spectrum stays small (<= 128 channels).  Measured at B = 20 (tests/diag/fft_kernels_time.py): the three per-bin GEMMs
+        // of a training step -26 %, the single-pass transforms +20-35 % (one 640-thread workgroup per CU): forward 0.85 ->
+        // 0.81 ms, backward 1.33 -> 1.17 ms; an eval-mode forward (frozen guide, inference) is slower and keeps 32 points.
+        const int t40 = 41 - g->k;
+        const long p32 = (long)cdiv(g->H, t32) * cdiv(g->W, t32) * 1024, p40 = (long)cdiv(g->H, t40) * cdiv(g->W, t40) * 1600;
+        const char* fe = getenv("GDN_FFT_NP");                      // measurement / test override: 32 or 40
+        const int force = fe ? atoi(fe) : 0;
+        if (f.np == 32 && (g->hints & GDN_HINT_TRAIN) && g->k >= 7 && g->Cin <= 128 && g->Cout <= 128 && 5 * p40 <= 4 * p32) f.np = 40;
+        if (force == 32 && f.np == 40) f.np = 32;
+        if (force == 40 && f.np == 32 && g->k >= 5) f.np = 40;
     }
     f.bins = FFT_BINS_OF(f.np);
     f.T = f.np - g->k + 1;
@@ -824,6 +916,7 @@ void launch_weights_np(const FftGeom& f, const float* w, float* Wf, hipStream_t 
 }
 void launch_weights(const FftGeom& f, const float* w, float* Wf, hipStream_t st) {
     if (f.np == 16) launch_weights_np<16>(f, w, Wf, st);
+    else if (f.np == 40) launch_weights_np<40>(f, w, Wf, st);
     else launch_weights_np<32>(f, w, Wf, st);
 }
 
@@ -831,12 +924,15 @@ void launch_weights(const FftGeom& f, const float* w, float* Wf, hipStream_t st)
 void launch_fft2d_fwd(const FftGeom& f, int chans, const float* x, int ldx, float2* Xf, int halo, const float* in_scale,
                       const float* in_shift, int in_relu, const float* bnb_y, int ld_bnb, const float* bnb_co, const float* bnb_kk,
                       int up2x, hipStream_t st) {
-    const dim3 gr(chans / FFT_CG * 8 * cdiv(f.M, 8));
+    const dim3 gr(chans / FFT_CG_OF(f.np) * 8 * cdiv(f.M, 8)), bl(f.np * FFT_CG_OF(f.np));
     if (f.np == 16)
-        hipLaunchKernelGGL(fft2d_fwd_kernel<16>, gr, dim3(16 * FFT_CG), 0, st, x, ldx, Xf, f, halo, in_scale, in_shift, in_relu, bnb_y,
+        hipLaunchKernelGGL(fft2d_fwd_kernel<16>, gr, bl, 0, st, x, ldx, Xf, f, halo, in_scale, in_shift, in_relu, bnb_y,
+                           ld_bnb, bnb_co, bnb_kk, up2x);
+    else if (f.np == 40)
+        hipLaunchKernelGGL(fft2d_fwd_kernel<40>, gr, bl, 0, st, x, ldx, Xf, f, halo, in_scale, in_shift, in_relu, bnb_y,
                            ld_bnb, bnb_co, bnb_kk, up2x);
     else
-        hipLaunchKernelGGL(fft2d_fwd_kernel<32>, gr, dim3(32 * FFT_CG), 0, st, x, ldx, Xf, f, halo, in_scale, in_shift, in_relu, bnb_y,
+        hipLaunchKernelGGL(fft2d_fwd_kernel<32>, gr, bl, 0, st, x, ldx, Xf, f, halo, in_scale, in_shift, in_relu, bnb_y,
                            ld_bnb, bnb_co, bnb_kk, up2x);
 }
 }  // namespace
@@ -865,12 +961,15 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
     launch_weights(f, w, Wf, st);
     hipLaunchKernelGGL(cgemm_bins_kernel<false>, dim3(cdiv(f.M, 64) * (f.N / 64) * f.bins), dim3(256), 0, st,
                        (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, f.N, f.C);
-    const dim3 gv(f.N / FFT_CG * 8 * cdiv(f.M, 8));
+    const dim3 gv(f.N / FFT_CG_OF(f.np) * 8 * cdiv(f.M, 8)), bv(f.np * FFT_CG_OF(f.np));
     if (f.np == 16)
-        hipLaunchKernelGGL(ifft2d_valid_kernel<16>, gv, dim3(16 * FFT_CG), 0, st, (const float2*)Yf, y, ldy, addsrc, ld_add, stats,
+        hipLaunchKernelGGL(ifft2d_valid_kernel<16>, gv, bv, 0, st, (const float2*)Yf, y, ldy, addsrc, ld_add, stats,
+                           ep_scale, ep_shift, act, f);
+    else if (f.np == 40)
+        hipLaunchKernelGGL(ifft2d_valid_kernel<40>, gv, bv, 0, st, (const float2*)Yf, y, ldy, addsrc, ld_add, stats,
                            ep_scale, ep_shift, act, f);
     else
-        hipLaunchKernelGGL(ifft2d_valid_kernel<32>, gv, dim3(32 * FFT_CG), 0, st, (const float2*)Yf, y, ldy, addsrc, ld_add, stats,
+        hipLaunchKernelGGL(ifft2d_valid_kernel<32>, gv, bv, 0, st, (const float2*)Yf, y, ldy, addsrc, ld_add, stats,
                            ep_scale, ep_shift, act, f);
     return gdn_launch_status();
 }
@@ -931,6 +1030,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         }
 #define GDN_TAPS(KK) case KK: \
             if (f.np == 16) hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 16>), dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
+            else if (f.np == 40) hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 40>), dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
             else hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 32>), dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
             break;
         switch (f.k) {
@@ -949,6 +1049,9 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         if (f.np == 16)
             hipLaunchKernelGGL(ifft_cols_kernel<16>, dim3(cdiv(f.M, 4) << cq_shift, FFT_NK_OF(16)), dim3(256), 0, st, (const float2*)Ef, R,
                                f.C, f.M, 16, cq_shift);
+        else if (f.np == 40)
+            hipLaunchKernelGGL(ifft_cols_kernel<40>, dim3(cdiv(f.M, 4) << cq_shift, FFT_NK_OF(40)), dim3(256), 0, st, (const float2*)Ef, R,
+                               f.C, f.M, 40, cq_shift);
         else
             hipLaunchKernelGGL(ifft_cols_kernel<32>, dim3(cdiv(f.M, 4) << cq_shift, FFT_NK_OF(32)), dim3(256), 0, st, (const float2*)Ef, R,
                                f.C, f.M, 32, cq_shift);
@@ -962,6 +1065,9 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
             const float* ad = f.reflect ? (const float*)nullptr : addsrc;
             if (f.np == 16)
                 hipLaunchKernelGGL(ifft_rows_overlap_kernel<16>, gr, dim3(256), 0, st, (const float2*)R, o, ldo, ad, ld_add, f, parity, Ho,
+                                   Wo, off, cq_shift);
+            else if (f.np == 40)
+                hipLaunchKernelGGL(ifft_rows_overlap_kernel<40>, gr, dim3(256), 0, st, (const float2*)R, o, ldo, ad, ld_add, f, parity, Ho,
                                    Wo, off, cq_shift);
             else
                 hipLaunchKernelGGL(ifft_rows_overlap_kernel<32>, gr, dim3(256), 0, st, (const float2*)R, o, ldo, ad, ld_add, f, parity, Ho,

@@ -20,7 +20,7 @@ class ConvGeom(Structure):
     """gdn_conv_geom (include/gdn_hip.h)."""
     _fields_ = [("B", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
                 ("k", c_int32), ("stride", c_int32), ("pad", c_int32), ("pad_mode", c_int32),
-                ("transposed", c_int32)]
+                ("transposed", c_int32), ("hints", c_int32)]
 
 
 _PG = POINTER(ConvGeom)

@@ -480,8 +480,12 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
         if lazy or up is not None or x2 is not None or residual is not None or ldt != torch.float32:
             raise GdnError("train-mode InstanceNorm is implemented for the standalone fp32 ConvBlock / ConvTBlock only")
         return _conv_instnorm_train(ctx, x, conv, bn, relu, op, w, reflect, need_dx)
+    # GDN_HINT_TRAIN: a trained layer in train mode (forward + backward + weight gradient) -- the frequency-domain path then
+    # tiles for the sum of both passes (40-point tiles on the 9x9 layers); frozen / eval-mode layers keep the forward-optimal plan
+    fft_train = bool(ctx.record and bn.training and conv.weight.requires_grad)
     use_fft = (_FFT_MIN_K > 0 and ldt == torch.float32 and x2 is None and conv.kernel_size[0] >= _FFT_MIN_K
-               and conv.stride[0] == 1 and op.fft_ok(x.shape[0], x.shape[1], x.shape[2], backward=ctx.record))
+               and conv.stride[0] == 1
+               and op.fft_ok(x.shape[0], x.shape[1], x.shape[2], backward=ctx.record, train=fft_train))
     use_wino = (not use_fft and _WINOGRAD and ldt == torch.float32 and x2 is None
                 and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and op.wino_ok(x.shape[0], x.shape[1], x.shape[2]))
     use_wino2 = (not use_fft and not use_wino and _WINO2_MIN_C > 0 and ldt == torch.float32 and x2 is None
@@ -497,6 +501,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     use_fft = use_fft or use_wino or use_wino2
     in_kw = {}
     xt = x                               # the tensor the conv kernels read
+    hint_kw = {"train": fft_train} if use_fft_only else {}
     if up is not None:
         if not (use_fft and not use_wino2):
             raise GdnError("internal: deferred upsampling reached a layer without a fused loader")
@@ -515,7 +520,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
               and ops.c1_ok(x, conv.out_channels, conv.kernel_size[0], conv.stride[0], reflect or conv.padding[0]))
     if bn.training:
         if use_fft:
-            r = alt_fwd(xt, w, stats=True, **{state_kw: keep_xf}, **in_kw)
+            r = alt_fwd(xt, w, stats=True, **{state_kw: keep_xf}, **in_kw, **hint_kw)
             y, st = r[0], r[1]
             xf = r[2] if keep_xf else None
         elif use_c1:
@@ -535,7 +540,8 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     if fused:
         # eval-mode BN folded into the conv epilogue: conv + scale/shift + ReLU (+ residual) in one pass
         if use_fft:
-            y = a = alt_fwd(xt, w, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual, **in_kw)
+            y = a = alt_fwd(xt, w, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual, **in_kw,
+                            **hint_kw)
         elif use_c1:
             y = a = ops.conv_c1_fwd(xt, w, reflect=bool(reflect), affine=(co[0], co[1]),
                                     act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
@@ -543,7 +549,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
             y = a = op.fwd(xt, w, x2=x2, affine=(co[0], co[1]), act=ops.ACT_RELU if relu else ops.ACT_NONE, addsrc=residual)
     else:
         if not bn.training:
-            y = (alt_fwd(xt, w, **in_kw) if use_fft else ops.conv_c1_fwd(xt, w, reflect=bool(reflect)) if use_c1
+            y = (alt_fwd(xt, w, **in_kw, **hint_kw) if use_fft else ops.conv_c1_fwd(xt, w, reflect=bool(reflect)) if use_c1
                  else op.fwd(xt, w, x2=x2))
         else:
             out_info = BnOut(y, co, relu)
@@ -608,7 +614,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                         extra["up2x"] = up.mode             # ... the low-resolution source of the deferred upsampling
                         gx = up.src
                     dx = alt_bwd(dy, w, in_hw, dw_tap=gv, need_dx=want_dx, **{bstate_kw: xf},
-                                 addsrc=ctx.pop_grad_as(gx, ldt) if want_dx else None, **extra)
+                                 addsrc=ctx.pop_grad_as(gx, ldt) if want_dx else None, **extra, **hint_kw)
                     if want_dx:
                         ctx.grads[id(gx)] = (gx, dx)
                         if bnb is not None:

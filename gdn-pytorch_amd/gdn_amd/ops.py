@@ -106,12 +106,12 @@ class Conv:
         self._geom = {}
         self._fwd_ws = {}
 
-    def geom(self, B, H, W):
-        key = (B, H, W)
+    def geom(self, B, H, W, hints=0):
+        key = (B, H, W, hints)
         g = self._geom.get(key)
         if g is None:
             cg = ConvGeom(B, H, W, self.cin, self.cout, self.k, self.stride, self.pad,
-                          1 if self.reflect else 0, 1 if self.transposed else 0)
+                          1 if self.reflect else 0, 1 if self.transposed else 0, hints)
             ho, wo = ctypes.c_int32(), ctypes.c_int32()
             lib.gdn_conv_out_dims(ctypes.byref(cg), ctypes.byref(ho), ctypes.byref(wo))
             g = (cg, ctypes.byref(cg), ho.value, wo.value)
@@ -185,20 +185,21 @@ class Conv:
         return dx
 
     # ---- FFT-domain path (csrc/conv_fft.hip): stride-1 zero-padded fp32 layers with 64..256 channels ----
-    def fft_ok(self, B, H, W, backward=False):
+    def fft_ok(self, B, H, W, backward=False, train=False):
         """True when gdn_fftconv_fwd (and, with `backward`, gdn_fftconv_bwd) supports this layer at this input size.
-        Stride-1 ConvTranspose2d layers are forward-only."""
-        _, ref, _, _ = self.geom(B, H, W)
+        Stride-1 ConvTranspose2d layers are forward-only.  train (here and in fft_fwd / fft_bwd, the same value for one
+        layer instance): GDN_HINT_TRAIN -- forward + backward of a trained layer, tiled for the sum of both."""
+        _, ref, _, _ = self.geom(B, H, W, 1 if train else 0)
         if backward:
             return int(lib.gdn_fftconv_bwd_workspace_bytes(ref)) > 0
         return int(lib.gdn_fftconv_spectrum_bytes(ref)) > 0
 
-    def fft_stats_slots(self, B, H, W):
-        _, ref, _, _ = self.geom(B, H, W)
+    def fft_stats_slots(self, B, H, W, train=False):
+        _, ref, _, _ = self.geom(B, H, W, 1 if train else 0)
         return int(lib.gdn_fftconv_stats_slots(ref))
 
     def fft_fwd(self, x, w_tap, stats=False, addsrc=None, spectrum=False, out=None, stats_out=None, affine=None,
-                act=ACT_NONE, in_affine=None, in_relu=False, up2x=0):
+                act=ACT_NONE, in_affine=None, in_relu=False, up2x=0, train=False):
         """y = conv(x) (+ addsrc) through the frequency domain; returns y, then the BatchNorm partials when `stats`,
         then the input spectrum (opaque uint8 buffer for fft_bwd) when `spectrum`.
         in_affine = (scale, shift): x is a raw conv output and the layer input is [relu](x*scale + shift), applied on load.
@@ -207,7 +208,7 @@ class Conv:
         B, H, W, C1 = x.shape
         if up2x:
             H, W = 2 * H, 2 * W
-        _, ref, Ho, Wo = self.geom(B, H, W)
+        _, ref, Ho, Wo = self.geom(B, H, W, 1 if train else 0)
         nb = int(lib.gdn_fftconv_fwd_workspace_bytes(ref))
         if nb == 0 or C1 != self.cin:
             raise GdnError("fftconv: unsupported layer k=%d stride=%d Cin=%d Cout=%d" % (self.k, self.stride, C1, self.cout))
@@ -229,7 +230,7 @@ class Conv:
         _, ref, _, _ = self.geom(B, H, W)
         return int(lib.gdn_winoconv_bnb_slots(ref))
 
-    def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None, dyb=None, up2x=0):
+    def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None, dyb=None, up2x=0, train=False):
         """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's saved state xf:
         input + weight spectra) from one transform of dy.  w_tap is the FORWARD tap-major weight [k*k, Cout, Cin]; it is
         only read when xf is None.
@@ -240,7 +241,7 @@ class Conv:
         _chk(dy, "dy")
         B = dy.shape[0]
         H, W = in_hw
-        _, ref, Ho, Wo = self.geom(B, H, W)
+        _, ref, Ho, Wo = self.geom(B, H, W, 1 if train else 0)
         nb = int(lib.gdn_fftconv_bwd_workspace_bytes(ref))
         if nb == 0:
             raise GdnError("fftconv: unsupported layer k=%d stride=%d" % (self.k, self.stride))

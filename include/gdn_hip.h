@@ -60,7 +60,16 @@ typedef struct {
     int32_t k, stride, pad;
     int32_t pad_mode;   /* 0 zero padding, 1 reflection padding (Conv2d only) */
     int32_t transposed; /* 0 Conv2d, 1 ConvTranspose2d */
+    int32_t hints;      /* GDN_HINT_* bits; 0 = none.  A hint never changes results beyond rounding, only which internal
+                         * plan a transform-domain path picks; every call of one layer instance (workspace / state queries,
+                         * forward, backward) must carry the same hints. */
 } gdn_conv_geom;
+
+/* GDN_HINT_TRAIN: the layer runs forward AND backward with a weight gradient (a trained layer in train mode).  The
+ * frequency-domain path then tiles for the sum of both passes: 40-point tiles (32 valid outputs of a 9x9 window: 128 x 416
+ * is exactly 4 x 13 of them, 26 % fewer transformed points) shorten the three per-bin GEMM chains of a training step by a
+ * quarter but make the forward's single-pass transforms slower, so inference / frozen layers keep the 32-point tiles. */
+enum { GDN_HINT_TRAIN = 1 };
 
 enum { GDN_ACT_NONE = 0, GDN_ACT_TANH = 1, GDN_ACT_RELU = 2 };   /* bit flags */
 

@@ -30,6 +30,52 @@ CASES = [
 
 @pytest.mark.parametrize("case", CASES, ids=["c%d_%d_k%d_%dx%dx%d" % c for c in CASES])
 def test_fftconv_matches_cpu_conv(gpu, case):
+    _check_case(gpu, case, {})
+
+
+# 40-point tiles (GDN_HINT_TRAIN on the 9x9 / 7x7 layers where they save a fifth of the points; GDN_FFT_NP=40 forces them on
+# any k >= 5 layer): T = 32 / 34 / 36, ragged edges, single tile, exact fit, Cin != Cout
+CASES40 = [
+    (64, 64, 9, 2, 40, 70),
+    (64, 64, 9, 1, 64, 96),          # exactly 2 x 3 tiles of 32
+    (128, 128, 7, 2, 26, 52),
+    (64, 128, 7, 1, 17, 33),
+    (64, 64, 9, 1, 9, 12),           # image smaller than one tile
+    (128, 64, 5, 1, 37, 75),
+]
+
+
+@pytest.mark.parametrize("case", CASES40, ids=["c%d_%d_k%d_%dx%dx%d" % c for c in CASES40])
+def test_fftconv_40_point_tiles(gpu, case, monkeypatch):
+    monkeypatch.setenv("GDN_FFT_NP", "40")
+    _check_case(gpu, case, {"train": True})
+
+
+def test_fftconv_train_hint_picks_its_own_plan(gpu):
+    """The hint only selects the tiling: forward / backward results with and without it agree to rounding, and the saved
+    state of one is not interchangeable with the other (different size)."""
+    from gdn_amd import ops
+    from gdn_amd._lib import lib
+    op = ops.Conv(64, 64, 9, 1, 4)
+    B, H, W = 2, 64, 96
+    s0 = int(lib.gdn_fftconv_spectrum_bytes(op.geom(B, H, W, 0)[1]))
+    s1 = int(lib.gdn_fftconv_spectrum_bytes(op.geom(B, H, W, 1)[1]))
+    assert s0 > 0 and s1 > 0 and s0 != s1
+    x = torch.randn(B, H, W, 64, device=gpu)
+    w = torch.randn(81, 64, 64, device=gpu) * 0.02
+    gy = torch.randn(B, H, W, 64, device=gpu)
+    y0, xf0 = op.fft_fwd(x, w, spectrum=True)
+    y1, xf1 = op.fft_fwd(x, w, spectrum=True, train=True)
+    assert xf0.numel() == s0 and xf1.numel() == s1
+    close(y1, y0, rtol=1e-4, what="forward, 40- vs 32-point tiles")
+    dw0, dw1 = torch.empty_like(w), torch.empty_like(w)
+    dx0 = op.fft_bwd(gy, w, (H, W), xf=xf0, dw_tap=dw0)
+    dx1 = op.fft_bwd(gy, w, (H, W), xf=xf1, dw_tap=dw1, train=True)
+    close(dx1, dx0, rtol=1e-4, what="data gradient")
+    close(dw1, dw0, rtol=1e-4, what="weight gradient")
+
+
+def _check_case(gpu, case, hint):
     from gdn_amd import ops
     ci, co, k, B, H, W = case
     g = torch.Generator().manual_seed(1234 + k + H)
@@ -42,26 +88,26 @@ def test_fftconv_matches_cpu_conv(gpu, case):
     y_ref = F.conv2d(xr, wr, None, 1, k // 2)
     y_ref.backward(gy)
     op = ops.Conv(ci, co, k, 1, k // 2)
-    assert op.fft_ok(B, H, W)
+    assert op.fft_ok(B, H, W, **hint)
     xd, wd = nhwc(x).to(gpu), tapmajor(w, False).to(gpu)
-    y, st, xf = op.fft_fwd(xd, wd, stats=True, spectrum=True)
+    y, st, xf = op.fft_fwd(xd, wd, stats=True, spectrum=True, **hint)
     close(nchw(y), y_ref, what="fwd")
     close(st[:, 0].sum(0), y_ref.detach().sum((0, 2, 3)), rtol=1e-3, atol_scale=1e-3, what="stats sum")
     close(st[:, 1].sum(0), (y_ref.detach() ** 2).sum((0, 2, 3)), what="stats sumsq")
     # residual + eval-BN affine + ReLU epilogue
     sc, sh = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g)
-    y2 = op.fft_fwd(xd, wd, addsrc=nhwc(res).to(gpu), affine=(sc.to(gpu), sh.to(gpu)), act=ops.ACT_RELU)
+    y2 = op.fft_fwd(xd, wd, addsrc=nhwc(res).to(gpu), affine=(sc.to(gpu), sh.to(gpu)), act=ops.ACT_RELU, **hint)
     close(nchw(y2), torch.relu(y_ref.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + res, what="epilogue")
     # backward: both gradients from one transform of dy; dx accumulates onto an incoming gradient
     dw = torch.full_like(wd, 7.0)
-    dx = op.fft_bwd(nhwc(gy).to(gpu), wd, (H, W), xf=xf, dw_tap=dw, addsrc=nhwc(gres).to(gpu))
+    dx = op.fft_bwd(nhwc(gy).to(gpu), wd, (H, W), xf=xf, dw_tap=dw, addsrc=nhwc(gres).to(gpu), **hint)
     close(nchw(dx), xr.grad + gres, what="dgrad")
     close(dw, tapmajor(wr.grad, False), what="wgrad")
     # either gradient alone
-    dx_only = op.fft_bwd(nhwc(gy).to(gpu), wd, (H, W))
+    dx_only = op.fft_bwd(nhwc(gy).to(gpu), wd, (H, W), **hint)
     close(nchw(dx_only), xr.grad, what="dgrad only")
     dw2 = torch.zeros_like(wd)
-    assert op.fft_bwd(nhwc(gy).to(gpu), wd, (H, W), xf=xf, dw_tap=dw2, need_dx=False) is None
+    assert op.fft_bwd(nhwc(gy).to(gpu), wd, (H, W), xf=xf, dw_tap=dw2, need_dx=False, **hint) is None
     assert torch.equal(dw2, dw)
     # and against the direct kernels
     close(y, op.fwd(xd, wd), what="fwd vs direct")

@@ -148,7 +148,13 @@ def test_train_step_vs_real_trainer(gpu, golden, mode):
 
 
 def test_train_step_gradients_vs_oracle(gpu):
-    """Per-parameter gradient tensors (not just norms) on a small DtoD problem."""
+    """Per-parameter gradient tensors (not just norms) on a small DtoD problem.
+
+    The backward starts from the ORACLE's dL/d(out): the BerHu / Sobel terms are L1-type, so their gradient is a sign
+    function of (out - gt), and a 1e-4 difference between two fp32 forwards flips it on a few pixels -- which moves the
+    heavily cancelling sums (a BatchNorm bias gradient of 4 % of the typical norm) by percents whatever the kernels do.
+    (The oracle itself, fp32 against fp64, shows it: 0.5 % on typical parameters.)  dL/d(out) itself is compared in
+    test_train_step_vs_real_trainer; here the subject is the network's backward."""
     import gdn_amd.AE_model_unet as M
     from gdn_amd import utils as U
     depth, rgb, sparse = O.synthetic_batch(1, 32, 64, seed=4)
@@ -159,8 +165,9 @@ def test_train_step_gradients_vs_oracle(gpu):
     model = model.to(gpu).train()
     out = model(depth.to(gpu), istrain=False)
     loss, _, _ = U.dtod_loss(out, depth.to(gpu), sparse.to(gpu))
-    loss.backward()
     assert loss.item() == pytest.approx(ref["loss"], rel=1e-3)
+    close_abs(out, ref["outputs"], 1e-3, what="depth map")
+    out.backward(ref["dout"].to(gpu))
     worst = 0.0
     typical = float(np.median([ref["grads"][k].double().norm().item() for k, _ in model.named_parameters()]))
     for k, p in model.named_parameters():

@@ -188,6 +188,11 @@ template <int NP>
 __device__ __forceinline__ float tw_cos(int idx) { return NP == 40 ? kCos40[idx % 40] : kCos32[(idx & (NP - 1)) * (32 / (NP == 40 ? 32 : NP))]; }
 template <int NP>
 __device__ __forceinline__ float tw_sin(int idx) { return NP == 40 ? kSin40[idx % 40] : kSin32[(idx & (NP - 1)) * (32 / (NP == 40 ? 32 : NP))]; }
+// ... for an index already in [0, NP)
+template <int NP>
+__device__ __forceinline__ float tw_cos_r(int idx) { return NP == 40 ? kCos40[idx] : kCos32[idx * (32 / (NP == 40 ? 32 : NP))]; }
+template <int NP>
+__device__ __forceinline__ float tw_sin_r(int idx) { return NP == 40 ? kSin40[idx] : kSin32[idx * (32 / (NP == 40 ? 32 : NP))]; }
 
 struct FftGeom {
     int np, bins;                // tile size (32 / 16), kept bins = np * (np/2 + 1)
@@ -473,14 +478,19 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
         float gr[K], gi[K];
 #pragma unroll
         for (int ty = 0; ty < K; ++ty) { gr[ty] = 0.f; gi[ty] = 0.f; }
+        int ph[K];                                   // (ky * ty) mod NP, advanced by ty per step: wave-uniform, no division
+#pragma unroll
+        for (int ty = 0; ty < K; ++ty) ph[ty] = 0;
 #pragma unroll 8
         for (int ky = 0; ky < NP; ++ky) {
             const float2 v = F[(size_t)(ky * NK + kx) * bs];
 #pragma unroll
             for (int ty = 0; ty < K; ++ty) {
-                const float cs = tw_cos<NP>(ky * ty), sn = tw_sin<NP>(ky * ty);
+                const float cs = tw_cos_r<NP>(ph[ty]), sn = tw_sin_r<NP>(ph[ty]);
                 gr[ty] += v.x * cs - v.y * sn;
                 gi[ty] += v.x * sn + v.y * cs;
+                ph[ty] += ty;
+                if (ph[ty] >= NP) ph[ty] -= NP;
             }
         }
         const float alpha = (kx == 0 || kx == NP / 2) ? 1.f : 2.f;

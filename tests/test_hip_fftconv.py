@@ -51,10 +51,11 @@ def test_fftconv_40_point_tiles(gpu, case, monkeypatch):
     _check_case(gpu, case, {"train": True})
 
 
-def test_fftconv_train_hint_picks_its_own_plan(gpu):
+def test_fftconv_train_hint_picks_its_own_plan(gpu, monkeypatch):
     """The hint only selects the tiling: forward / backward results with and without it agree to rounding, and the saved
     state of one is not interchangeable with the other (different size)."""
     from gdn_amd import ops
+    monkeypatch.delenv("GDN_FFT_NP", raising=False)
     from gdn_amd._lib import lib
     op = ops.Conv(64, 64, 9, 1, 4)
     B, H, W = 2, 64, 96

@@ -646,6 +646,11 @@ __global__ __launch_bounds__(NP * FFT_CG_OF(NP), NP == 16 ? 4 : 2) void fft2d_fw
         int off_x = ix0 * ldx;                             // running ix * ldx (interior columns: no multiply per element)
         const float is = in_scale ? in_scale[cg + c] : 1.f, it = in_scale ? in_shift[cg + c] : 0.f;
         const float lo = in_relu ? 0.f : -3.402823466e38f;
+        if (a >= nvalid) {
+            // zero-padding rows of a dy tile (whole waves when T is a multiple of four rows): nothing to load or transform
+#pragma unroll
+            for (int kx = 0; kx < NK; ++kx) { re[kx] = 0.f; im[kx] = 0.f; }
+        } else {
         if (up2x) {
             // x is the LOW-resolution tensor [B][H/2][W/2][ldx]; the layer input is its x2 bilinear upsampling
             // (up2x = 1: align_corners False, 2: True), interpolated here from the four neighbours of every element --
@@ -708,6 +713,7 @@ __global__ __launch_bounds__(NP * FFT_CG_OF(NP), NP == 16 ? 4 : 2) void fft2d_fw
             }
         }
         fftn<NP, -1>(re, im);
+        }
 #pragma unroll
         for (int kx = 0; kx < NK; ++kx) lds[(a * NK + kx) * CG + c] = make_float2(re[kx], im[kx]);
     }

@@ -103,6 +103,9 @@ _SIGS = {
 _STATUS_FUNCS = {n for n, (r, _) in _SIGS.items() if r is c_int32} - {"gdn_version", "gdn_device_info"}
 
 EXPORTS = tuple(_SIGS)
+# The C ABI revision these signatures (and ConvGeom's layout) describe: gdn_version() of the library must match exactly --
+# a stale build would take the arguments apart differently.
+ABI_VERSION = 210
 
 
 class _Lib:
@@ -125,6 +128,10 @@ class _Lib:
             fn = getattr(dll, name)      # AttributeError if the symbol is missing: fail loudly
             fn.restype = res
             fn.argtypes = args
+        have = int(dll.gdn_version())
+        if have != ABI_VERSION:
+            raise GdnError("%s implements C ABI revision %d, this package binds revision %d -- rebuild it with "
+                           "`python gdn-pytorch_amd/build.py --force`" % (LIB_PATH, have, ABI_VERSION))
         self._dll = dll
         return dll
 

@@ -40,6 +40,8 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
+/* Revision of this header (argument lists, struct layouts).  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+ * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
 /* Fills name[] with the HIP device name of the current device; returns CU count (<0 on error). */

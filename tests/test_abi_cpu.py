@@ -151,3 +151,14 @@ def test_host_planning_code_under_asan():
                        timeout=600)
     assert r.returncode == 0 and "asan host queries ok" in r.stdout, r.stdout[-2000:] + r.stderr[-6000:]
     assert "AddressSanitizer" not in r.stderr
+
+
+def test_loader_rejects_a_library_of_another_abi_revision(built_lib, monkeypatch):
+    """The ctypes binding describes one revision of the C ABI (argument lists, gdn_conv_geom's layout); a stale build must be
+    refused at load time instead of taking the arguments apart differently."""
+    import gdn_amd._lib as L
+    assert L.lib.gdn_version() == L.ABI_VERSION
+    fresh = L._Lib()
+    monkeypatch.setattr(L, "ABI_VERSION", L.ABI_VERSION + 1)
+    with pytest.raises(L.GdnError, match="revision"):
+        fresh.gdn_version()

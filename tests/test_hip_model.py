@@ -630,3 +630,50 @@ def test_guide_batched_pass_is_bitwise_the_two_forwards(gpu):
     for faithful in (True, False):
         one = T.guide_latent_loss(G, depth, est, faithful=faithful)
         assert torch.equal(one, two), (faithful, float(one), float(two))
+
+
+@pytest.mark.parametrize("mode", ["DtoD", "RtoD"])
+def test_training_step_is_bitwise_reproducible(gpu, mode):
+    """SURVEY 5 (race detection: 'run twice, bit-compare'): two training steps from identical state -- fresh models, same seed,
+    same batch, in one process (so the second run meets workspaces, saved-state buffers and allocator blocks the first one
+    left dirty) -- must agree BITWISE in the loss, the depth map, every parameter gradient, the BatchNorm running statistics
+    and the post-Adam parameters.  A race between the frequency-domain backward's two streams, a read of an uninitialised
+    workspace region or an atomically ordered sum would show here."""
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import optim
+    from gdn_amd import trainer as T
+    from gdn_amd import utils as U
+    H, W, B = 128, 416, 2
+    depth, rgb, sparse = [t.to(gpu) for t in O.synthetic_batch(B, H, W, seed=21)]
+
+    def run():
+        torch.manual_seed(7)
+        if mode == "DtoD":
+            net = M.AutoEncoder_DtoD(input_dim=1, height=H, width=W).to(gpu).train()
+            guide = None
+        else:
+            net = M.AutoEncoder_2(height=H, width=W).to(gpu).train()
+            guide = M.AutoEncoder_DtoD(input_dim=1, height=H, width=W).to(gpu).eval().requires_grad_(False)
+        opt = optim.Adam(net.parameters(), lr=2e-5)
+        if mode == "DtoD":
+            out = net(depth, istrain=False)
+            loss = U.dtod_loss(out, depth, sparse)[0]
+        else:
+            out = net(rgb, istrain=False)
+            lat = T.guide_latent_loss(guide, depth, out)
+            loss = U.rtod_pixel_loss(out, depth, rgb, sparse, plus=lat)[0]
+        opt.zero_grad()
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+        opt.step()
+        torch.cuda.synchronize()
+        state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        return loss.detach().clone(), out.detach().clone(), grads, state
+
+    a, b = run(), run()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert a[2].keys() == b[2].keys() and len(a[2]) > 100
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), "gradient of %s differs between two identical steps" % k
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), "%s differs after two identical steps" % k

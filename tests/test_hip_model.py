@@ -493,6 +493,62 @@ def test_train_step_b20_vs_oracle(gpu):
             assert float((a - b).norm() / b.norm()) < 1e-3, "post-Adam " + k
 
 
+def test_rtod_train_step_b20_vs_oracle(gpu):
+    """The per-GPU workload of BASELINE configs[2] / [3] in fp32: RtoD, batch 20, 128x416, default engine -- R with the
+    frequency-domain / Winograd paths, the x2 upsampling folded into the decoder convolutions, 40-point tiles on its trained
+    9x9 layers; the frozen eval-mode guide in ONE batched encoder-only pass (the trainer's default) -- against the CPU
+    oracle's RtoD training step (two full guide forwards, like the reference) on the same seeded inputs.
+    Bars as in test_train_step_b20_vs_oracle; the latent term 2e-3 relative."""
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import trainer as T
+    from gdn_amd import utils as U
+    from gdn_amd.optim import Adam
+    B = 20
+    depth, rgb, sparse = O.synthetic_batch(B, 128, 416, seed=1)
+    sd = O.init_state_dict("AutoEncoder_2", seed=0)
+    g_sd = O.init_state_dict("AutoEncoder_DtoD", seed=1)
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    torch.set_num_threads(max(1, min(len(__import__("os").sched_getaffinity(0)), 32)))
+    ref = O.train_step("RtoD", ref_sd, (depth, rgb, sparse), {}, g_sd={k: v.clone() for k, v in g_sd.items()})
+    model = M.AutoEncoder_2(input_dim=3)
+    model.load_state_dict(sd)
+    model = model.to(gpu).train()
+    G = M.AutoEncoder_DtoD(input_dim=1)
+    G.load_state_dict(g_sd)
+    G = G.to(gpu).eval().requires_grad_(False)
+    opt = Adam(model.parameters(), 2e-5, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
+    d, r, sp = depth.to(gpu), rgb.to(gpu), sparse.to(gpu)
+    out = model(r, istrain=False)
+    lat = T.guide_latent_loss(G, d, out)
+    loss, ol, sm = U.rtod_pixel_loss(out, d, r, sp, plus=lat)
+    out.retain_grad()
+    opt.zero_grad()
+    loss.backward()
+    assert loss.item() == pytest.approx(ref["loss"], rel=1e-3)
+    assert ol.item() == pytest.approx(ref["output_loss"], rel=1e-3) and sm.item() == pytest.approx(ref["smoothness_loss"], rel=1e-3)
+    assert lat.item() == pytest.approx(ref["latent_loss"], rel=2e-3)
+    close_abs(out, ref["outputs"], 1e-3, what="RtoD B=20 depth map")
+    close(out.grad, ref["dout"], rtol=2e-3, atol_scale=2e-3, what="RtoD B=20 dL/dout", outliers=1e-3)
+    typical = float(np.median([ref["grads"][k].double().norm().item() for k, _ in model.named_parameters()]))
+    worst, worst_k = 0.0, None
+    for k, p in model.named_parameters():
+        gr, rr = p.grad.detach().cpu().double(), ref["grads"][k].double()
+        rel = float((gr - rr).norm() / (rr.norm() + 1e-3 * typical))
+        if rel > worst:
+            worst, worst_k = rel, k
+    print("RtoD B=20 worst per-parameter gradient rel-L2 error %.3e (%s), typical grad norm %.3e; depth map max err %.3e"
+          % (worst, worst_k, typical, float((out.detach().cpu() - ref["outputs"]).abs().max())))
+    assert worst < 2e-2, "%s: relative gradient error %.3e" % (worst_k, worst)
+    opt.step()
+    hip_sd = model.state_dict()
+    for k, v in ref_sd.items():
+        if "running_" in k:
+            close(hip_sd[k], v, rtol=1e-3, atol_scale=1e-3, what="RtoD B=20 " + k)
+        elif v.dim() == 4:
+            a, b = hip_sd[k].detach().cpu().double(), v.double()
+            assert float((a - b).norm() / b.norm()) < 1e-3, "post-Adam " + k
+
+
 def test_train_bn_fusion_matches_unfused(gpu, monkeypatch):
     """Row N1 (north_star 'conv+BN+ReLU fused'): with the train-mode fusion on -- relu(bn1(conv1 x)) applied in conv2's
     patch loader, BatchNorm-backward reductions emitted by the data-gradient epilogues -- the step must equal the unfused

@@ -374,9 +374,11 @@ def test_bf16_odd_shapes_train_step(gpu, name, B, H, W):
     assert losses[1] == pytest.approx(losses[0], rel=5e-2)
 
 
-def test_bf16_rtod_vs_emulation(gpu):
+@pytest.mark.parametrize("B", [2, 20])
+def test_bf16_rtod_vs_emulation(gpu, B):
     """BASELINE configs[2] (RtoD, bf16) at network level against the ORACLE: AutoEncoder_2 (bilinear upsample, concat 1x1,
-    reflection-padded decoder ConvBlocks, smoothness loss) + the frozen eval-mode guide, B = 2, 128x416, one RtoD step.
+    reflection-padded decoder ConvBlocks, smoothness loss) + the frozen eval-mode guide, 128x416, one RtoD step, at B = 2 and
+    at the configuration's own batch 20 (tile, split-K and BatchNorm-partial plans differ with the batch).
     The reference for a bf16 implementation is oracle.bf16_emulation(): the reference's fp32 CPU arithmetic with every
     tensor the HIP path stores as bfloat16 rounded where it is stored.  Two roundings of the same tensors still differ by
     summation order -- and a 1-ulp bf16 flip (2^-8) is amplified like any other perturbation -- so bars are stated per
@@ -391,7 +393,7 @@ def test_bf16_rtod_vs_emulation(gpu):
     import gdn_amd.AE_model_unet as M
     from gdn_amd import utils as U
     from oracle import gdn_oracle as O
-    depth, rgb, sparse = O.synthetic_batch(2, 128, 416, seed=0)
+    depth, rgb, sparse = O.synthetic_batch(B, 128, 416, seed=0)
     sd_r = O.init_state_dict("AutoEncoder_2", seed=0)
     sd_g = O.init_state_dict("AutoEncoder_DtoD", seed=1)
     cl = lambda d: {k: v.clone() for k, v in d.items()}

@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
 """Headline benchmark: training images/s of the GDN hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Without a launcher environment (RANK unset) ``--gpus N`` with N > 1 starts N fresh rank processes itself (one per GPU,
+`distributed.launch_ranks`: the parent never touches the GPU, forwards rank 0's JSON line as the last line of its own
+stdout and exits with the first non-zero child code) -- the reference trains on N GPUs from ONE command
+(GDN_main.py:24,150-173, `--gpu_num 0,1,2,3` + nn.DataParallel).  Under torch.distributed.run the ranks are the launcher's;
+``--gpus`` must then equal WORLD_SIZE (anything else is an error, rc 2).
 
 A "step" is one full training step of BASELINE.json's configs[1]: DtoD mode
 (AutoEncoder_DtoD forward, BerHu + 3*Sobel loss, backward, fused Adam), batch 20
@@ -177,13 +183,17 @@ def cpu_baseline(batch=20):
 
 def step_mfma_util():
     """Whole-step MFMA utilisation from the committed rocprofv3 PMC pass over training steps of this workload
-    (tools/pmc_step.sh -> profiles/r02_step_mfma_util.json): sum SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x GRBM_GUI_ACTIVE).
-    Counters cannot be read from inside the timed process, so the bench line carries the committed figure (None if absent)."""
-    f = ROOT / "profiles" / "r02_step_mfma_util.json"
+    (tools/pmc_step.sh -> profiles/rNN_step_mfma_util.json, newest round): sum SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x
+    GRBM_GUI_ACTIVE).  Counters cannot be read from inside the timed process, so the bench line carries the committed figure
+    together with the commit it was collected at (`collected_at`: a replay of a file, not a live measurement); None if absent."""
+    files = sorted((ROOT / "profiles").glob("r[0-9][0-9]_step_mfma_util.json"))
+    if not files:
+        return None
+    f = files[-1]
     try:
         d = json.loads(f.read_text())
-        return {"mfma_util_pct": d["mfma_util_pct"], "source": "profiles/" + f.name, "steps": d.get("steps"),
-                "note": d.get("note")}
+        return {"mfma_util_pct": d["mfma_util_pct"], "source": "profiles/" + f.name, "collected_at": d.get("collected_at"),
+                "live": False, "steps": d.get("steps"), "note": d.get("note")}
     except Exception:  # noqa: BLE001
         return None
 
@@ -194,6 +204,11 @@ def infer_main(args):
     import gdn_amd.AE_model_unet as M
     from gdn_amd import distributed as D
     rank, local_rank, world = D.init()
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher environment has WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return 2
     dev = torch.device("cuda", 0 if os.environ.get("GDN_SINGLE_DEVICE") == "1" else local_rank)   # (test hook: all ranks on one GPU)
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
@@ -246,6 +261,7 @@ def infer_main(args):
                "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+               "rccl_ranks": dist_info()[0], "dist_backend": dist_info()[1],
                "config": {"workload": "legacy AutoEncoder eval forward, batch %d per GPU, 256x832, %s, %s, "
                                       "BASELINE configs[4]" % (B, args.dtype, "hipGraph replay" if graph is not None else "eager"),
                           "global_batch": B * world, "parallelism": "dp%d" % world,
@@ -369,15 +385,17 @@ def other_configs(dev, B, depth, rgb, sparse):
             out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         gc.collect()
         torch.cuda.empty_cache()
-    try:
-        ms, chk = infer_measure(dev, 64, "fp32", 3, 1, graph=True)
-        out["infer_b64_graph"] = {"workload": "legacy AutoEncoder eval forward, batch 64, 256x832, fp32, hipGraph replay, "
-                                              "BASELINE configs[4]", "ms_per_step": round(ms, 3),
-                                  "value": round(64 / ms * 1e3, 2), "unit": "images/s", "steps": 3, "warmup": 1}
-    except Exception as e:  # noqa: BLE001
-        out["infer_b64_graph"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    gc.collect()
-    torch.cuda.empty_cache()
+    for key, dt in (("infer_b64_graph", "fp32"), ("infer_b64_graph_bf16", "bf16")):
+        try:
+            ms, chk = infer_measure(dev, 64, dt, 3, 1, graph=True)
+            out[key] = {"workload": "legacy AutoEncoder eval forward, batch 64, 256x832, %s, hipGraph replay, "
+                                    "BASELINE configs[4]" % dt, "ms_per_step": round(ms, 3),
+                        "value": round(64 / ms * 1e3, 2), "unit": "images/s", "steps": 3, "warmup": 1,
+                        "out_checksum": round(chk, 6)}
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        gc.collect()
+        torch.cuda.empty_cache()
     return out
 
 
@@ -411,6 +429,67 @@ def infer_measure(dev, B, dtype, steps, warmup, graph=True, seed=0):
     return ms, float(o.double().abs().mean().item())
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) as a plain command: start N fresh child processes of this script, one per GPU,
+    BEFORE anything here touches the GPU (counting devices does not), wait, forward rank 0's stdout (its last line is the
+    JSON record) and return the first non-zero child exit code."""
+    from gdn_amd import distributed as D
+    n = args.gpus
+    single = os.environ.get("GDN_SINGLE_DEVICE") == "1"          # test hook: every rank on GPU 0 (gloo backend)
+    if args.selftest_launch:
+        devices = [None] * n
+    else:
+        have = torch.cuda.device_count()
+        need = 1 if single else n
+        if have < need:
+            print("bench.py: --gpus %d asked for but %d GPU(s) are visible on this machine (HIP_VISIBLE_DEVICES=%s); "
+                  "nothing was launched" % (n, have, os.environ.get("HIP_VISIBLE_DEVICES")), file=sys.stderr)
+            return 2
+        devices = [None] * n if single else list(range(n))
+    rc, text = D.launch_ranks(argv, devices, script=str(pathlib.Path(__file__).resolve()), capture_rank0=True)
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    if rc != 0:
+        print("bench.py: a rank exited with code %d" % rc, file=sys.stderr)
+    return rc
+
+
+def dist_info():
+    """(ranks, backend) of the process group the gradient all-reduce runs on ("nccl" is RCCL on ROCm)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), str(dist.get_backend())
+    return 1, None
+
+
+def launch_selftest(args):
+    """--selftest-launch: the rank plumbing of a self-launched job without any GPU work (CPU test of the launcher: gloo,
+    world size 2): join the group, all-reduce a token, rank 0 prints a record that is labelled as no measurement."""
+    from gdn_amd import distributed as D
+    import torch.distributed as dist
+    rank, local_rank, world = D.init(backend=os.environ.get("GDN_DIST_BACKEND") or "gloo")
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world), file=sys.stderr)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return 2
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    print("rank %d of %d up (selftest)" % (rank, world), file=sys.stderr)
+    flush_c_stdio()
+    if rank == 0:
+        ranks, backend = dist_info()
+        print(json.dumps({"metric": "launch selftest (no GPU work, not a measurement)", "value": None, "unit": None,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "rccl_ranks": ranks,
+                          "dist_backend": backend, "token_sum": float(t.item()),
+                          "spawned": os.environ.get("GDN_SPAWNED") == "1"}), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -432,9 +511,18 @@ def main():
                          "master weights/BN statistics/losses/Adam). The headline line is fp32 DtoD.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)   # CPU test of the self-launcher
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short RtoD fp32 / RtoD bf16 / inference measurements appended as other_configs (N=1 only)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # one command, N GPUs: this process becomes the launcher and never touches the GPU
+        return self_launch(args, sys.argv[1:])
+    if args.selftest_launch:
+        return launch_selftest(args)
 
     from gdn_amd import distributed as D
     from gdn_amd.synthetic import synthetic_batch
@@ -442,8 +530,14 @@ def main():
     if args.mode == "infer":
         return infer_main(args)
     rank, local_rank, world = D.init()
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        # a --gpus that the launcher did not honour would report one GPU's throughput as N GPUs': refuse
+        print("bench.py: --gpus %d but the launcher environment has WORLD_SIZE %d (rank %d); start it as "
+              "`python bench.py --gpus N` or under torch.distributed.run with --nproc-per-node N" % (args.gpus, world, rank),
+              file=sys.stderr)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return 2
     dev = torch.device("cuda", 0 if os.environ.get("GDN_SINGLE_DEVICE") == "1" else local_rank)   # (test hook: all ranks on one GPU)
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
@@ -484,8 +578,9 @@ def main():
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+            "rccl_ranks": dist_info()[0], "dist_backend": dist_info()[1],
             "config": {"workload": "%s training step (fwd + losses + bwd + fused Adam), batch %d per GPU, 128x416, "
-                                   "%s, BASELINE configs[%d]" % (args.mode, B, args.dtype, 1 if args.mode == "DtoD" else 2),
+                                   "%s, BASELINE configs[%d]" % (args.mode, B, args.dtype, 1 if args.mode == "DtoD" else (3 if world > 1 else 2)),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "launch": "hipGraph replay of the whole step" if graphed is not None else "eager",
                        "direct_conv_equiv_tflops_per_gpu": round(gflop_img * B * args.steps / dt / 1e3, 2),
@@ -542,4 +637,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

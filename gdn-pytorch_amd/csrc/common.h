@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/gdn_hip.h"
 
 #define GDN_WAVE 64
@@ -12,6 +13,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static inline int gdn_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GDN_OK : GDN_ERR_LAUNCH;
+}
+
+// GDN_PLAN_BATCH=<n> (test / measurement override, read per call): every plan that depends on the batch size -- the
+// frequency-domain tile size, the direct kernels' tile configuration and split-K factor -- is chosen as if the batch were n.
+// With it a batch-1 run takes the plans of a batch-n run, so an image's result can be compared BITWISE across batch sizes
+// (tests/test_hip_robustness.py::test_legacy_inference_b64_graph_matches_single_image).
+static inline int gdn_plan_batch(int B) {
+    const char* e = getenv("GDN_PLAN_BATCH");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : B;
 }
 
 __host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -856,7 +856,7 @@ bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
     // waste of T = 28, the per-bin GEMMs get M = 540 rows instead of 160 (measured: forward GEMM -31 %, step -1.7 ms).
     {
         const int t32 = 33 - g->k;
-        const long m32 = (long)g->B * cdiv(g->H, t32) * cdiv(g->W, t32);
+        const long m32 = (long)gdn_plan_batch(g->B) * cdiv(g->H, t32) * cdiv(g->W, t32);
         f.np = (g->k <= 5 && 3L * g->Cout > 2 * m32) ? 16 : 32;
         // 40-point tiles for a TRAINED layer (GDN_HINT_TRAIN) where they cut the transformed points by at least a fifth -- the
         // 9x9 layers at 128 x 416: T = 32 tiles the image exactly, 4 x 13 x 1600 points against 6 x 18 x 1024 -- and the weight

@@ -1021,8 +1021,11 @@ int pick_cfg_f32(int64_t M, int N, bool scalar, int forced) {
 
 #define CFG_BF16 0x10000     // GDN_CFG_BF16 in tile_cfg: tensors hold bf16
 int64_t max_phase_m(const IgemmParams& P);
+// the row count the PLANS (tile configuration, split-K factor) are chosen for: the launch's own, unless GDN_PLAN_BATCH
+// overrides the batch size (common.h)
+int64_t plan_phase_m(const IgemmParams& P) { return max_phase_m(P) / P.B * gdn_plan_batch(P.B); }
 int pick_cfg(const IgemmParams& P, int N, bool scalar, int tile_cfg) {
-    const int64_t M = max_phase_m(P);
+    const int64_t M = plan_phase_m(P);
     return (tile_cfg & CFG_BF16) ? pick_cfg_bf16(P, M, N, tile_cfg & 0xff) : pick_cfg_f32(M, N, scalar, tile_cfg & 0xff);
 }
 
@@ -1102,7 +1105,7 @@ void launch_one(const IgemmParams& P, hipStream_t st) {
 int pick_ksplit(const IgemmParams& P, int cfg, bool scalar, int tile_cfg) {
     if (scalar || (P.N % 4) || cfg == 4 || cfg >= 8 || (tile_cfg & 0x800)) return 1;
     const TileCfg tc = kCfg[cfg];
-    const int64_t blocks = cdiv64(cdiv64(max_phase_m(P), tc.bm), 8) * 8 * cdiv(P.N, tc.bn) * P.nphase;
+    const int64_t blocks = cdiv64(cdiv64(plan_phase_m(P), tc.bm), 8) * 8 * cdiv(P.N, tc.bn) * P.nphase;
     if (blocks >= 1200 && !(tile_cfg & 0x400)) return 1;      // measured: splitting only pays below ~one round of resident workgroups (0x400: tuning override)
     int min_taps = MAX_TAPS;
     for (int i = 0; i < P.nphase; ++i) {

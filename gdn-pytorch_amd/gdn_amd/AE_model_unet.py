@@ -104,7 +104,10 @@ class _Bridge(torch.autograd.Function):
         trainable = any(p.requires_grad for p in fctx.gdn_module.parameters())
         pending = arena.bind_grads() if trainable else []      # a frozen network (the guide) only passes dx through
         red = getattr(fctx.gdn_module, "_gdn_reducer", None)
-        if red is not None and red.arena is arena and not pending:
+        # the overlapped reducer hands buckets to async all-reduces while the tape is still running; a carried gradient
+        # (backward without zero_grad: finish_grads adds it to the arena AFTER the tape) or a caller-owned .grad would be
+        # added behind those reductions' backs -- then sync_gradients reduces the whole arena after finish_grads instead
+        if red is not None and red.arena is arena and not pending and not getattr(arena, "_bound_before", None):
             red.begin()
             ctx.reducer = red
         for o, g in zip(outs, gouts):

@@ -196,51 +196,135 @@ def allreduce_max_scalar(t):
 # The reference's multi-GPU idiom: `python GDN_main.py DATA --gpu_num 0,1,2,3` (README.md:82, GDN_main.py:24,150-173)
 # trains on four GPUs from ONE command (nn.DataParallel).  Here that command becomes one process per listed device.
 # ----------------------------------------------------------------------------
-def _free_port():
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+def _host_store(world):
+    """The rendezvous store of a self-launched job, hosted by the PARENT on a port the kernel picks (port 0): no window
+    between choosing a free port and rank 0 binding it.  The children connect as clients (torch's env:// rendezvous does
+    that for every rank when TORCHELASTIC_USE_AGENT_STORE=True -- what torch.distributed.run's agent sets).  CPU only: the
+    parent never touches the GPU."""
+    from datetime import timedelta
+    store = dist.TCPStore("127.0.0.1", 0, world, is_master=True, timeout=timedelta(seconds=1800), wait_for_workers=False)
+    return store, store.port
 
 
-def launch_ranks(argv, devices, module="gdn_amd.GDN_main", extra_env=None, timeout=None):
-    """Start one fresh child process per entry of `devices` running ``python -m <module> <argv>`` with
-    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, wait for all of them and return the first non-zero exit code (0 if
-    all succeeded; the others are terminated as soon as one fails).  The parent must not have touched the GPU: the
-    children are started with subprocess (fork + exec of a new interpreter), never by exec-ing over an initialised
-    process.  LOCAL_RANK indexes the visible-device list, which is set to exactly `devices` for every child (RCCL needs
-    to see its peers' devices for xGMI peer access)."""
+def visible_devices(devices):
+    """HIP_VISIBLE_DEVICES for the children of launch_ranks.  `devices` index the devices THIS process may use: if the
+    scheduler already restricted them (HIP_VISIBLE_DEVICES set), the list is mapped through that restriction instead of
+    overwriting it with indices that would name someone else's GPUs; an index beyond it is refused."""
+    devices = [str(d) for d in devices]
+    outer = os.environ.get("HIP_VISIBLE_DEVICES")
+    if outer is None or outer.strip() == "":
+        return ",".join(devices)
+    allowed = [d.strip() for d in outer.split(",") if d.strip() != ""]
+    mapped = []
+    for d in devices:
+        if not d.isdigit() or int(d) >= len(allowed):
+            raise RuntimeError("device %s requested but HIP_VISIBLE_DEVICES=%s exposes only %d device(s)"
+                               % (d, outer, len(allowed)))
+        mapped.append(allowed[int(d)])
+    return ",".join(mapped)
+
+
+def _stop(procs, grace=5.0):
+    """terminate -> wait -> kill for every child still alive (each child leads its own session / process group, so its own
+    helpers go with it)."""
+    import signal
+    import time
+    alive = [p for p in procs if p.poll() is None]
+    for p in alive:
+        try:
+            os.killpg(p.pid, signal.SIGTERM)
+        except (ProcessLookupError, PermissionError, OSError):
+            p.terminate()
+    t0 = time.time()
+    while alive and time.time() - t0 < grace:
+        alive = [p for p in alive if p.poll() is None]
+        time.sleep(0.05)
+    for p in alive:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError, OSError):
+            p.kill()
+    for p in procs:
+        try:
+            p.wait(timeout=grace)
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def launch_ranks(argv, devices, module="gdn_amd.GDN_main", extra_env=None, timeout=None, script=None, capture_rank0=False):
+    """Start one fresh child process per entry of `devices` running ``python -m <module> <argv>`` (or ``python <script>
+    <argv>``) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, wait for all of them and return the first non-zero exit
+    code (0 if all succeeded; the others are stopped as soon as one fails).  The parent must not have touched the GPU:
+    the children are started with subprocess (fork + exec of a new interpreter), never by exec-ing over an initialised
+    process.  LOCAL_RANK indexes the visible-device list, which is set to exactly `devices` (mapped through an outer
+    HIP_VISIBLE_DEVICES restriction) for every child: RCCL needs to see its peers' devices for xGMI peer access.
+
+    capture_rank0: rank 0's stdout is piped and returned as text -> (rc, text); the other ranks' stdout goes to this
+    process's stderr, so a caller can forward rank 0's result line as the last line of its own stdout.
+
+    Whatever ends the wait -- success, a failed rank, the timeout, an exception, SIGINT / SIGTERM in the parent -- no child
+    survives it: terminate, a grace period, then kill (each child is a session leader, signalled as a group)."""
+    import signal
     import subprocess
     import sys
+    import threading
     import time
     world = len(devices)
-    port = _free_port()
-    procs = []
-    for r in range(world):
-        env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
-                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
-        if devices and all(d is not None for d in devices):
-            env["HIP_VISIBLE_DEVICES"] = ",".join(str(d) for d in devices)
-        env["GDN_SPAWNED"] = "1"
-        if extra_env:
-            env.update(extra_env)
-        procs.append(subprocess.Popen([sys.executable, "-m", module, *argv], env=env))
-    rc, t0 = 0, time.time()
-    alive = list(procs)
-    while alive:
-        for pr in list(alive):
-            code = pr.poll()
-            if code is None:
-                continue
-            alive.remove(pr)
-            if code != 0 and rc == 0:
-                rc = code
-                for other in alive:               # a dead rank would leave the others hanging in a collective
-                    other.terminate()
-        if timeout is not None and time.time() - t0 > timeout and alive:
-            for other in alive:
-                other.kill()
-            rc = rc or 124
-        time.sleep(0.05)
-    return rc
+    vis = visible_devices(devices) if devices and all(d is not None for d in devices) else None
+    store, port = _host_store(world)
+    procs, rank0_out, reader = [], [], None
+    prev = {}
+
+    def on_signal(signum, _frame):
+        raise KeyboardInterrupt("signal %d" % signum)
+
+    in_main = threading.current_thread() is threading.main_thread()
+    if in_main:
+        for sg in (signal.SIGTERM, signal.SIGINT):
+            prev[sg] = signal.signal(sg, on_signal)
+    rc = 0
+    try:
+        for r in range(world):
+            env = dict(os.environ)
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                        "MASTER_PORT": str(port), "TORCHELASTIC_USE_AGENT_STORE": "True",
+                        "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+            if vis is not None:
+                env["HIP_VISIBLE_DEVICES"] = vis
+            env["GDN_SPAWNED"] = "1"
+            if extra_env:
+                env.update(extra_env)
+            cmd = [sys.executable, script, *argv] if script else [sys.executable, "-m", module, *argv]
+            out = None
+            if capture_rank0:
+                out = subprocess.PIPE if r == 0 else sys.stderr
+            procs.append(subprocess.Popen(cmd, env=env, stdout=out, start_new_session=True))
+        if capture_rank0:
+            def pump():
+                for line in procs[0].stdout:
+                    rank0_out.append(line.decode("utf-8", "replace"))
+            reader = threading.Thread(target=pump, daemon=True)
+            reader.start()
+        t0 = time.time()
+        alive = list(procs)
+        while alive:
+            for pr in list(alive):
+                code = pr.poll()
+                if code is None:
+                    continue
+                alive.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code     # killed by signal n: the shell's 128 + n
+                    _stop(alive)                      # a dead rank would leave the others hanging in a collective
+            if timeout is not None and time.time() - t0 > timeout and alive:
+                _stop(alive, grace=1.0)
+                rc = rc or 124
+            time.sleep(0.05)
+    finally:
+        _stop(procs)
+        if reader is not None:
+            reader.join(timeout=5.0)
+        for sg, h in prev.items():
+            signal.signal(sg, h)
+        del store
+    return (rc, "".join(rank0_out)) if capture_rank0 else rc

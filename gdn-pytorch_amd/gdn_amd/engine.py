@@ -258,11 +258,19 @@ class Ctx:
         self.tape = None      # drop the saved activations
 
 
+def _chan_slice(t):
+    """True for a pure channel slice of a dense NHWC buffer: channel stride 1, one pixel pitch, rows and images laid out
+    back to back at that pitch -- the only non-contiguous shape gdn_add_pitched addresses correctly (a spatial crop or a
+    strided batch view has other row / image strides and takes the generic copy)."""
+    return (t.dim() == 4 and t.shape[3] % 4 == 0 and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2)
+            and t.stride(0) == t.shape[1] * t.stride(1))
+
+
 def _dense(t):
     """Dense copy of a channel-slice view (the gradient of a torch.cat half); contiguous tensors pass through."""
     if t.is_contiguous():
         return t
-    if t.dim() == 4 and t.shape[3] % 4 == 0 and t.stride(3) == 1:
+    if _chan_slice(t):
         return ops.add_pitched(t)
     out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
     out.copy_(t)
@@ -272,7 +280,7 @@ def _dense(t):
 def _add(a, b, out_dtype):
     if a.is_contiguous() and b.is_contiguous():
         return ops.add(a, b, out_dtype=out_dtype)
-    if a.dim() == 4 and a.shape[3] % 4 == 0 and a.stride(3) == 1 and b.stride(3) == 1:
+    if _chan_slice(a) and _chan_slice(b):
         return ops.add_pitched(a, b, out_dtype=out_dtype)
     return ops.add(_dense(a), _dense(b), out_dtype=out_dtype)
 

@@ -66,6 +66,28 @@ class Adam(torch.optim.Optimizer):
             ops.adam_step(pdata, grad, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"],
                           st["step"], self.grad_scale)
 
+    def _step_partial(self, ar, st, group):
+        if self.capturable:
+            raise GdnError("capturable Adam needs a gradient for every parameter of the arena (its step counter is one device "
+                           "scalar); a partially covered step cannot be captured")
+        if st["pstep"] is None:
+            st["pstep"] = {id(p): st["step"] for p, _, _, _ in ar.items}
+        b1, b2 = group["betas"]
+        for p, o, n, tr in ar.items:
+            if p.grad is None:
+                continue
+            g = p.grad
+            gslice = ar.grad[o:o + n]
+            if g.data_ptr() != gslice.data_ptr():
+                # a caller-owned gradient: bring it into the parameter's physical (tap-major) order
+                gslice = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
+            st["pstep"][id(p)] += 1
+            ops.adam_step(ar.data[o:o + n], gslice, st["m"][o:o + n], st["v"][o:o + n], group["lr"], b1, b2, group["eps"],
+                          group["weight_decay"], st["pstep"][id(p)], self.grad_scale)
+        counts = set(st["pstep"].values())
+        if len(counts) == 1:              # everyone level again: back to the one-launch update
+            st["step"], st["pstep"] = counts.pop(), None
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -81,18 +103,22 @@ class Adam(torch.optim.Optimizer):
                     continue
                 if all(p.grad is None for p in ps):
                     continue              # nothing ran backward for this model: skip it, like torch.optim.Adam
-                if any(p.grad is None for p in ps):
-                    # part of the model got no gradient this step (frozen sub-modules, an unused branch): torch.optim.Adam
-                    # skips those parameters, and so does the per-tensor path below -- the one-launch arena update would
-                    # apply weight decay and stale moments to them
-                    loose.extend(p for p in ps if p.grad is not None)
-                    continue
                 st = self._flat.get(id(ar))
                 if st is None:
-                    st = {"m": ops.zeros((ar.numel,), ar.device), "v": ops.zeros((ar.numel,), ar.device), "step": 0}
+                    # ONE state store per arena: flat moments; `pstep` is None while every parameter has taken the same
+                    # number of steps (st["step"]) and becomes a per-parameter count once coverage has been partial
+                    st = {"m": ops.zeros((ar.numel,), ar.device), "v": ops.zeros((ar.numel,), ar.device), "step": 0,
+                          "pstep": None}
                     self._flat[id(ar)] = st
-                st["step"] += 1
-                self._apply(ar.data, ar.grad, st, group, ar.device)
+                if st["pstep"] is None and all(p.grad is not None for p in ps):
+                    st["step"] += 1
+                    self._apply(ar.data, ar.grad, st, group, ar.device)
+                else:
+                    # part of the model got no gradient this step (frozen sub-modules, an unused branch): torch.optim.Adam
+                    # skips those parameters -- the one-launch update would apply weight decay and stale moments to them.
+                    # The others are updated per tensor ON SLICES OF THE SAME FLAT MOMENTS with their own step counts, so a
+                    # parameter never alternates between two sets of moments when coverage changes between steps.
+                    self._step_partial(ar, st, group)
                 ar.touch()        # the kernel wrote the parameters behind torch's back: bf16 shadows are stale
             for p in loose:
                 if p.grad is None:

@@ -129,8 +129,10 @@ def guide_latent_loss(G, depths, outputs, faithful=False, latent_grad=False):
 
     Default (the reference as shipped, F3): both under no_grad, value only.
     faithful=True runs the guide exactly like the reference: two full forwards with ``istrain=True``.
-    Otherwise the four features come from encoder-only passes (bit-identical, 52 % of the work); without
-    latent_grad the frozen eval-mode guide has no cross-sample coupling, so both inputs share ONE batched pass.
+    Otherwise the four features come from encoder-only passes (the same layers: 52 % of the work); without
+    latent_grad the frozen eval-mode guide has no cross-sample coupling, so both inputs share ONE batched pass (the
+    library picks tilings / split factors from the batch size, so a 2B pass equals two B passes to rounding, bitwise only
+    where the plans coincide; its peak activation memory is that of a 2B forward).
     latent_grad=True is the guided training the paper describes: the estimate's features keep their autograd
     history, so d(latent)/d(outputs) flows back through the frozen, eval-mode G into the trained network."""
     feats = (lambda x: G(x, istrain=True)[:4]) if faithful or not hasattr(G, "guide_features") else G.guide_features
@@ -147,8 +149,9 @@ def guide_latent_loss(G, depths, outputs, faithful=False, latent_grad=False):
             ft = feats(outputs.detach())
         else:
             # eval-mode guide: no cross-sample coupling, so the two forwards share ONE pass over the concatenated batch --
-            # element for element the same arithmetic, half the launches, the weight transforms computed once.  `faithful`
-            # still runs the whole network (decoder included) like the reference; otherwise the pass stops at the bottleneck.
+            # the same per-sample arithmetic up to the summation order of batch-size-dependent plans, half the launches, the
+            # weight transforms computed once.  `faithful` still runs the whole network (decoder included) like the
+            # reference; otherwise the pass stops at the bottleneck.
             B = depths.shape[0]
             both = feats(_cat_batch(depths, outputs.detach()))
             ft_tar = [f[:B] for f in both]

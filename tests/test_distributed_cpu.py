@@ -175,3 +175,79 @@ def test_rank_sharded_loader_order():
     assert len(set(flat)) == 100 and set(flat) <= set(ds)
     single = GpuAugmentLoader(ds, 5, "cpu", train=True, seed=7, order_seed=99)._epoch_order()
     assert sorted(single) == ds and [single[r::4][:25] for r in range(4)] == orders
+
+
+def _run_bench(args, env_extra=None, drop=("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(root / "bench.py"), *args], env=env, capture_output=True, text=True, timeout=300)
+
+
+@pytest.mark.timeout(400)
+def test_bench_gpus_n_self_launches_ranks_gloo():
+    """`python bench.py --gpus 2` as a plain command (no launcher environment) starts two fresh rank processes itself --
+    the reference's one-command multi-GPU idiom (GDN_main.py:24,150-173) applied to the program the driver runs for the
+    scaling curve -- and forwards rank 0's JSON record as the LAST line of its own stdout.  (--selftest-launch: the rank
+    plumbing without GPU work; gloo.)"""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--selftest-launch"], {"GDN_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    rec = json.loads(lines[-1])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["dist_backend"] == "gloo"
+    assert rec["token_sum"] == 3.0 and rec["spawned"] is True and rec["steps"] == 3
+    assert "rank 1 of 2 up" in r.stderr                      # the other rank ran too, and its output stayed off stdout
+
+
+def test_bench_gpus_mismatch_is_an_error():
+    """--gpus N that the launcher environment does not honour is rc 2 with a message, not a warning; and asking for more
+    GPUs than the machine has fails before anything is launched, naming the device count."""
+    r = _run_bench(["--gpus", "2", "--selftest-launch"], {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"}, drop=())
+    assert r.returncode == 2 and "WORLD_SIZE is 1" in r.stderr and r.stdout.strip() == ""
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+        assert r.returncode == 2 and "%d GPU(s) are visible" % torch.cuda.device_count() in r.stderr
+        assert r.stdout.strip() == ""
+
+
+def test_visible_devices_maps_through_an_outer_restriction(monkeypatch):
+    """launch_ranks must not overwrite a scheduler's HIP_VISIBLE_DEVICES with raw indices: the requested
+    devices index the visible list; an index beyond it is refused."""
+    import pathlib
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "gdn-pytorch_amd"))
+    from gdn_amd import distributed as D
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    assert D.visible_devices(["0", "1", "2"]) == "0,1,2"
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,6,7")
+    assert D.visible_devices([0, 1]) == "4,5" and D.visible_devices(["3", "0"]) == "7,4"
+    with pytest.raises(RuntimeError, match="exposes only 4"):
+        D.visible_devices(["4"])
+
+
+def test_launch_ranks_leaves_no_child_behind_on_timeout(tmp_path):
+    """The wait loop's timeout (like an exception or a signal in the parent) ends every child: terminate, then kill."""
+    import pathlib
+    import subprocess
+    import sys
+    import time
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "gdn-pytorch_amd"))
+    from gdn_amd import distributed as D
+    script = tmp_path / "sleeper.py"
+    script.write_text("import os, sys, time, signal\n"
+                      "signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"          # needs the kill escalation
+                      "open(sys.argv[1] + '/pid%s' % os.environ['RANK'], 'w').write(str(os.getpid()))\n"
+                      "time.sleep(600)\n")
+    t0 = time.time()
+    rc = D.launch_ranks([str(tmp_path)], [None, None], script=str(script), timeout=3)
+    assert rc == 124 and time.time() - t0 < 60
+    for r in range(2):
+        pid = int((tmp_path / ("pid%d" % r)).read_text())
+        assert subprocess.run(["kill", "-0", str(pid)], capture_output=True).returncode != 0, "rank %d survived" % r

@@ -470,6 +470,11 @@ def test_train_step_b20_vs_oracle(gpu):
     assert loss.item() == pytest.approx(ref["loss"], rel=1e-3)
     assert ol.item() == pytest.approx(ref["output_loss"], rel=1e-3) and gl.item() == pytest.approx(ref["gradient_loss"], rel=1e-3)
     close_abs(out, ref["outputs"], 1e-3, what="B=20 depth map")
+    # the maximum over 1 M pixels wanders with the summation order of the day (5-8e-4, most of it the REFERENCE's own fp32
+    # rounding: DESIGN 4); the rms is stable to three digits (4.1-4.3e-5) and is what catches a real regression under it
+    d = (out.detach().cpu().double() - ref["outputs"].double())
+    rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
+    assert rms <= 6e-5, "B=20 depth map rms error %.3e > 6e-5 (max %.3e)" % (rms, mx)
     close(out.grad, ref["dout"], rtol=2e-3, atol_scale=2e-3, what="B=20 dL/dout", outliers=1e-3)
     typical = float(np.median([ref["grads"][k].double().norm().item() for k, _ in model.named_parameters()]))
     worst, worst_k = 0.0, None
@@ -478,8 +483,8 @@ def test_train_step_b20_vs_oracle(gpu):
         rel = float((gr - rr).norm() / (rr.norm() + 1e-3 * typical))
         if rel > worst:
             worst, worst_k = rel, k
-    print("B=20 worst per-parameter gradient rel-L2 error %.3e (%s), typical grad norm %.3e; depth map max err %.3e"
-          % (worst, worst_k, typical, float((out.detach().cpu() - ref["outputs"]).abs().max())))
+    print("B=20 worst per-parameter gradient rel-L2 error %.3e (%s), typical grad norm %.3e; depth map max err %.3e rms %.3e"
+          % (worst, worst_k, typical, mx, rms))
     assert worst < 2e-2, "%s: relative gradient error %.3e" % (worst_k, worst)
     opt.step()
     hip_sd = model.state_dict()
@@ -491,6 +496,30 @@ def test_train_step_b20_vs_oracle(gpu):
         elif v.dim() == 4:
             a, b = hip_sd[k].detach().cpu().double(), v.double()
             assert float((a - b).norm() / b.norm()) < 1e-3, "post-Adam " + k
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_forward_b20_depth_map_vs_oracle_two_seeds(gpu, seed):
+    """The forward half of the benchmarked configuration on two independent draws (weights AND batch), so the depth-map
+    margin is not one sample deep: max|err| <= 1e-3 (the north-star bar) and rms <= 6e-5 against the CPU oracle's
+    train-mode forward at B = 20, 128x416 (~5 s of oracle time per seed)."""
+    import gdn_amd.AE_model_unet as M
+    B = 20
+    depth, _, _ = O.synthetic_batch(B, 128, 416, seed=seed)
+    sd = O.init_state_dict("AutoEncoder_DtoD", seed=seed)
+    torch.set_num_threads(max(1, min(len(__import__("os").sched_getaffinity(0)), 32)))
+    with torch.no_grad():
+        ref = O.forward_dtod({k: v.clone() for k, v in sd.items()}, depth, istrain=False, training=True)
+    model = M.AutoEncoder_DtoD(input_dim=1)
+    model.load_state_dict(sd)
+    model = model.to(gpu).train()
+    with torch.no_grad():
+        out = model(depth.to(gpu), istrain=False)
+    d = out.detach().cpu().double() - ref.double()
+    rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
+    print("B=20 forward seed %d: depth map max err %.3e rms %.3e" % (seed, mx, rms))
+    assert mx <= 1e-3, "seed %d: depth map max error %.3e > 1e-3 (rms %.3e)" % (seed, mx, rms)
+    assert rms <= 6e-5, "seed %d: depth map rms error %.3e > 6e-5 (max %.3e)" % (seed, rms, mx)
 
 
 def test_rtod_train_step_b20_vs_oracle(gpu):
@@ -671,9 +700,44 @@ def test_adam_skips_parameters_without_gradient(gpu):
             assert not torch.equal(p.detach(), before[k]), k
 
 
+def test_adam_keeps_one_state_when_coverage_changes(gpu):
+    """a parameter whose gradient is missing on one step and present on the next must keep ONE set of moments and
+    its own step count (the partially covered step runs per tensor on slices of the flat moments).  Three steps -- full,
+    part of the model frozen, full -- against torch.optim.Adam fed the same gradients."""
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import utils as U
+    from gdn_amd.optim import Adam
+    H, W = 32, 64
+    depth, rgb, sparse = [t.to(gpu) for t in O.synthetic_batch(1, H, W, seed=4)]
+    torch.manual_seed(3)
+    model = M.AutoEncoder_DtoD(input_dim=1, height=H, width=W).to(gpu).train()
+    opt = Adam(model.parameters(), 1e-3, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
+    model(depth, istrain=False)                                  # builds the arena
+    ref = {k: v.detach().clone().contiguous().requires_grad_(True) for k, v in model.named_parameters()}
+    ropt = torch.optim.Adam(list(ref.values()), 1e-3, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
+    for step in range(3):
+        model.res512_3.requires_grad_(step != 1)
+        out = model(depth, istrain=False)
+        loss, _, _ = U.dtod_loss(out, depth, sparse)
+        opt.zero_grad()
+        loss.backward()
+        for k, p in model.named_parameters():
+            ref[k].grad = None if p.grad is None else p.grad.detach().clone().contiguous()
+        assert (step == 1) == any(p.grad is None for p in model.parameters())
+        opt.step()
+        ropt.step()
+        for k, p in model.named_parameters():
+            torch.testing.assert_close(p.detach(), ref[k].detach(), rtol=2e-5, atol=2e-7, msg=lambda m, k=k, s=step: "%s step %d: %s" % (k, s, m))
+            with torch.no_grad():
+                ref[k].copy_(p.detach())                         # same starting point for the next step's comparison
+    st = next(iter(opt._flat.values()))
+    assert st["pstep"] is not None and len(set(st["pstep"].values())) == 2      # res512_3 is one step behind, for good
+
+
 def test_guide_batched_pass_is_bitwise_the_two_forwards(gpu):
-    """RtoD latent loss with the frozen eval-mode guide: one pass over cat(depths, outputs) gives BITWISE the features of the
-    reference's two separate forwards (faithful mode: full network; default: encoder only)."""
+    """RtoD latent loss with the frozen eval-mode guide: one pass over cat(depths, outputs) gives the features of the
+    reference's two separate forwards (faithful mode: full network; default: encoder only) -- bitwise at this size, where the
+    batch-size-dependent plans (tile size, split factors) of a B and a 2B pass coincide; to rounding in general."""
     import gdn_amd.AE_model_unet as M
     from gdn_amd import trainer as T
     from gdn_amd import utils as U
@@ -685,7 +749,8 @@ def test_guide_batched_pass_is_bitwise_the_two_forwards(gpu):
         two = U.latent_loss(G(est, istrain=True)[:4], G(depth, istrain=True)[:4])
     for faithful in (True, False):
         one = T.guide_latent_loss(G, depth, est, faithful=faithful)
-        assert torch.equal(one, two), (faithful, float(one), float(two))
+        torch.testing.assert_close(one, two, rtol=1e-5, atol=0.0)
+        assert torch.equal(one, two), (faithful, float(one), float(two))     # (plans coincide at B = 3 / 6)
 
 
 @pytest.mark.parametrize("mode", ["DtoD", "RtoD"])

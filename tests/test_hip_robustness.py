@@ -282,6 +282,61 @@ def test_legacy_inference_at_config4_resolution(gpu):
         assert e < 2e-2, "legacy 256x832 bf16 f%d: rel L2 %.3e vs the bf16 emulation" % (i, e)
 
 
+def test_legacy_inference_b64_graph_matches_single_image(gpu, monkeypatch):
+    """BASELINE configs[4] at its OWN batch (depth_extract.py:113-147's network, 256x832, B = 64, one hipGraph replay): the
+    9x9 layers' activations are 3.5 GB and each of their spectra ~6.9 GB, so every kernel of the eval path (frequency-domain
+    transforms and per-bin GEMMs, Winograd, the direct kernels) indexes past 4 GiB.  Eval-mode BatchNorm has no cross-sample
+    coupling, so (a) two copies of one image in slots 0 and 63 must come out BITWISE equal inside the B = 64 replay, and
+    (b) images 0 and 63 must be BITWISE equal to the same images run alone at B = 1 -- with GDN_PLAN_BATCH=64 for that run,
+    because the library picks tile sizes / split factors from the batch size and a different plan is a different summation
+    order (without the override the B = 1 run agrees to rounding, also checked)."""
+    import gdn_amd.AE_model_unet as M
+    H, W, B = 256, 832, 64
+    sd = O.init_state_dict("AutoEncoder", seed=6)
+    gen = torch.Generator().manual_seed(77)
+    x = torch.rand(B, 3, H, W, generator=gen) * 2 - 1
+    x[B - 2] = x[1]                                        # a duplicate pair (slots 1 and 62) far apart in memory
+    x = x.to(gpu)
+
+    def build():
+        m = M.AutoEncoder(height=H, width=W)
+        m.load_state_dict(sd)
+        return m.to(gpu).eval()
+
+    m = build()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m(x, istrain=False)                                # warm-up: workspaces allocated outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m(x, istrain=False)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert torch.equal(out[1], out[B - 2]), "the same image in slots 1 and 62 of one B=64 replay differs"
+    assert not torch.equal(out[0], out[1])
+    big = {b: out[b].clone() for b in (0, 1, B - 1)}
+    del g, out, m
+    torch.cuda.empty_cache()
+    # alone, default plans: equal to rounding
+    m1 = build()
+    for b in (0, B - 1):
+        o1 = m1(x[b:b + 1].contiguous(), istrain=False)
+        close_abs(o1[0], big[b], 1e-4, what="B=64 image %d vs alone (default B=1 plans)" % b)
+    del m1
+    # alone, with the B = 64 plans: bitwise
+    monkeypatch.setenv("GDN_PLAN_BATCH", str(B))
+    m2 = build()
+    for b in (0, B - 1):
+        o2 = m2(x[b:b + 1].contiguous(), istrain=False)
+        assert torch.equal(o2[0], big[b]), "image %d: B=64 graph replay vs B=1 (same plans) max diff %.3e" % (
+            b, float((o2[0] - big[b]).abs().max()))
+
+
 def test_legacy_instance_norm_eval(gpu):
     """AutoEncoder(norm='Instance') (AE_model_unet.py:146-155): InstanceNorm2d(affine, track_running_stats) in eval()
     normalises with the running statistics; checked against the same layers executed by torch on the CPU."""
@@ -440,4 +495,38 @@ def test_bench_json_line_is_last_on_stdout_with_rccl(gpu):
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     rec = json.loads(lines[-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0
+    assert sum(ln.startswith("{") for ln in lines) == 1
+
+
+@pytest.mark.parametrize("mode,dtype", [("DtoD", "fp32"), ("RtoD", "bf16")])
+def test_bench_gpus_2_self_launch_trains_two_ranks(gpu, mode, dtype):
+    """`python bench.py --gpus 2` as ONE plain command on the GPU: the parent starts two fresh rank processes (it never
+    touches the GPU itself), they train data-parallel with the bucketed gradient all-reduce overlapped with backward, and
+    rank 0's JSON record -- n_gpus 2, rccl_ranks 2, global batch 2 x B -- is the last line of the parent's stdout.  On a
+    1-GPU box both ranks share cuda:0 over gloo (GDN_SINGLE_DEVICE / GDN_DIST_BACKEND test hooks: RCCL refuses two ranks on
+    one device); on a multi-GPU node the same command runs RCCL over xGMI.  RtoD bf16 is BASELINE configs[3]'s per-rank
+    workload; without the hooks a 1-GPU box must refuse --gpus 2 with the device count in the message."""
+    import json
+    import os
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--mode", mode, "--dtype", dtype, "--no-roofline", "--no-cpu-baseline", "--no-other-configs"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=base, timeout=300, cwd=str(root))
+        assert r.returncode == 2 and "1 GPU(s) are visible" in r.stderr and r.stdout.strip() == ""
+        env = dict(base, GDN_SINGLE_DEVICE="1", GDN_DIST_BACKEND="gloo")
+        backend = "gloo"
+    else:
+        env, backend = base, "nccl"
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    rec = json.loads(lines[-1])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["dist_backend"] == backend and rec["value"] > 0
+    assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2" and rec["scaling"] == "weak"
+    assert rec["dtype"] == ("f32" if dtype == "fp32" else "bf16") and mode in rec["config"]["workload"]
     assert sum(ln.startswith("{") for ln in lines) == 1

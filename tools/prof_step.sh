@@ -22,24 +22,43 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 grp = collections.Counter()
 tot = collections.Counter()
 torch_k = 0
-steps = 0
-for r in rows:
+adam_at = []
+def family(n):
+    if re.search(r"cgemm|fft", n): return "fft chain"
+    if "wino" in n or re.search(r"\bw2_", n): return "winograd"
+    if re.search(r"conv_igemm|conv_rowpatch|conv_head|conv_c1|splitk", n) and "wgrad" not in n: return "direct conv (igemm/rowpatch/c1/head/splitk)"
+    if "wgrad" in n: return "direct wgrad"
+    if re.search(r"bn_", n): return "batchnorm"
+    if re.search(r"berhu|sobel|smooth|sqdiff|finalize_sum|absdiff|zero_u32", n): return "losses/metrics"
+    if "adam" in n: return "adam"
+    if "at::native" in n or n.startswith("void at::"): return "torch (at::native)"
+    if "rocclr" in n or "copyBuffer" in n or "fillBuffer" in n: return "runtime copies/fills (set-up, outside the steps)"
+    return "other gdn"
+for i, r in enumerate(rows):
     n = r["Kernel_Name"]
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     if "adam" in n:
-        steps += 1
-    if n.startswith("void at::native") or "at::native" in n:
+        adam_at.append(i)
+    fam = family(n)
+    if fam.startswith("torch"):
         torch_k += 1
-    fam = ("fft chain" if re.search(r"cgemm|fft", n) else "winograd" if "wino" in n else "direct conv (igemm/head/splitk)" if re.search(r"conv_igemm|conv_head|splitk", n)
-           else "direct wgrad" if "wgrad" in n else "batchnorm" if re.search(r"bn_", n) else "losses/metrics" if re.search(r"berhu|sobel|smooth|sqdiff|finalize_sum|absdiff|zero_u32", n)
-           else "adam" if "adam" in n else "other gdn" if "anonymous" in n or "kernel" in n and "at::" not in n else "torch")
     grp[fam] += d
     tot[fam] += 1
+steps = len(adam_at)
 T = sum(grp.values())
 print("steps seen: %d   dispatches: %d   torch (at::native) dispatches: %d" % (steps, len(rows), torch_k))
-print("%-36s %10s %8s %8s" % ("family", "ms/step", "%", "launches/step"))
+if steps >= 2:
+    a, b = adam_at[-2], adam_at[-1]
+    inner = rows[a + 1:b + 1]
+    span = (int(rows[b]["End_Timestamp"]) - int(rows[a]["End_Timestamp"])) / 1e6
+    busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in inner) / 1e6
+    foreign = [r["Kernel_Name"] for r in inner if not family(r["Kernel_Name"]).split()[0] in
+               ("fft", "winograd", "direct", "batchnorm", "losses/metrics", "adam", "other")]
+    print("steady-state step (between the last two adam kernels): %d dispatches, %.2f ms span, %.2f ms sum of kernel time, "
+          "%d not from libgdn_hip.so%s" % (len(inner), span, busy, len(foreign), (": " + ", ".join(sorted(set(foreign))[:4])) if foreign else ""))
+print("%-48s %10s %8s %8s" % ("family", "ms/step", "%", "launches/step"))
 for k, v in grp.most_common():
-    print("%-36s %10.2f %8.1f %8.1f" % (k, v / 1e3 / max(steps, 1), 100 * v / T, tot[k] / max(steps, 1)))
-print("%-36s %10.2f" % ("sum of kernel time per step", T / 1e3 / max(steps, 1)))
+    print("%-48s %10.2f %8.1f %8.1f" % (k, v / 1e3 / max(steps, 1), 100 * v / T, tot[k] / max(steps, 1)))
+print("%-48s %10.2f" % ("sum of kernel time per step", T / 1e3 / max(steps, 1)))
 PY
 head -c 400 $out/bench.json; echo; cat $out/step_summary.txt; head -45 $out/by_kernel_and_grid.txt

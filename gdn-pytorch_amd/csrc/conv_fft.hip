@@ -446,51 +446,62 @@ __global__ __launch_bounds__(256, 4) void cgemm_tn_bins_kernel(const float* __re
 }
 
 // Inverse DFT of the weight-gradient spectrum dWf[bin][n][c] (complex) at the k*k taps only, separably:
-//   g[ty] = sum_ky F[ky][kx] e^{+i 2 pi ky ty / 32}            (K complex values per kx)
-//   dw[ty][tx] += alpha_kx Re( g[ty] e^{+i 2 pi kx tx / 32} )   (Hermitian weights 1 for kx = 0, 16, else 2)
-// so the spectrum is read ONCE and a thread does 32*K + K*K complex MACs per kx instead of 32*K*K, with 32*K + K twiddle
-// lookups instead of 32*K*K (the lookups, wave-uniform scalar loads, bounded the earlier per-tap-row kernels).
-// block = 64 (n, c) pairs x 4 groups of kx (one wave each: every twiddle index is wave-uniform); the four partial tap sets
-// meet in LDS in a fixed order.
-// P[0] += P[1] + ... + P[nsplit-1] (fixed order): the partial spectra of a split weight-gradient reduction
-__global__ __launch_bounds__(256) void fft_sum_splits_kernel(float* __restrict__ P, int64_t n4, int nsplit) {
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        f32x4 v = reinterpret_cast<const f32x4*>(P)[i];
-        for (int sp = 1; sp < nsplit; ++sp) v += reinterpret_cast<const f32x4*>(P)[(int64_t)sp * n4 + i];
-        reinterpret_cast<f32x4*>(P)[i] = v;
-    }
+//   g[ty] = sum_ky F[ky][kx] e^{+i 2 pi ky ty / NP}            (K complex values per kx)
+//   dw[ty][tx] += alpha_kx Re( g[ty] e^{+i 2 pi kx tx / NP} )   (Hermitian weights 1 for kx = 0, NP/2, else 2)
+// so the spectrum is read ONCE and a thread does NP*K + K*K complex MACs per kx instead of NP*K*K.
+// Round 3: one WAVE per kx (was: a quarter of the kx bins per wave, N*C/64 workgroups in all -- 64 workgroups for a 64-channel
+// layer, 388 us for 1.3 MB of output).  grid = (N*C/64, ceil(NK/4)): a workgroup is 64 (n, c) pairs x 4 kx, the ky loop is
+// fully unrolled so every twiddle of the first stage is a literal (no scalar table lookups), the partial spectra of a split
+// reduction GEMM are summed while they are loaded (fixed order; fft_sum_splits is gone), the four waves meet in LDS and the
+// workgroup writes its partial tap set part[blockIdx.y][tap][n][c]; fft_taps_reduce sums the ceil(NK/4) partial sets in order.
+template <int NP>
+__device__ __forceinline__ constexpr float tw_lit_cos(int q) {         // cos(2 pi q / NP), q in [0, NP): folded after unrolling
+    constexpr float C40[11] = {1.0f, 0.98768834059513777f, 0.95105651629515353f, 0.89100652418836790f, 0.80901699437494745f,
+                               0.70710678118654757f, 0.58778525229247314f, 0.45399049973954680f, 0.30901699437494745f,
+                               0.15643446504023092f, 0.0f};
+    constexpr float C32[9] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f,
+                              0.55557023301960229f, 0.38268343236508984f, 0.19509032201612833f, 0.0f};
+    if (NP == 40) return q <= 10 ? C40[q] : q <= 20 ? -C40[20 - q] : q <= 30 ? -C40[q - 20] : C40[40 - q];
+    const int r = q * (32 / (NP == 40 ? 32 : NP));                   // angle in 32nds of a turn
+    return r <= 8 ? C32[r] : r <= 16 ? -C32[16 - r] : r <= 24 ? -C32[r - 16] : C32[32 - r];
 }
+template <int NP>
+__device__ __forceinline__ constexpr float tw_lit_sin(int q) { return tw_lit_cos<NP>((q + 3 * NP / 4) % NP); }   // sin x = cos(x - pi/2)
 
 template <int K, int NP>
-__global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C) {
-    constexpr int NK = FFT_NK_OF(NP);
-    __shared__ float red[3][K * K][64];
+__global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __restrict__ P, float* __restrict__ part, int N, int C,
+                                                             int nsplit) {
+    constexpr int NK = FFT_NK_OF(NP), BINS = FFT_BINS_OF(NP);
+    __shared__ float red[3][K][64];                 // one filter row at a time: 7 KB, so the kernel never crowds a 107 KB
+                                                    // transform workgroup of the other stream off a CU (the old 62 KB did)
     const int pl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + pl;             // N*C is a multiple of 64
-    const int c = i % C, n = i / C;
-    const int kx0 = (grp * NK) / 4, kx1 = ((grp + 1) * NK) / 4;     // the NK kx bins in four groups
+    const int i = blockIdx.x * 64 + pl;             // (n, c) pair; N*C is a multiple of 64
+    const int kx = blockIdx.y * 4 + grp;            // wave-uniform
+    const size_t bs = (size_t)N * C;
     float acc[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
-    const float2* F = reinterpret_cast<const float2*>(P) + (size_t)n * C + c;
-    const size_t bs = (size_t)N * C;
-    for (int kx = kx0; kx < kx1; ++kx) {
+    if (kx < NK) {
+        const float2* F = reinterpret_cast<const float2*>(P) + (size_t)kx * bs + i;
+        const size_t sky = (size_t)NK * bs, ssp = (size_t)BINS * bs;
         float gr[K], gi[K];
 #pragma unroll
         for (int ty = 0; ty < K; ++ty) { gr[ty] = 0.f; gi[ty] = 0.f; }
-        int ph[K];                                   // (ky * ty) mod NP, advanced by ty per step: wave-uniform, no division
 #pragma unroll
-        for (int ty = 0; ty < K; ++ty) ph[ty] = 0;
-#pragma unroll 8
         for (int ky = 0; ky < NP; ++ky) {
-            const float2 v = F[(size_t)(ky * NK + kx) * bs];
+            float2 v = *F;
+            const float2* Fs = F;
+            for (int sp = 1; sp < nsplit; ++sp) {        // P[0] + P[1] + ... in order, as fft_sum_splits did
+                Fs += ssp;
+                const float2 u = *Fs;
+                v.x += u.x; v.y += u.y;
+            }
+            F += sky; GDN_KEEP(F);
 #pragma unroll
             for (int ty = 0; ty < K; ++ty) {
-                const float cs = tw_cos_r<NP>(ph[ty]), sn = tw_sin_r<NP>(ph[ty]);
+                const float cs = tw_lit_cos<NP>((ky * ty) % NP), sn = tw_lit_sin<NP>((ky * ty) % NP);
                 gr[ty] += v.x * cs - v.y * sn;
                 gi[ty] += v.x * sn + v.y * cs;
-                ph[ty] += ty;
-                if (ph[ty] >= NP) ph[ty] -= NP;
             }
         }
         const float alpha = (kx == 0 || kx == NP / 2) ? 1.f : 2.f;
@@ -498,18 +509,33 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
         for (int tx = 0; tx < K; ++tx) {
             const float cs = tw_cos<NP>(kx * tx) * alpha, sn = tw_sin<NP>(kx * tx) * alpha;
 #pragma unroll
-            for (int ty = 0; ty < K; ++ty) acc[ty * K + tx] += gr[ty] * cs - gi[ty] * sn;
+            for (int ty = 0; ty < K; ++ty) acc[ty * K + tx] = gr[ty] * cs - gi[ty] * sn;
         }
     }
-    if (grp > 0) {
+    float* dst = part + (size_t)blockIdx.y * K * K * bs + i;
 #pragma unroll
-        for (int t = 0; t < K * K; ++t) red[grp - 1][t][pl] = acc[t];
+    for (int ty = 0; ty < K; ++ty) {
+        if (ty > 0) __syncthreads();
+        if (grp > 0) {
+#pragma unroll
+            for (int tx = 0; tx < K; ++tx) red[grp - 1][tx][pl] = acc[ty * K + tx];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int tx = 0; tx < K; ++tx)
+                dst[(size_t)(ty * K + tx) * bs] = ((acc[ty * K + tx] + red[0][tx][pl]) + red[1][tx][pl]) + red[2][tx][pl];
+        }
     }
-    __syncthreads();
-    if (grp == 0) {
-#pragma unroll
-        for (int t = 0; t < K * K; ++t)
-            dw[((size_t)t * N + n) * C + c] = (((acc[t] + red[0][t][pl]) + red[1][t][pl]) + red[2][t][pl]) * (1.0f / (NP * NP));
+}
+
+// dw[tap][n][c] = scale * (part[0] + part[1] + ... + part[G-1]) (fixed order); n4 = K*K*N*C / 4
+__global__ __launch_bounds__(256) void fft_taps_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int64_t n4, int G,
+                                                              float scale) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(part)[i];
+        for (int g = 1; g < G; ++g) v += reinterpret_cast<const f32x4*>(part)[(int64_t)g * n4 + i];
+        reinterpret_cast<f32x4*>(dw)[i] = v * scale;
     }
 }
 
@@ -890,9 +916,13 @@ inline int tn_splits(const FftGeom& f) {
     while (s > 1 && f.M / s < 64) --s;
     return s < 1 ? 1 : s;
 }
-// weight-spectrum / weight-gradient-product region of the backward workspace
+// weight-spectrum / weight-gradient-product region of the backward workspace: the weight planes (data gradient without a saved
+// state), or the per-split products of the reduction GEMM followed by the partial tap sets of fft_wgrad_taps
+inline size_t tn_prod_bytes(const FftGeom& f) { return al256((size_t)tn_splits(f) * f.bins * 2 * f.C * f.N * 4); }
+inline int taps_groups(const FftGeom& f) { return cdiv(f.np / 2 + 1, 4); }
 inline size_t wf_region_bytes(const FftGeom& f) {
-    const size_t planes = (size_t)f.bins * 3 * f.C * f.N * 4, prod = (size_t)tn_splits(f) * f.bins * 2 * f.C * f.N * 4;
+    const size_t planes = (size_t)f.bins * 3 * f.C * f.N * 4;
+    const size_t prod = tn_prod_bytes(f) + al256((size_t)taps_groups(f) * f.k * f.k * f.C * f.N * 4);
     return al256(planes > prod ? planes : prod);
 }
 
@@ -1040,18 +1070,19 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         const int ns = tn_splits(f);
         hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * f.bins * ns), dim3(256), 0, st,
                            (const float*)Df, (const float*)xf, P, f.M, f.N, f.C, ns, f.bins);
-        if (ns > 1) {
-            const int64_t n4 = (int64_t)f.bins * f.N * f.C * 2 / 4;
-            hipLaunchKernelGGL(fft_sum_splits_kernel, dim3(blocks(n4)), dim3(256), 0, st, P, n4, ns);
-        }
+        float* part = (float*)((char*)P + tn_prod_bytes(f));
+        const dim3 gt(f.N * f.C / 64, taps_groups(f));
 #define GDN_TAPS(KK) case KK: \
-            if (f.np == 16) hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 16>), dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
-            else if (f.np == 40) hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 40>), dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
-            else hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 32>), dim3(f.N * f.C / 64), dim3(256), 0, st, (const float*)P, dw, f.N, f.C); \
+            if (f.np == 16) hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 16>), gt, dim3(256), 0, st, (const float*)P, part, f.N, f.C, ns); \
+            else if (f.np == 40) hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 40>), gt, dim3(256), 0, st, (const float*)P, part, f.N, f.C, ns); \
+            else hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 32>), gt, dim3(256), 0, st, (const float*)P, part, f.N, f.C, ns); \
             break;
         switch (f.k) {
             GDN_TAPS(3) GDN_TAPS(5) GDN_TAPS(7) GDN_TAPS(9)
         }
+        const int64_t n4 = (int64_t)f.k * f.k * f.N * f.C / 4;
+        hipLaunchKernelGGL(fft_taps_reduce_kernel, dim3(blocks(n4)), dim3(256), 0, st, (const float*)part, dw, n4, taps_groups(f),
+                           1.0f / (f.np * f.np));
 #undef GDN_TAPS
     }
     if (dx && (phases & GDN_FFT_BWD_DX)) {

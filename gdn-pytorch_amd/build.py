@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
             if verbose and r.stderr:
                 sys.stderr.write(r.stderr)
     objs = [OUT / (s.stem + ".o") for s in srcs]
-    if force or jobs or not LIB.exists():
+    if force or jobs or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs):
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "wino_gemm.h"
 #include "up2x.h"
+#include "gemm_x3.h"
 
 namespace {
 
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
         r[2][j] = 0.5f * (gk[0][j] - gk[1][j] + gk[2][j]);
         r[3][j] = gk[2][j];
     }
-    float* dst = U + (swap ? (size_t)c * N + n : (size_t)n * C + c);
+    float* dst = U ? U + (swap ? (size_t)c * N + n : (size_t)n * C + c) : nullptr;      // (U == NULL: only the swapped set)
     const size_t bs = (size_t)N * C;
     float u[4][4];
 #pragma unroll
@@ -163,10 +164,12 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
         u[i2][2] = 0.5f * (r[i2][0] - r[i2][1] + r[i2][2]);
         u[i2][3] = r[i2][2];
     }
+    if (dst) {
 #pragma unroll
-    for (int i2 = 0; i2 < 4; ++i2)
+        for (int i2 = 0; i2 < 4; ++i2)
 #pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2) { dst[0] = u[i2][j2]; dst += bs; GDN_KEEP(dst); }
+            for (int j2 = 0; j2 < 4; ++j2) { dst[0] = u[i2][j2]; dst += bs; GDN_KEEP(dst); }
+    }
     if (Uswap) {
         // G flip(g) G^T = P (G g G^T) P with P the permutation (3,1,2,0): flipping the taps swaps rows 0 <-> 3 of G g
         float* d2 = Uswap + (size_t)c * N + n;
@@ -178,6 +181,62 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
                 d2[0] = u[pi][pj]; d2 += bs; GDN_KEEP(d2);
             }
     }
+}
+
+// The same transform written as bf16 x 3 packed panels (gemm_x3.h) for the GEMMs that run on the bf16 matrix pipe.
+// swap = 0: rows = n (output channel), k = c -- the forward's B operand U[bin][n][c];  swap = 1: rows = c, k = n from the
+// flipped taps -- the data gradient's.  thread = (row, 8 consecutive k): 9 taps x 8 values in, 16 bins x 3 planes x 16 bytes out.
+__global__ __launch_bounds__(256) void wino_weights_x3_kernel(const float* __restrict__ w, unsigned char* __restrict__ Up, int N, int C,
+                                                              int swap) {
+    const int rows = swap ? C : N, K = swap ? N : C, k8n = K / 8;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * k8n) return;
+    // consecutive lanes take consecutive rows when the 8 k values are strided in memory (swap: k = n, stride C), consecutive k
+    // blocks otherwise (k = c contiguous): either way a wave's loads are contiguous runs
+    const int row = swap ? i % rows : i / k8n, k8 = swap ? i / rows : i % k8n;
+    float gk[8][3][3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+            const int tap = swap ? (2 - ty) * 3 + (2 - tx) : ty * 3 + tx;
+            if (swap) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gk[e][ty][tx] = w[((size_t)tap * N + k8 * 8 + e) * C + row];
+            } else {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(w + ((size_t)tap * N + row) * C + k8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(w + ((size_t)tap * N + row) * C + k8 * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gk[e][ty][tx] = lo[e]; gk[4 + e][ty][tx] = hi[e]; }
+            }
+        }
+    const int KB = K / X3_BK;
+    const size_t per_bin = x3_packed_bytes(rows, K);
+    unsigned char* dst = Up + x3_off(row, k8 * 8, 0, KB);
+#pragma unroll
+    for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+            unsigned h[3][4];
+            float uu[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                // (G g G^T)[i2][j2]: rows of G = (1,0,0), (.5,.5,.5), (.5,-.5,.5), (0,0,1)
+                float r[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    r[j] = i2 == 0 ? gk[e][0][j] : i2 == 3 ? gk[e][2][j]
+                         : 0.5f * (i2 == 1 ? gk[e][0][j] + gk[e][1][j] + gk[e][2][j] : gk[e][0][j] - gk[e][1][j] + gk[e][2][j]);
+                uu[e] = j2 == 0 ? r[0] : j2 == 3 ? r[2] : 0.5f * (j2 == 1 ? r[0] + r[1] + r[2] : r[0] - r[1] + r[2]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x3_split2(uu[2 * q], uu[2 * q + 1], h[0][q], h[1][q], h[2][q]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const uint4 v = {h[p][0], h[p][1], h[p][2], h[p][3]};
+                *reinterpret_cast<uint4*>(dst + (size_t)(i2 * 4 + j2) * per_bin + (size_t)p * 128 * 64) = v;
+            }
+        }
 }
 
 // y = A^T m A (2x2 outputs per tile) with the conv_igemm epilogue; stats slot = group of 4 tiles
@@ -297,7 +356,16 @@ bool wino_geom(const gdn_conv_geom* g, WinoGeom& f) {
 
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 inline size_t v_bytes(const WinoGeom& f) { return al256((size_t)WINO_BINS * f.M * f.C * 4); }
-inline size_t u_bytes(const WinoGeom& f) { return al256((size_t)WINO_BINS * f.N * f.C * 4); }
+// transformed weights: fp32 [16][N][C], or the bf16 x 3 panels of either orientation (rows padded to whole 128-row tiles)
+inline size_t u_bytes(const WinoGeom& f) {
+    size_t b = (size_t)WINO_BINS * f.N * f.C * 4;
+    const size_t p1 = (size_t)WINO_BINS * x3_packed_bytes(f.N, f.C), p2 = (size_t)WINO_BINS * x3_packed_bytes(f.C, f.N);
+    if (p1 > b) b = p1;
+    if (p2 > b) b = p2;
+    return al256(b);
+}
+// GDN_X3=0 keeps every per-bin GEMM on the fp32 MFMA (A/B measurements, accuracy studies)
+inline bool x3_on() { const char* e = getenv("GDN_X3"); return !(e && e[0] == '0'); }
 inline size_t m_bytes(const WinoGeom& f) { return al256((size_t)WINO_BINS * f.M * f.N * 4); }
 inline int tn_splits(const WinoGeom& f) { return wino_tn_splits(f.M, f.N, f.C); }
 
@@ -341,8 +409,17 @@ extern "C" int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t 
     float* Usw = state_out ? (float*)((char*)state_out + v_bytes(f)) : nullptr;
     hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(f.M, 4) << f.cq_shift), dim3(256), 0, st, x, ldx, V, f, in_scale, in_shift,
                        in_relu, in_up2x);
-    hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 0, Usw);
-    launch_wino_gemm((const float*)V, (const float*)U, Mo, f.M, f.N, f.C, st);
+    // the per-bin GEMMs run as bf16 x 3 split products on the bf16 matrix pipe where the shape allows (gemm_x3.h); the data
+    // gradient's weight set (its GEMM has N = Cin) is written in the form ITS kernel will read
+    const bool x3f = x3_on() && gemm_x3_ok(f.M, f.N, f.C), x3d = x3_on() && gemm_x3_ok(f.M, f.C, f.N);
+    if (!x3f || (Usw && !x3d))
+        hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, x3f ? (float*)nullptr : U, f.N,
+                           f.C, 0, x3d ? (float*)nullptr : Usw);
+    if (x3f) hipLaunchKernelGGL(wino_weights_x3_kernel, dim3(cdiv(f.N * f.C / 8, 256)), dim3(256), 0, st, w, (unsigned char*)U, f.N, f.C, 0);
+    if (Usw && x3d)
+        hipLaunchKernelGGL(wino_weights_x3_kernel, dim3(cdiv(f.N * f.C / 8, 256)), dim3(256), 0, st, w, (unsigned char*)Usw, f.N, f.C, 1);
+    if (x3f) launch_gemm_x3_nt((const float*)V, U, Mo, WINO_BINS, f.M, f.N, f.C, st);
+    else launch_wino_gemm((const float*)V, (const float*)U, Mo, f.M, f.N, f.C, st);
     hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, (const float*)Mo, y, ldy, addsrc,
                        ld_add, stats, ep_scale, ep_shift, act, f, f.N, f.nq_shift, (const float*)nullptr, 0,
                        (const float*)nullptr, 0);
@@ -357,7 +434,7 @@ extern "C" size_t gdn_winoconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     const size_t Md = f.reflect ? (size_t)f.B * cdiv(f.H + 2, 2) * cdiv(f.W + 2, 2) : (size_t)f.M;
     const size_t vd = al256((size_t)WINO_BINS * Md * f.N * 4), eo = al256((size_t)WINO_BINS * Md * f.C * 4);
     const size_t padded = f.reflect ? al256((size_t)f.B * (f.H + 2) * (f.W + 2) * f.C * 4) : 0;
-    const size_t pr = (size_t)tn_splits(f) * u_bytes(f);            // weight-gradient products, one set per split
+    const size_t pr = (size_t)tn_splits(f) * al256((size_t)WINO_BINS * f.N * f.C * 4);   // weight-gradient products, one set per split
     return (vd > m_bytes(f) ? vd : m_bytes(f)) + u_bytes(f) + (eo > pr ? eo : pr) + padded;
 }
 
@@ -412,9 +489,14 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
         hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(fd.M, 4) << fd.cq_shift), dim3(256), 0, st, dy, ldy, Vd, fd,
                            (const float*)nullptr, (const float*)nullptr, 0, 0);
         const float* Ud = U;
+        // (the forward decided the form of its saved set from the FORWARD tile count f.M; the padded-domain gradient of a
+        // reflection layer has more tiles but the same N and K, so eligibility is the same)
+        const bool x3d = x3_on() && gemm_x3_ok(f.M, f.C, f.N);
         if (state) Ud = (const float*)((const char*)state + v_bytes(f));      // transformed by the forward's launch
+        else if (x3d) hipLaunchKernelGGL(wino_weights_x3_kernel, dim3(cdiv(f.N * f.C / 8, 256)), dim3(256), 0, st, w, (unsigned char*)U, f.N, f.C, 1);
         else hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 1, (float*)nullptr);
-        launch_wino_gemm((const float*)Vd, Ud, Eo, fd.M, f.C, f.N, st);
+        if (x3d) launch_gemm_x3_nt((const float*)Vd, Ud, Eo, WINO_BINS, fd.M, f.C, f.N, st);
+        else launch_wino_gemm((const float*)Vd, Ud, Eo, fd.M, f.C, f.N, st);
         hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(fd.M, 4) << fd.nq_shift), dim3(256), 0, st, (const float*)Eo, out, ld_out,
                            f.reflect ? (const float*)nullptr : addsrc, ld_add, bnb_y ? bnb_partial : (float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, 0, fd, f.C, fd.nq_shift, bnb_y, ld_bnb, bnb_co, bnb_relu);

@@ -28,6 +28,7 @@
 // (verified against the direct correlation in tests/test_wino2conv_model_cpu.py).
 #include "common.h"
 #include "wino_gemm.h"
+#include "gemm_x3.h"
 
 namespace {
 
@@ -391,15 +392,35 @@ inline size_t ua_bytes(const W2Geom& f) { return al256((size_t)WINO_BINS * f.Cy 
 inline size_t ma_bytes(const W2Geom& f) { return al256((size_t)WINO_BINS * f.Ma * f.Cy * 4); }          // Mo / Dv, form A
 inline size_t vb_bytes(const W2Geom& f) { return al256((size_t)WINO_BINS * f.Mb * f.Cy * 4); }          // Vd, form B
 inline size_t eb_bytes(const W2Geom& f) { return al256((size_t)WINO_BINS * f.Mb * 4 * f.Cx * 4); }      // Eo, form B
+// the U region also holds the bf16 x 3 panels of the transformed weights (gemm_x3.h; packed from the fp32 set by one small
+// launch): rows = Cy, k = 4 Cx (form A) or rows = 4 Cx, k = Cy (form B), behind the fp32 set
+inline size_t ux_bytes(const W2Geom& f) {
+    const size_t pa = (size_t)WINO_BINS * x3_packed_bytes(f.Cy, 4 * f.Cx), pb = (size_t)WINO_BINS * x3_packed_bytes(4 * f.Cx, f.Cy);
+    return ua_bytes(f) + al256(pa > pb ? pa : pb);
+}
+inline bool x3_on() { const char* e = getenv("GDN_X3"); return !(e && e[0] == '0'); }
 inline int w2_splits(const W2Geom& f) { return wino_tn_splits(f.Ma, f.Cy, 4 * f.Cx); }
-inline size_t p_bytes(const W2Geom& f) { return (size_t)w2_splits(f) * ua_bytes(f); }                   // P, one set per split
+inline size_t p_bytes(const W2Geom& f) {                                                                // P, one set per split
+    const size_t pr = (size_t)w2_splits(f) * ua_bytes(f);
+    return pr > ux_bytes(f) ? pr : ux_bytes(f);
+}
+// the 16 per-bin GEMMs Cm = A * U^T: as bf16 x 3 split products on the bf16 matrix pipe where the shape allows, else fp32 MFMA
+void w2_gemm(const W2Geom& f, const float* A, float* U, float* Cm, int M, int N, int K, hipStream_t st) {
+    if (x3_on() && gemm_x3_ok(M, N, K)) {
+        void* Up = (char*)U + ua_bytes(f);
+        launch_x3_pack_rows(U, Up, WINO_BINS, N, K, st);
+        launch_gemm_x3_nt(A, Up, Cm, WINO_BINS, M, N, K, st);
+    } else {
+        launch_wino_gemm(A, (const float*)U, Cm, M, N, K, st);
+    }
+}
 inline size_t pad_bytes(const W2Geom& f) { return f.reflect ? al256((size_t)f.B * (f.Hx + 2) * (f.Wx + 2) * f.Cx * 4) : 0; }
 
 void run_form_a(const W2Geom& f, const float* x, int ldx, const float* w, int swap, float* V, float* U, float* Mo, float* y, int ldy,
                 const W2Ep& ep, hipStream_t st) {
     hipLaunchKernelGGL(w2_input_a_kernel, dim3(cdiv(f.Ma, 4) << f.xq), dim3(256), 0, st, x, ldx, V, f);
     hipLaunchKernelGGL(w2_weights_a_kernel, dim3(cdiv(f.Cy * f.Cx, 256)), dim3(256), 0, st, w, U, f.Cy, f.Cx, swap);
-    launch_wino_gemm((const float*)V, (const float*)U, Mo, f.Ma, f.Cy, 4 * f.Cx, st);
+    w2_gemm(f, (const float*)V, U, Mo, f.Ma, f.Cy, 4 * f.Cx, st);
     hipLaunchKernelGGL(w2_output_a_kernel, dim3(cdiv(f.Ma, 4) << f.yq), dim3(256), 0, st, (const float*)Mo, y, ldy, ep, f);
 }
 
@@ -407,7 +428,7 @@ void run_form_b(const W2Geom& f, const float* d, int ldd, const float* w, int sw
                 int Hout, int Wout, int off, const W2Ep& ep, hipStream_t st) {
     hipLaunchKernelGGL(w2_input_b_kernel, dim3(cdiv(f.Mb, 4) << f.yq), dim3(256), 0, st, d, ldd, Vd, f);
     hipLaunchKernelGGL(w2_weights_b_kernel, dim3(cdiv(f.Cx * f.Cy, 256)), dim3(256), 0, st, w, U, f.Cx, f.Cy, swap);
-    launch_wino_gemm((const float*)Vd, (const float*)U, Eo, f.Mb, 4 * f.Cx, f.Cy, st);
+    w2_gemm(f, (const float*)Vd, U, Eo, f.Mb, 4 * f.Cx, f.Cy, st);
     hipLaunchKernelGGL(w2_output_b_kernel, dim3(cdiv(f.Mb, 4) << f.xq), dim3(256), 0, st, (const float*)Eo, out, ldo, ep, f, Hout, Wout, off);
 }
 
@@ -424,7 +445,7 @@ extern "C" size_t gdn_wino2conv_state_bytes(const gdn_conv_geom* g) {
 extern "C" size_t gdn_wino2conv_fwd_workspace_bytes(const gdn_conv_geom* g) {
     W2Geom f;
     if (!w2_geom(g, f)) return 0;
-    return g->transposed ? vb_bytes(f) + ua_bytes(f) + eb_bytes(f) : va_bytes(f) + ua_bytes(f) + ma_bytes(f);
+    return g->transposed ? vb_bytes(f) + ux_bytes(f) + eb_bytes(f) : va_bytes(f) + ux_bytes(f) + ma_bytes(f);
 }
 
 extern "C" int64_t gdn_wino2conv_stats_slots(const gdn_conv_geom* g) {
@@ -447,13 +468,13 @@ extern "C" int gdn_wino2conv_fwd(const gdn_conv_geom* g, const float* x, int32_t
     char* p = (char*)workspace;
     if (!g->transposed) {
         float* V = (float*)p; p += va_bytes(f);
-        float* U = (float*)p; p += ua_bytes(f);
+        float* U = (float*)p; p += ux_bytes(f);
         float* Mo = (float*)p;
         if (state_out) V = (float*)state_out;
         run_form_a(f, x, ldx, w, 0, V, U, Mo, y, ldy, ep, st);
     } else {
         float* Vd = (float*)p; p += vb_bytes(f);
-        float* U = (float*)p; p += ua_bytes(f);
+        float* U = (float*)p; p += ux_bytes(f);
         float* Eo = (float*)p;
         run_form_b(f, x, ldx, w, 0, Vd, U, Eo, y, ldy, f.Hx, f.Wx, 0, ep, st);
     }
@@ -493,7 +514,7 @@ extern "C" int gdn_wino2conv_bwd(const gdn_conv_geom* g, const float* dy, int32_
         hipLaunchKernelGGL(w2_input_a_kernel, dim3(cdiv(f.Ma, 4) << f.xq), dim3(256), 0, st, dy, ldy, V, f);
         if (dx) {
             hipLaunchKernelGGL(w2_weights_a_kernel, dim3(cdiv(f.Cy * f.Cx, 256)), dim3(256), 0, st, w, U, f.Cy, f.Cx, 1);
-            launch_wino_gemm((const float*)V, (const float*)U, Mo, f.Ma, f.Cy, 4 * f.Cx, st);
+            w2_gemm(f, (const float*)V, U, Mo, f.Ma, f.Cy, 4 * f.Cx, st);
             const W2Ep ep = {addsrc, ld_add, nullptr, nullptr, nullptr, 0};
             hipLaunchKernelGGL(w2_output_a_kernel, dim3(cdiv(f.Ma, 4) << f.yq), dim3(256), 0, st, (const float*)Mo, dx, ldx, ep, f);
         }

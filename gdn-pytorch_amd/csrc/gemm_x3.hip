@@ -1,0 +1,182 @@
+// fp32 per-bin GEMMs as bf16 x 3 split products on v_mfma_f32_32x32x16_bf16 (see gemm_x3.h for the arithmetic and the layout).
+#include "gemm_x3.h"
+
+namespace {
+
+// ---- packing: fp32 [bins][rows][K] -> panels.  thread = (row, 8 consecutive k): two 16-byte loads, three 16-byte stores ----
+__global__ __launch_bounds__(256) void x3_pack_rows_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, int rows,
+                                                           int K, int rows_pad) {
+    const int KB = K / X3_BK, k8n = K / 8;
+    const int bin = blockIdx.y;
+    const size_t per_bin = x3_packed_bytes(rows, K);
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < (int64_t)rows_pad * k8n; i += (int64_t)gridDim.x * 256) {
+        const int k8 = (int)(i % k8n), row = (int)(i / k8n);
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+        if (row < rows) {
+            const float* s = src + ((size_t)bin * rows + row) * K + k8 * 8;
+            lo = *reinterpret_cast<const f32x4*>(s);
+            hi = *reinterpret_cast<const f32x4*>(s + 4);
+        }
+        unsigned h[3][4];
+        x3_split2(lo[0], lo[1], h[0][0], h[1][0], h[2][0]);
+        x3_split2(lo[2], lo[3], h[0][1], h[1][1], h[2][1]);
+        x3_split2(hi[0], hi[1], h[0][2], h[1][2], h[2][2]);
+        x3_split2(hi[2], hi[3], h[0][3], h[1][3], h[2][3]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const uint4 v = {h[p][0], h[p][1], h[p][2], h[p][3]};
+            *reinterpret_cast<uint4*>(dst + (size_t)bin * per_bin + x3_off(row, k8 * 8, p, KB)) = v;
+        }
+    }
+}
+
+// ---- the GEMM ----
+// Workgroup = 128 x 128 output tile, 4 waves (2 x 2) of 64 x 64 = 2 x 2 MFMA tiles; a stage is 32 k: per wave 2 sub-steps of
+// (6 + 6 fragment reads, 24 MFMAs).  LDS: three bf16 planes of A and of B, [plane][128 rows][64 B] each (48 KB); two
+// workgroups per CU (232 registers: two accumulator sets).  A is staged global (fp32) -> registers -> split -> LDS with the loads of stage i + 1 issued
+// before the MFMAs of stage i; B's stage is a linear 24 KB copy of its panel.
+// XCD-aware order (as wino_gemm_kernel): XCD j owns bins j, j + 8, ... and walks them with the N tiles of one M tile back to
+// back, so an A tile is fetched from the fabric once and a bin's weight panels stay in that XCD's L2.
+__global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(const float* __restrict__ A, const unsigned char* __restrict__ Bp,
+                                                            float* __restrict__ C, int M, int N, int K, int bins) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[3 * 128 * 64], Bs[3 * 128 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int NT = N / 128, MT = (M + 127) / 128, KB = K / X3_BK;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int bin = (sq / (NT * MT)) * 8 + xcd;
+    if (bin >= bins) return;
+    const int m0 = ((sq / NT) % MT) * 128, nt = sq % NT;
+    const float* Ab = A + (size_t)bin * M * K;
+    const unsigned char* Bb = Bp + (size_t)bin * x3_packed_bytes(N, K) + (size_t)nt * KB * (3 * 128 * 64);
+    float* Cb = C + (size_t)bin * M * N;
+
+    f32x16 acc[2][2], cor[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; cor[i][j][r] = 0.f; }
+
+    // A staging: thread = (row = tid >> 1, half = tid & 1): 16 consecutive k (64 B) of one row; rows past M read row M - 1
+    const int arow = tid >> 1, ahalf = tid & 1;
+    const int am = m0 + arow < M ? m0 + arow : M - 1;
+    const float* ap = Ab + (size_t)am * K + ahalf * 16;
+    f32x4 ra[4];
+    f32x4 rb[6];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) ra[v] = *reinterpret_cast<const f32x4*>(ap + (size_t)kb * X3_BK + v * 4);
+        const unsigned char* bsrc = Bb + (size_t)kb * (3 * 128 * 64) + tid * 16;
+#pragma unroll
+        for (int v = 0; v < 6; ++v) rb[v] = *reinterpret_cast<const f32x4*>(bsrc + v * 4096);
+    };
+    const int a_sw = (arow >> 2) & 3;
+    auto lstore = [&]() {
+        unsigned h[3][8];                            // packed pairs: k = 2 q, 2 q + 1
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            x3_split2(ra[v][0], ra[v][1], h[0][v * 2], h[1][v * 2], h[2][v * 2]);
+            x3_split2(ra[v][2], ra[v][3], h[0][v * 2 + 1], h[1][v * 2 + 1], h[2][v * 2 + 1]);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {            // the thread's two 16-byte chunks (k = half*16 + c*8 ..)
+                const uint4 v = {h[p][c * 4 + 0], h[p][c * 4 + 1], h[p][c * 4 + 2], h[p][c * 4 + 3]};
+                *reinterpret_cast<uint4*>(&As[(p * 128 + arow) * 64 + (((ahalf * 2 + c) ^ a_sw) * 16)]) = v;
+            }
+#pragma unroll
+        for (int v = 0; v < 6; ++v) *reinterpret_cast<f32x4*>(&Bs[v * 4096 + tid * 16]) = rb[v];
+    };
+    // fragment addresses: lane (r = lane & 31, h = lane >> 5) reads 16 B of row (tile row base + r) at chunk (2 s + h) ^ swz(row)
+    const int r32 = lane & 31, h = lane >> 5;
+    const int f_sw = (r32 >> 2) & 3;                                   // tile row bases are multiples of 32: same swizzle
+    const int a_base = (wm * 64 + r32) * 64, b_base = (wn * 64 + r32) * 64;
+
+    gload(0);
+    for (int kb = 0; kb < KB; ++kb) {
+        lstore();
+        __syncthreads();
+        if (kb + 1 < KB) gload(kb + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int co = ((2 * s + h) ^ f_sw) * 16;
+            x3_bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    af[i][p] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(&As[p * 8192 + a_base + i * 2048 + co]));
+                    bf[i][p] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(&Bs[p * 8192 + b_base + i * 2048 + co]));
+                }
+            // The bf16 MFMA aligns its 16 products AND the C input to the largest exponent among them and truncates what
+            // falls below ~half an ulp of it, per addend, toward zero (measured: tests/diag/mfma_rounding.py); the sum itself is
+            // rounded to nearest.  A leading product a1*b1 has a 16-bit significand, so against a running sum sqrt(K) larger
+            // it loses nothing; a correction product sits 8 or 16 bits lower and WOULD be cut at the running sum's ulp.  Hence
+            // two accumulators: `acc` chains the leading products, `cor` chains the five correction products (its own ulp is
+            // 2^-8 of acc's), and the two meet once, in the epilogue.  No vector-ALU work in the loop; 32 roundings per
+            // K = 512 instead of the 512 of the k-ordered fp32 MFMA chain this replaces.
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], cor[i][j], 0, 0, 0);
+                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], cor[i][j], 0, 0, 0);
+                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], cor[i][j], 0, 0, 0);
+                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], cor[i][j], 0, 0, 0);
+                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], cor[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = nt * 128 + wn * 64 + j * 32 + r32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < M) Cb[(size_t)m * N + col] = acc[i][j][r] + cor[i][j][r];
+            }
+        }
+}
+
+}  // namespace
+
+void launch_x3_pack_rows(const float* src, void* dst, int bins, int rows, int K, hipStream_t st) {
+    const int rows_pad = (rows + X3_TILE - 1) / X3_TILE * X3_TILE;
+    const int64_t n = (int64_t)rows_pad * (K / 8);
+    const int64_t nb = cdiv64(n, 256);
+    hipLaunchKernelGGL(x3_pack_rows_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096), bins), dim3(256), 0, st, src,
+                       (unsigned char*)dst, rows, K, rows_pad);
+}
+
+void launch_gemm_x3_nt(const float* A, const void* Bp, float* C, int bins, int M, int N, int K, hipStream_t st) {
+    const int NT = N / 128, MT = (M + 127) / 128, bg = (bins + 7) / 8;
+    hipLaunchKernelGGL(gemm_x3_nt_kernel, dim3(MT * NT * bg * 8), dim3(256), 0, st, A, (const unsigned char*)Bp, C, M, N, K, bins);
+}
+
+// ---- C ABI: measurement / test hooks (the product path calls the launchers from the Winograd entry points) ----
+extern "C" size_t gdn_gemm_x3_packed_bytes(int32_t bins, int32_t rows, int32_t K) {
+    if (bins < 1 || rows < 1 || K < X3_BK || (K % X3_BK)) return 0;
+    return (size_t)bins * x3_packed_bytes(rows, K);
+}
+
+extern "C" int gdn_gemm_x3_pack(const float* src, void* dst, int32_t bins, int32_t rows, int32_t K, void* stream) {
+    (void)hipGetLastError();
+    if (!src || !dst || bins < 1 || rows < 1 || K < X3_BK || (K % X3_BK)) return GDN_ERR_BAD_ARG;
+    launch_x3_pack_rows(src, dst, bins, rows, K, (hipStream_t)stream);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_gemm_x3_nt(const float* A, const void* Bp, float* C, int32_t bins, int32_t M, int32_t N, int32_t K,
+                              void* stream) {
+    (void)hipGetLastError();
+    if (!A || !Bp || !C || bins < 1) return GDN_ERR_BAD_ARG;
+    if (!gemm_x3_ok(M, N, K)) return GDN_ERR_UNSUPPORTED;
+    launch_gemm_x3_nt(A, Bp, C, bins, M, N, K, (hipStream_t)stream);
+    return gdn_launch_status();
+}

@@ -431,6 +431,27 @@ def conv_c1_wgrad(x1, gw, dw81, reflect=False, flip=False):
                           stream())
 
 
+def gemm_x3_pack(Bm):
+    """fp32 [bins, rows, K] -> packed bf16 x 3 panels (opaque uint8 buffer for gemm_x3_nt)."""
+    _chk(Bm, "B")
+    bins, rows, K = Bm.shape
+    nb = int(lib.gdn_gemm_x3_packed_bytes(bins, rows, K))
+    if nb == 0 or not Bm.is_contiguous():
+        raise GdnError("gemm_x3_pack: needs a dense [bins, rows, K] tensor with K a multiple of 32")
+    out = torch.empty(nb, dtype=torch.uint8, device=Bm.device)
+    lib.gdn_gemm_x3_pack(_p(Bm), _p(out), bins, rows, K, stream())
+    return out
+
+
+def gemm_x3_nt(A, Bp, N, out=None):
+    """C[bin] = A[bin] @ B[bin]^T with fp32 A [bins, M, K], packed B (gemm_x3_pack of [bins, N, K]); fp32 C [bins, M, N]."""
+    _chk(A, "A")
+    bins, M, K = A.shape
+    C = out if out is not None else torch.empty((bins, M, N), dtype=torch.float32, device=A.device)
+    lib.gdn_gemm_x3_nt(_p(A), _p(Bp), _p(C), bins, M, N, K, stream())
+    return C
+
+
 def transpose_taps(w_tap, out=None, dtype=None):
     """[T, R, C] -> [T, C, R]; dtype (or out.dtype) may differ from w_tap's: fp32 master -> bf16 copy."""
     T, R, C = w_tap.shape

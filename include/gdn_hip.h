@@ -40,7 +40,7 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
-/* Revision of this header (argument lists, struct layouts).  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+/* Revision of this header (argument lists, struct layouts).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
  * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
@@ -271,6 +271,18 @@ size_t gdn_conv_c1_wgrad_workspace_bytes(void);
 int gdn_conv_c1_wgrad(const float* x1, const float* gw, int32_t ldg, int32_t B, int32_t H, int32_t W, int32_t N, int32_t k,
                       int32_t pad, int32_t reflect, int32_t flip, float* dw,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* fp32 per-bin GEMMs on the bf16 matrix pipe ("bf16 x 3": an fp32 operand is exactly the sum of three bf16 terms; six bf16
+ * products, accumulated in fp32, reproduce the fp32 product to its own rounding level at 6/16 of the matrix-pipe cycles) --
+ * the core behind the Winograd layers' per-bin GEMMs (torch / cuDNN conv2d of the 512-channel ResidualBlocks,
+ * AE_model_unet.py:45-57).  Measurement / test hooks: the product path reaches the same kernels through gdn_winoconv_*.
+ *   gdn_gemm_x3_pack : B fp32 row-major [bins][rows][K] -> packed bf16 panels (gdn_gemm_x3_packed_bytes), split once
+ *   gdn_gemm_x3_nt   : C[bin][m][n] = sum_k A[bin][m][k] * B[bin][n][k];  A fp32 row-major [bins][M][K] (split while it is
+ *                      staged), Bp the packed panels of B [bins][N][K], C fp32 row-major [bins][M][N].
+ * N a multiple of 128, K a multiple of 32 (GDN_ERR_UNSUPPORTED otherwise). */
+size_t gdn_gemm_x3_packed_bytes(int32_t bins, int32_t rows, int32_t K);
+int gdn_gemm_x3_pack(const float* src, void* dst, int32_t bins, int32_t rows, int32_t K, void* stream);
+int gdn_gemm_x3_nt(const float* A, const void* Bp, float* C, int32_t bins, int32_t M, int32_t N, int32_t K, void* stream);
 
 /* bf16 weight gradient (BASELINE configs[2]): x and dy hold bfloat16, dw is fp32 (the master
  * gradient arena).  Same contract as gdn_conv_wgrad otherwise.  Needs Cx and Cout multiples of

@@ -367,7 +367,13 @@ inline size_t u_bytes(const WinoGeom& f) {
 // GDN_X3=0 keeps every per-bin GEMM on the fp32 MFMA (A/B measurements, accuracy studies)
 inline bool x3_on() { const char* e = getenv("GDN_X3"); return !(e && e[0] == '0'); }
 inline size_t m_bytes(const WinoGeom& f) { return al256((size_t)WINO_BINS * f.M * f.N * 4); }
-inline int tn_splits(const WinoGeom& f) { return wino_tn_splits(f.M, f.N, f.C); }
+inline bool tn_x3(const WinoGeom& f) { return x3_on() && gemm_x3_tn_ok(f.M, f.N, f.C); }
+inline int tn_splits(const WinoGeom& f) { return tn_x3(f) ? gemm_x3_tn_splits(WINO_BINS, f.M, f.N, f.C) : wino_tn_splits(f.M, f.N, f.C); }
+// (workspace sizing: the larger of the two kernels' split counts, so GDN_X3 may change between the query and the call)
+inline int tn_splits_max(const WinoGeom& f) {
+    const int a = wino_tn_splits(f.M, f.N, f.C), b = gemm_x3_tn_ok(f.M, f.N, f.C) ? gemm_x3_tn_splits(WINO_BINS, f.M, f.N, f.C) : 1;
+    return a > b ? a : b;
+}
 
 }  // namespace
 
@@ -434,7 +440,7 @@ extern "C" size_t gdn_winoconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     const size_t Md = f.reflect ? (size_t)f.B * cdiv(f.H + 2, 2) * cdiv(f.W + 2, 2) : (size_t)f.M;
     const size_t vd = al256((size_t)WINO_BINS * Md * f.N * 4), eo = al256((size_t)WINO_BINS * Md * f.C * 4);
     const size_t padded = f.reflect ? al256((size_t)f.B * (f.H + 2) * (f.W + 2) * f.C * 4) : 0;
-    const size_t pr = (size_t)tn_splits(f) * al256((size_t)WINO_BINS * f.N * f.C * 4);   // weight-gradient products, one set per split
+    const size_t pr = (size_t)tn_splits_max(f) * al256((size_t)WINO_BINS * f.N * f.C * 4);   // weight-gradient products, one set per split
     return (vd > m_bytes(f) ? vd : m_bytes(f)) + u_bytes(f) + (eo > pr ? eo : pr) + padded;
 }
 
@@ -469,7 +475,8 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
     if (dw) {
         hipLaunchKernelGGL(wino_dy_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, dy, ldy, Vd, f);
         const int ns = tn_splits(f);
-        launch_wino_gemm_tn((const float*)Vd, (const float*)state, Eo, f.M, f.N, f.C, ns, st);
+        if (tn_x3(f)) launch_gemm_x3_tn((const float*)Vd, (const float*)state, Eo, WINO_BINS, f.M, f.N, f.C, ns, st);
+        else launch_wino_gemm_tn((const float*)Vd, (const float*)state, Eo, f.M, f.N, f.C, ns, st);
         hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, (const float*)Eo, dw, f.N, f.C, ns);
     }
     if (dx) {

@@ -399,9 +399,21 @@ inline size_t ux_bytes(const W2Geom& f) {
     return ua_bytes(f) + al256(pa > pb ? pa : pb);
 }
 inline bool x3_on() { const char* e = getenv("GDN_X3"); return !(e && e[0] == '0'); }
-inline int w2_splits(const W2Geom& f) { return wino_tn_splits(f.Ma, f.Cy, 4 * f.Cx); }
+inline bool w2_tn_x3(const W2Geom& f) { return x3_on() && gemm_x3_tn_ok(f.Ma, f.Cy, 4 * f.Cx); }
+inline int w2_splits(const W2Geom& f) {
+    return w2_tn_x3(f) ? gemm_x3_tn_splits(WINO_BINS, f.Ma, f.Cy, 4 * f.Cx) : wino_tn_splits(f.Ma, f.Cy, 4 * f.Cx);
+}
+inline int w2_splits_max(const W2Geom& f) {
+    const int a = wino_tn_splits(f.Ma, f.Cy, 4 * f.Cx);
+    const int b = gemm_x3_tn_ok(f.Ma, f.Cy, 4 * f.Cx) ? gemm_x3_tn_splits(WINO_BINS, f.Ma, f.Cy, 4 * f.Cx) : 1;
+    return a > b ? a : b;
+}
+void w2_gemm_tn(const W2Geom& f, const float* Dv, const float* V, float* P, int ns, hipStream_t st) {
+    if (w2_tn_x3(f)) launch_gemm_x3_tn(Dv, V, P, WINO_BINS, f.Ma, f.Cy, 4 * f.Cx, ns, st);
+    else launch_wino_gemm_tn(Dv, V, P, f.Ma, f.Cy, 4 * f.Cx, ns, st);
+}
 inline size_t p_bytes(const W2Geom& f) {                                                                // P, one set per split
-    const size_t pr = (size_t)w2_splits(f) * ua_bytes(f);
+    const size_t pr = (size_t)w2_splits_max(f) * ua_bytes(f);
     return pr > ux_bytes(f) ? pr : ux_bytes(f);
 }
 // the 16 per-bin GEMMs Cm = A * U^T: as bf16 x 3 split products on the bf16 matrix pipe where the shape allows, else fp32 MFMA
@@ -523,7 +535,7 @@ extern "C" int gdn_wino2conv_bwd(const gdn_conv_geom* g, const float* dy, int32_
             float* P = U;
             hipLaunchKernelGGL(w2_lift_kernel, dim3(cdiv(f.Ma, 4) << f.yq), dim3(256), 0, st, x, ldx_in, Dv, f);
             const int ns = w2_splits(f);
-            launch_wino_gemm_tn((const float*)Dv, (const float*)V, P, f.Ma, f.Cy, 4 * f.Cx, ns, st);
+            w2_gemm_tn(f, (const float*)Dv, (const float*)V, P, ns, st);
             hipLaunchKernelGGL(w2_wgrad_output_kernel, dim3(cdiv(f.Cy * f.Cx, 256)), dim3(256), 0, st, (const float*)P, dw, f.Cy, f.Cx, 1, ns);
         }
         return gdn_launch_status();
@@ -538,7 +550,7 @@ extern "C" int gdn_wino2conv_bwd(const gdn_conv_geom* g, const float* dy, int32_
         float* P = U;
         hipLaunchKernelGGL(w2_lift_kernel, dim3(cdiv(f.Ma, 4) << f.yq), dim3(256), 0, st, dy, ldy, Dv, f);
         const int ns = w2_splits(f);
-        launch_wino_gemm_tn((const float*)Dv, (const float*)state, P, f.Ma, f.Cy, 4 * f.Cx, ns, st);
+        w2_gemm_tn(f, (const float*)Dv, (const float*)state, P, ns, st);
         hipLaunchKernelGGL(w2_wgrad_output_kernel, dim3(cdiv(f.Cy * f.Cx, 256)), dim3(256), 0, st, (const float*)P, dw, f.Cy, f.Cx, 0, ns);
     }
     if (dx) {

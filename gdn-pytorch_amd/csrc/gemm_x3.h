@@ -58,3 +58,15 @@ void launch_gemm_x3_nt(const float* A, const void* Bp, float* C, int bins, int M
 // packs fp32 row-major [bins][rows][K] into panels (rows padded with zeros to whole tiles)
 void launch_x3_pack_rows(const float* src, void* dst, int bins, int rows, int K, hipStream_t st);
 static inline bool gemm_x3_ok(int M, int N, int K) { return M >= 1 && N >= 128 && N % 128 == 0 && K >= 32 && K % 32 == 0; }
+// P[split][bin][i][j] = sum over the split's rows t of A[bin][t][i] * Bm[bin][t][j]  (fp32 row-major operands [bins][T][NI] /
+// [bins][T][NJ], both split on the fly); the caller sums the nsplit partial sets in a fixed order.  NI, NJ multiples of 128.
+void launch_gemm_x3_tn(const float* A, const float* Bm, float* P, int bins, int T, int NI, int NJ, int nsplit, hipStream_t st);
+static inline bool gemm_x3_tn_ok(int T, int NI, int NJ) { return T >= 1 && NI >= 128 && NI % 128 == 0 && NJ >= 128 && NJ % 128 == 0; }
+// splits of the reduction: two workgroups per CU fill the chip at 512 workgroups; chunks of at least 256 rows, at most 8
+static inline int gemm_x3_tn_splits(int bins, int T, int NI, int NJ) {
+    const int wgs = (NI / 128) * (NJ / 128) * bins;
+    int s = (512 + wgs - 1) / wgs;
+    if (s > 8) s = 8;
+    while (s > 1 && T / s < 256) --s;
+    return s < 1 ? 1 : s;
+}

@@ -30,6 +30,42 @@ __global__ __launch_bounds__(256) void x3_pack_rows_kernel(const float* __restri
     }
 }
 
+// One 32-deep stage of a wave's 64 x 64 tile from the LDS images As / Bs ([plane][128 rows][64 B], chunk-swizzled): two
+// sub-steps of 6 + 6 fragment reads and 24 MFMAs.
+__device__ __forceinline__ void x3_stage_mfma(const unsigned char* As, const unsigned char* Bs, int a_base, int b_base, int h, int f_sw,
+                                              f32x16 (&acc)[2][2], f32x16 (&cor)[2][2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int co = ((2 * s + h) ^ f_sw) * 16;
+        x3_bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                af[i][p] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(&As[p * 8192 + a_base + i * 2048 + co]));
+                bf[i][p] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(&Bs[p * 8192 + b_base + i * 2048 + co]));
+            }
+        // The bf16 MFMA aligns its 16 products AND the C input to the largest exponent among them and truncates what
+        // falls below ~half an ulp of it, per addend, toward zero (measured: tests/diag/mfma_rounding.py); the sum itself is
+        // rounded to nearest.  A leading product a1*b1 has a 16-bit significand, so against a running sum sqrt(K) larger
+        // it loses nothing; a correction product sits 8 or 16 bits lower and WOULD be cut at the running sum's ulp.  Hence
+        // two accumulators: `acc` chains the leading products, `cor` chains the five correction products (its own ulp is
+        // 2^-8 of acc's), and the two meet once, in the epilogue.  No vector-ALU work in the loop; 32 roundings per
+        // K = 512 instead of the 512 of the k-ordered fp32 MFMA chain this replaces.
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], cor[i][j], 0, 0, 0);
+                cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], cor[i][j], 0, 0, 0);
+                cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], cor[i][j], 0, 0, 0);
+                cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], cor[i][j], 0, 0, 0);
+                cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], cor[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            }
+    }
+}
+
 // ---- the GEMM ----
 // Workgroup = 128 x 128 output tile, 4 waves (2 x 2) of 64 x 64 = 2 x 2 MFMA tiles; a stage is 32 k: per wave 2 sub-steps of
 // (6 + 6 fragment reads, 24 MFMAs).  LDS: three bf16 planes of A and of B, [plane][128 rows][64 B] each (48 KB); two
@@ -99,36 +135,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(const float* __restr
         lstore();
         __syncthreads();
         if (kb + 1 < KB) gload(kb + 1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int co = ((2 * s + h) ^ f_sw) * 16;
-            x3_bf16x8 af[2][3], bf[2][3];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    af[i][p] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(&As[p * 8192 + a_base + i * 2048 + co]));
-                    bf[i][p] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(&Bs[p * 8192 + b_base + i * 2048 + co]));
-                }
-            // The bf16 MFMA aligns its 16 products AND the C input to the largest exponent among them and truncates what
-            // falls below ~half an ulp of it, per addend, toward zero (measured: tests/diag/mfma_rounding.py); the sum itself is
-            // rounded to nearest.  A leading product a1*b1 has a 16-bit significand, so against a running sum sqrt(K) larger
-            // it loses nothing; a correction product sits 8 or 16 bits lower and WOULD be cut at the running sum's ulp.  Hence
-            // two accumulators: `acc` chains the leading products, `cor` chains the five correction products (its own ulp is
-            // 2^-8 of acc's), and the two meet once, in the epilogue.  No vector-ALU work in the loop; 32 roundings per
-            // K = 512 instead of the 512 of the k-ordered fp32 MFMA chain this replaces.
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], cor[i][j], 0, 0, 0);
-                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], cor[i][j], 0, 0, 0);
-                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], cor[i][j], 0, 0, 0);
-                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], cor[i][j], 0, 0, 0);
-                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], cor[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                }
-        }
+        x3_stage_mfma(As, Bs, a_base, b_base, h, f_sw, acc, cor);
         __syncthreads();
     }
 #pragma unroll
@@ -140,6 +147,90 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(const float* __restr
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m < M) Cb[(size_t)m * N + col] = acc[i][j][r] + cor[i][j][r];
+            }
+        }
+}
+
+// Reduction-over-rows GEMM (the weight gradients):  P[split][bin][i][j] = sum_t A[bin][t][i] * Bm[bin][t][j], t in the split's
+// chunk of the T rows -- both operands fp32 row-major [bins][T][NI] / [bins][T][NJ], read as they lie (rows = the reduction).
+// The MFMA wants 8 consecutive t per lane: a thread loads 8 rows x 2 channels (coalesced 8-byte loads, a wave covers 128
+// channels of one row), so the 8 t values of a channel already sit in one thread's registers -- the transposition is the
+// register naming -- splits them and writes one 16-byte chunk per plane and channel: the LDS image is the NT kernel's
+// ([plane][channel][32 t], chunk-swizzled) and the MFMA stage is shared.  Both operands are split on the fly here (32 values
+// per thread and stage, ~176 vector instructions under 48 MFMAs per wave).
+__global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                            float* __restrict__ P, int T, int NI, int NJ, int nsplit, int bins) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[3 * 128 * 64], Bs[3 * 128 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int TI = NI / 128, TJ = NJ / 128;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int bin = (sq / (TI * TJ * nsplit)) * 8 + xcd;
+    if (bin >= bins) return;
+    const int split = (sq / (TI * TJ)) % nsplit, i0 = ((sq / TJ) % TI) * 128, j0 = (sq % TJ) * 128;
+    const int chunk = ((T + nsplit - 1) / nsplit + 31) / 32 * 32;
+    const int tb = split * chunk, te = tb + chunk < T ? tb + chunk : T;        // this workgroup reduces rows [tb, te)
+    f32x16 acc[2][2], cor[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; cor[i][j][r] = 0.f; }
+    // staging: thread = (t8 = tid >> 6: rows t8*8 .. t8*8+7 of the stage, cp = tid & 63: channels 2 cp, 2 cp + 1)
+    const int t8 = tid >> 6, cp = tid & 63;
+    const float* ap = A + ((size_t)bin * T) * NI + i0 + cp * 2;
+    const float* bp = Bm + ((size_t)bin * T) * NJ + j0 + cp * 2;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 ra[8], rb[8];
+    auto gload = [&](int t0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int t = t0 + t8 * 8 + e;
+            const f32x2 z = {0.f, 0.f};
+            ra[e] = t < te ? *reinterpret_cast<const f32x2*>(ap + (size_t)t * NI) : z;
+            rb[e] = t < te ? *reinterpret_cast<const f32x2*>(bp + (size_t)t * NJ) : z;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {                    // the thread's two channels = two LDS rows
+            const int row = cp * 2 + c;
+            const int off = row * 64 + ((t8 ^ ((row >> 2) & 3)) * 16);
+            unsigned ha[3][4], hb[3][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                x3_split2(ra[2 * q][c], ra[2 * q + 1][c], ha[0][q], ha[1][q], ha[2][q]);
+                x3_split2(rb[2 * q][c], rb[2 * q + 1][c], hb[0][q], hb[1][q], hb[2][q]);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const uint4 va = {ha[p][0], ha[p][1], ha[p][2], ha[p][3]}, vb = {hb[p][0], hb[p][1], hb[p][2], hb[p][3]};
+                *reinterpret_cast<uint4*>(&As[p * 8192 + off]) = va;
+                *reinterpret_cast<uint4*>(&Bs[p * 8192 + off]) = vb;
+            }
+        }
+    };
+    const int r32 = lane & 31, h = lane >> 5;
+    const int f_sw = (r32 >> 2) & 3;
+    const int a_base = (wm * 64 + r32) * 64, b_base = (wn * 64 + r32) * 64;
+    gload(tb);
+    for (int t0 = tb; t0 < te; t0 += 32) {
+        lstore();
+        __syncthreads();
+        if (t0 + 32 < te) gload(t0 + 32);
+        x3_stage_mfma(As, Bs, a_base, b_base, h, f_sw, acc, cor);
+        __syncthreads();
+    }
+    float* Pb = P + (((size_t)split * bins + bin) * NI) * NJ;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j0 + wn * 64 + j * 32 + r32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                Pb[(size_t)row * NJ + col] = acc[i][j][r] + cor[i][j][r];
             }
         }
 }
@@ -157,6 +248,12 @@ void launch_x3_pack_rows(const float* src, void* dst, int bins, int rows, int K,
 void launch_gemm_x3_nt(const float* A, const void* Bp, float* C, int bins, int M, int N, int K, hipStream_t st) {
     const int NT = N / 128, MT = (M + 127) / 128, bg = (bins + 7) / 8;
     hipLaunchKernelGGL(gemm_x3_nt_kernel, dim3(MT * NT * bg * 8), dim3(256), 0, st, A, (const unsigned char*)Bp, C, M, N, K, bins);
+}
+
+void launch_gemm_x3_tn(const float* A, const float* Bm, float* P, int bins, int T, int NI, int NJ, int nsplit, hipStream_t st) {
+    const int bg = (bins + 7) / 8;
+    hipLaunchKernelGGL(gemm_x3_tn_kernel, dim3((NI / 128) * (NJ / 128) * nsplit * bg * 8), dim3(256), 0, st, A, Bm, P, T, NI, NJ,
+                       nsplit, bins);
 }
 
 // ---- C ABI: measurement / test hooks (the product path calls the launchers from the Winograd entry points) ----
@@ -178,5 +275,14 @@ extern "C" int gdn_gemm_x3_nt(const float* A, const void* Bp, float* C, int32_t 
     if (!A || !Bp || !C || bins < 1) return GDN_ERR_BAD_ARG;
     if (!gemm_x3_ok(M, N, K)) return GDN_ERR_UNSUPPORTED;
     launch_gemm_x3_nt(A, Bp, C, bins, M, N, K, (hipStream_t)stream);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_gemm_x3_tn(const float* A, const float* Bm, float* P, int32_t bins, int32_t T, int32_t NI, int32_t NJ,
+                              int32_t nsplit, void* stream) {
+    (void)hipGetLastError();
+    if (!A || !Bm || !P || bins < 1 || T < 1 || nsplit < 1) return GDN_ERR_BAD_ARG;
+    if (!gemm_x3_tn_ok(T, NI, NJ)) return GDN_ERR_UNSUPPORTED;
+    launch_gemm_x3_tn(A, Bm, P, bins, T, NI, NJ, nsplit, (hipStream_t)stream);
     return gdn_launch_status();
 }

@@ -452,6 +452,16 @@ def gemm_x3_nt(A, Bp, N, out=None):
     return C
 
 
+def gemm_x3_tn(A, Bm, nsplit=1):
+    """P[split, bin] = A[bin]^T @ B[bin] over the split's rows; A [bins, T, NI], B [bins, T, NJ] fp32 -> [nsplit, bins, NI, NJ]."""
+    _chk(A, "A"); _chk(Bm, "B")
+    bins, T, NI = A.shape
+    NJ = Bm.shape[2]
+    P = torch.empty((nsplit, bins, NI, NJ), dtype=torch.float32, device=A.device)
+    lib.gdn_gemm_x3_tn(_p(A), _p(Bm), _p(P), bins, T, NI, NJ, nsplit, stream())
+    return P
+
+
 def transpose_taps(w_tap, out=None, dtype=None):
     """[T, R, C] -> [T, C, R]; dtype (or out.dtype) may differ from w_tap's: fp32 master -> bf16 copy."""
     T, R, C = w_tap.shape

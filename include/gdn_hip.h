@@ -279,10 +279,15 @@ int gdn_conv_c1_wgrad(const float* x1, const float* gw, int32_t ldg, int32_t B, 
  *   gdn_gemm_x3_pack : B fp32 row-major [bins][rows][K] -> packed bf16 panels (gdn_gemm_x3_packed_bytes), split once
  *   gdn_gemm_x3_nt   : C[bin][m][n] = sum_k A[bin][m][k] * B[bin][n][k];  A fp32 row-major [bins][M][K] (split while it is
  *                      staged), Bp the packed panels of B [bins][N][K], C fp32 row-major [bins][M][N].
+ *   gdn_gemm_x3_tn   : P[split][bin][i][j] = sum_t A[bin][t][i] * B[bin][t][j] over the split's chunk of the T rows (the weight
+ *                      gradients' reduction over tiles); A [bins][T][NI], B [bins][T][NJ] fp32 row-major, both split while staged;
+ *                      P fp32 [nsplit][bins][NI][NJ], partial sets to be summed by the caller.  NI, NJ multiples of 128.
  * N a multiple of 128, K a multiple of 32 (GDN_ERR_UNSUPPORTED otherwise). */
 size_t gdn_gemm_x3_packed_bytes(int32_t bins, int32_t rows, int32_t K);
 int gdn_gemm_x3_pack(const float* src, void* dst, int32_t bins, int32_t rows, int32_t K, void* stream);
 int gdn_gemm_x3_nt(const float* A, const void* Bp, float* C, int32_t bins, int32_t M, int32_t N, int32_t K, void* stream);
+int gdn_gemm_x3_tn(const float* A, const float* B, float* P, int32_t bins, int32_t T, int32_t NI, int32_t NJ, int32_t nsplit,
+                   void* stream);
 
 /* bf16 weight gradient (BASELINE configs[2]): x and dy hold bfloat16, dw is fp32 (the master
  * gradient arena).  Same contract as gdn_conv_wgrad otherwise.  Needs Cx and Cout multiples of

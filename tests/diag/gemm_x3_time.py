@@ -43,3 +43,9 @@ for lvl, (H, W) in ((3, (16, 52)), (4, (8, 26))):
     Mo = torch.empty(16, tiles, 512, device=dev)
     ms = timed(lambda: op.wino_gemm_only(V, U, Mo, 20, H, W))
     print("fp32 MFMA wino_gemm level %d (M %d): %.3f ms = %.1f TF" % (lvl, tiles, ms, 2.0 * 16 * tiles * 512 * 512 / ms / 1e9))
+# the reduction (weight-gradient) GEMM: level 3 / level 4 of the 512-channel layers
+for name, T in (("wino tn l3", 4160), ("wino tn l4", 1040)):
+    A = torch.randn(16, T, 512, device=dev); B = torch.randn(16, T, 512, device=dev)
+    for ns in (1, 2, 4):
+        ms = timed(lambda: ops.gemm_x3_tn(A, B, ns))
+        print("%s T %d splits %d: x3 %.3f ms = %.1f TF fp32-equiv" % (name, T, ns, ms, 2.0 * 16 * T * 512 * 512 / ms / 1e9), flush=True)

@@ -44,3 +44,31 @@ def test_gemm_x3_rejects_unsupported(gpu):
     Bp = ops.gemm_x3_pack(torch.zeros(1, 128, 64, device=gpu))
     with pytest.raises(GdnError):
         ops.gemm_x3_nt(A, Bp, 96)                      # N not a multiple of 128
+
+
+@pytest.mark.parametrize("bins,T,NI,NJ,ns", [(1, 32, 128, 128, 1), (2, 1000, 256, 128, 3), (16, 1040, 512, 512, 2), (3, 77, 128, 384, 1)])
+def test_gemm_x3_tn_matches_fp64(gpu, bins, T, NI, NJ, ns):
+    """The weight gradients' reduction GEMM P = A^T B over rows (both operands split on the fly, transposed in registers),
+    with the reduction cut into `ns` partial sets: their sum against fp64, same bar as the NT kernel."""
+    from gdn_amd import ops
+    g = torch.Generator().manual_seed(bins * 100 + T)
+    A = torch.randn(bins, T, NI, generator=g) * torch.logspace(-1, 1, NI).view(1, 1, NI)
+    B = torch.randn(bins, T, NJ, generator=g)
+    ref = torch.bmm(A.double().transpose(1, 2), B.double())
+    scale = torch.bmm(A.double().abs().transpose(1, 2), B.double().abs())
+    P = ops.gemm_x3_tn(A.to(gpu), B.to(gpu), ns).cpu().double()
+    assert P.shape == (ns, bins, NI, NJ)
+    err = float(((P.sum(0) - ref).abs() / scale).max())
+    print("gemm_x3_tn %dx%dx%dx%d/%d: max err / sum|a||b| = %.3e" % (bins, T, NI, NJ, ns, err))
+    assert err < 4e-6
+
+
+def test_gemm_x3_tn_exact_on_integers(gpu):
+    from gdn_amd import ops
+    g = torch.Generator().manual_seed(6)
+    bins, T, NI, NJ = 2, 100, 128, 256
+    A = torch.randint(-8, 9, (bins, T, NI), generator=g).float() + torch.arange(NI).view(1, 1, NI).float()
+    B = torch.randint(-8, 9, (bins, T, NJ), generator=g).float()
+    ref = torch.bmm(A.double().transpose(1, 2), B.double())
+    P = ops.gemm_x3_tn(A.to(gpu), B.to(gpu), 2).cpu().double().sum(0)
+    assert torch.equal(P, ref)

@@ -94,34 +94,39 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; cor[i][j][r] = 0.f; }
 
-    // A staging: thread = (row = tid >> 1, half = tid & 1): 16 consecutive k (64 B) of one row; rows past M read row M - 1
-    const int arow = tid >> 1, ahalf = tid & 1;
-    const int am = m0 + arow < M ? m0 + arow : M - 1;
-    const float* ap = Ab + (size_t)am * K + ahalf * 16;
+    // A staging: 8 lanes fetch one row's 32 k = a full 128-byte line (lane = 4 k), a wave instruction 8 rows; a thread holds
+    // rows rb, rb + 32, rb + 64, rb + 96.  (Fetching 16 k per thread -- 16-byte pieces of 32 different lines per instruction --
+    // measured 1.2x slower: the texture path, not the matrix pipe, set the pace.)  Rows past M read row M - 1.
+    const int k4 = tid & 7, rb0 = tid >> 3;
+    const float* ap[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int row = v * 32 + rb0;
+        ap[v] = Ab + (size_t)(m0 + row < M ? m0 + row : M - 1) * K + k4 * 4;
+    }
     f32x4 ra[4];
     f32x4 rb[6];
     auto gload = [&](int kb) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) ra[v] = *reinterpret_cast<const f32x4*>(ap + (size_t)kb * X3_BK + v * 4);
+        for (int v = 0; v < 4; ++v) ra[v] = *reinterpret_cast<const f32x4*>(ap[v] + (size_t)kb * X3_BK);
         const unsigned char* bsrc = Bb + (size_t)kb * (3 * 128 * 64) + tid * 16;
 #pragma unroll
         for (int v = 0; v < 6; ++v) rb[v] = *reinterpret_cast<const f32x4*>(bsrc + v * 4096);
     };
-    const int a_sw = (arow >> 2) & 3;
     auto lstore = [&]() {
-        unsigned h[3][8];                            // packed pairs: k = 2 q, 2 q + 1
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            x3_split2(ra[v][0], ra[v][1], h[0][v * 2], h[1][v * 2], h[2][v * 2]);
-            x3_split2(ra[v][2], ra[v][3], h[0][v * 2 + 1], h[1][v * 2 + 1], h[2][v * 2 + 1]);
-        }
+            const int row = v * 32 + rb0;
+            unsigned h0[3], h1[3];
+            x3_split2(ra[v][0], ra[v][1], h0[0], h0[1], h0[2]);
+            x3_split2(ra[v][2], ra[v][3], h1[0], h1[1], h1[2]);
+            const int off = row * 64 + (((k4 >> 1) ^ ((row >> 2) & 3)) * 16) + (k4 & 1) * 8;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {            // the thread's two 16-byte chunks (k = half*16 + c*8 ..)
-                const uint4 v = {h[p][c * 4 + 0], h[p][c * 4 + 1], h[p][c * 4 + 2], h[p][c * 4 + 3]};
-                *reinterpret_cast<uint4*>(&As[(p * 128 + arow) * 64 + (((ahalf * 2 + c) ^ a_sw) * 16)]) = v;
+            for (int p = 0; p < 3; ++p) {
+                const uint2 w = {h0[p], h1[p]};
+                *reinterpret_cast<uint2*>(&As[p * 8192 + off]) = w;
             }
+        }
 #pragma unroll
         for (int v = 0; v < 6; ++v) *reinterpret_cast<f32x4*>(&Bs[v * 4096 + tid * 16]) = rb[v];
     };
@@ -148,6 +153,108 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(const float* __restr
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m < M) Cb[(size_t)m * N + col] = acc[i][j][r] + cor[i][j][r];
             }
+        }
+}
+
+// ---- NT kernel, second structure: 512 threads, double-buffered LDS, ONE barrier per stage ----
+// 8 waves (2 x 4): wave tile (TM/2) x 32 = MI x 1 MFMA tiles (TM = 128: MI = 2; TM = 64 for GEMMs with few rows: MI = 1).  Both
+// operands' stage k + 1 is written to the other LDS buffer while stage k is multiplied, so the split arithmetic and the LDS
+// writes of one wave run under the MFMAs of the wave it shares a SIMD with, and a stage costs one barrier:
+//     iteration k:  split(regs) -> buf[(k+1)&1];  global loads of stage k + 2 -> regs;  MFMAs from buf[k&1];  barrier
+// LDS 2 x (3 TM + 3 x 128) x 64 B = 96 KB at TM = 128: one workgroup (two waves per SIMD) per CU.
+template <int TM>
+__global__ __launch_bounds__(512, 2) void gemm_x3_nt8_kernel(const float* __restrict__ A, const unsigned char* __restrict__ Bp,
+                                                             float* __restrict__ C, int M, int N, int K, int bins) {
+    constexpr int MI = TM / 64, A_BYTES = 3 * TM * 64, B_BYTES = 3 * 128 * 64;
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][A_BYTES], Bs[2][B_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+    const int NT = N / 128, MT = (M + TM - 1) / TM, KB = K / X3_BK;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int bin = (sq / (NT * MT)) * 8 + xcd;
+    if (bin >= bins) return;
+    const int m0 = ((sq / NT) % MT) * TM, nt = sq % NT;
+    const float* Ab = A + (size_t)bin * M * K;
+    const unsigned char* Bb = Bp + (size_t)bin * x3_packed_bytes(N, K) + (size_t)nt * KB * B_BYTES;
+    float* Cb = C + (size_t)bin * M * N;
+    f32x16 acc[MI], cor[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; cor[i][r] = 0.f; }
+    // A staging: 8 lanes per row (a full 128-byte line), 64 rows per pass, MI passes
+    const int k4 = tid & 7, rb0 = tid >> 3;
+    const float* ap[MI];
+#pragma unroll
+    for (int v = 0; v < MI; ++v) {
+        const int row = v * 64 + rb0;
+        ap[v] = Ab + (size_t)(m0 + row < M ? m0 + row : M - 1) * K + k4 * 4;
+    }
+    f32x4 ra[MI], rb[3];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int v = 0; v < MI; ++v) ra[v] = *reinterpret_cast<const f32x4*>(ap[v] + (size_t)kb * X3_BK);
+        const unsigned char* bsrc = Bb + (size_t)kb * B_BYTES + tid * 16;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) rb[v] = *reinterpret_cast<const f32x4*>(bsrc + v * 8192);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int v = 0; v < MI; ++v) {
+            const int row = v * 64 + rb0;
+            unsigned h0[3], h1[3];
+            x3_split2(ra[v][0], ra[v][1], h0[0], h0[1], h0[2]);
+            x3_split2(ra[v][2], ra[v][3], h1[0], h1[1], h1[2]);
+            const int off = row * 64 + (((k4 >> 1) ^ ((row >> 2) & 3)) * 16) + (k4 & 1) * 8;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const uint2 w = {h0[p], h1[p]};
+                *reinterpret_cast<uint2*>(&As[buf][p * TM * 64 + off]) = w;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 3; ++v) *reinterpret_cast<f32x4*>(&Bs[buf][v * 8192 + tid * 16]) = rb[v];
+    };
+    const int r32 = lane & 31, h = lane >> 5;
+    const int f_sw = (r32 >> 2) & 3;
+    const int a_base = (wm * (TM / 2) + r32) * 64, b_base = (wn * 32 + r32) * 64;
+    gload(0);
+    lstore(0);
+    if (KB > 1) gload(1);
+    __syncthreads();
+    for (int kb = 0; kb < KB; ++kb) {
+        const int cur = kb & 1;
+        if (kb + 1 < KB) lstore(cur ^ 1);                    // stage kb + 1 (in registers since the last iteration)
+        if (kb + 2 < KB) gload(kb + 2);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int co = ((2 * s + h) ^ f_sw) * 16;
+            x3_bf16x8 af[MI][3], bf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                bf[p] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(&Bs[cur][p * 8192 + b_base + co]));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    af[i][p] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(&As[cur][p * TM * 64 + a_base + i * 2048 + co]));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {            // (accumulator roles: see x3_stage_mfma)
+                cor[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], cor[i], 0, 0, 0);
+                cor[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], cor[i], 0, 0, 0);
+                cor[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[2], cor[i], 0, 0, 0);
+                cor[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], cor[i], 0, 0, 0);
+                cor[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], cor[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const int col = nt * 128 + wn * 32 + r32;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < M) Cb[(size_t)m * N + col] = acc[i][r] + cor[i][r];
         }
 }
 
@@ -247,7 +354,20 @@ void launch_x3_pack_rows(const float* src, void* dst, int bins, int rows, int K,
 
 void launch_gemm_x3_nt(const float* A, const void* Bp, float* C, int bins, int M, int N, int K, hipStream_t st) {
     const int NT = N / 128, MT = (M + 127) / 128, bg = (bins + 7) / 8;
-    hipLaunchKernelGGL(gemm_x3_nt_kernel, dim3(MT * NT * bg * 8), dim3(256), 0, st, A, (const unsigned char*)Bp, C, M, N, K, bins);
+    // Measured (B = 20, profiles/r03_gemm_x3_time_*.txt): the 256-thread kernel (two workgroups per CU, two barriers per stage)
+    // is the fastest on the large GEMMs (level 3: 0.264 ms against 0.281 for the 512-thread double-buffered one); with few row
+    // tiles (level 4, M = 1040: 576 tiles of 128 rows = 2.25 rounds of the chip) 64-row tiles win (0.067 against 0.078 ms).
+    // GDN_X3_NT = 4 / 8 / 64 forces a variant (measurement).
+    const char* e = getenv("GDN_X3_NT");
+    const int v = e ? atoi(e) : 0;
+    const bool small = v == 64 || (v == 0 && (int64_t)MT * NT * bins < 4 * 256);
+    if (small)
+        hipLaunchKernelGGL(gemm_x3_nt8_kernel<64>, dim3(((M + 63) / 64) * NT * bg * 8), dim3(512), 0, st, A, (const unsigned char*)Bp, C, M,
+                           N, K, bins);
+    else if (v == 8)
+        hipLaunchKernelGGL(gemm_x3_nt8_kernel<128>, dim3(MT * NT * bg * 8), dim3(512), 0, st, A, (const unsigned char*)Bp, C, M, N, K, bins);
+    else
+        hipLaunchKernelGGL(gemm_x3_nt_kernel, dim3(MT * NT * bg * 8), dim3(256), 0, st, A, (const unsigned char*)Bp, C, M, N, K, bins);
 }
 
 void launch_gemm_x3_tn(const float* A, const float* Bm, float* P, int bins, int T, int NI, int NJ, int nsplit, hipStream_t st) {

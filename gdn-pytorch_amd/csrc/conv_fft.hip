@@ -581,18 +581,33 @@ __global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __
     const float* ad = addsrc ? addsrc + ((size_t)(b * Ho + iy) * Wo + ix0) * ld_add + c : nullptr;   // dereferenced in range
     const bool has_next = tx + 1 < g.tiles_x;
     const int km1 = g.k - 1;
+    // (the pointers are made to depend on the transform's output: otherwise the loads below are hoisted above the transform,
+    // their NP results stay live across it and the kernel drops from three waves per SIMD to two)
+    asm volatile("" : "+v"(dst), "+v"(ad) : "v"(re[NP - 1]), "v"(re[0]));
+    // Every column adds ONE earlier value to its result: what the even neighbours stored (odd tiles, shared columns), or the
+    // addsrc term (first writer of a column), or nothing.  All of those loads are issued first, from clamped addresses, so
+    // none sits behind a branch (with the read-modify-write inside the store loop the compiler waited for each before the
+    // next: one dependent round trip per column).
+    constexpr int HB = NP / 2;                 // (in two halves: NP / 2 loads in flight, NP / 2 extra registers)
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int ix = ix0 + j;
-        if (ix >= 0 && ix < Wo) {
-            const float val = re[j] * (1.0f / (NP * NP));
-            // odd tiles: columns shared with the even neighbours were stored by the first launch
+    for (int hb = 0; hb < 2; ++hb) {
+        float prev[HB];
+#pragma unroll
+        for (int j2 = 0; j2 < HB; ++j2) {
+            const int j = hb * HB + j2, ix = ix0 + j;
+            const bool in = ix >= 0 && ix < Wo;
             const bool second = parity == 1 && (j < km1 || (j >= T && has_next));
-            if (second) *dst += val;
-            else *dst = ad ? val + *ad : val;
+            const int jc = (in ? j : (ix < 0 ? -ix0 : Wo - 1 - ix0)) - hb * HB;     // a column of this row that exists
+            const float* src = (second || !ad) ? dst + (ptrdiff_t)jc * lddx : ad + (ptrdiff_t)jc * ld_add;
+            prev[j2] = (second || ad) ? *src : 0.f;
         }
-        dst += lddx; GDN_KEEP(dst);
-        if (ad) { ad += ld_add; GDN_KEEP(ad); }
+#pragma unroll
+        for (int j2 = 0; j2 < HB; ++j2) {
+            const int j = hb * HB + j2, ix = ix0 + j;
+            if (ix >= 0 && ix < Wo) *dst = re[j] * (1.0f / (NP * NP)) + prev[j2];
+            dst += lddx; GDN_KEEP(dst);
+        }
+        if (ad) { ad += (ptrdiff_t)HB * ld_add; GDN_KEEP(ad); }
     }
 }
 

@@ -40,6 +40,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md, dense bf16 (v_mfma_f32_32x32x16_bf16); never the 2:1-sparse figure
 DTOD_TRAIN_GFLOP_PER_IMG = 1017.5
 
 
@@ -90,9 +91,11 @@ def wino_roofline(dev, B, reps=20):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    ms_g = timed(lambda: op.wino_gemm_only(V, U, Mo, B, H, W))
+    ms_g = timed(lambda: op.wino_gemm_only(V, U, Mo, B, H, W))           # the fp32 MFMA per-bin GEMM (GDN_X3=0 path)
+    Up = ops.gemm_x3_pack(U)
+    ms_x = timed(lambda: ops.gemm_x3_nt(V, Up, C, out=Mo))                # the same 16 GEMMs as bf16 x 3 split products
     ms_l = timed(lambda: op.wino_fwd(x, w, stats=True, state=True))
-    return ms_g, 2.0 * 16 * tiles * C * C, ms_l, 2.0 * B * H * W * 9 * C * C
+    return ms_g, 2.0 * 16 * tiles * C * C, ms_l, 2.0 * B * H * W * 9 * C * C, ms_x
 
 
 def fftconv_roofline(dev, B, reps=10):
@@ -605,15 +608,28 @@ def main():
                                 "frac": round(fl4 / (ms4 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                 "gflop_per_launch": round(fl4 / 1e9, 2), "ms_per_launch": round(ms4, 4)},
             }
-            # dominant kernel of the step since the 3x3 512-channel layers run as Winograd F(2x2,3x3): its per-bin GEMMs
-            ms_g, fl_g, ms_l, fl_l = wino_roofline(dev, B)
+            # dominant kernel of the step: the per-bin GEMMs of the Winograd layers, since round 3 executed as bf16 x 3 split
+            # products on the bf16 matrix pipe (csrc/gemm_x3.hip: six bf16 MFMA products per fp32 product)
+            ms_g, fl_g, ms_l, fl_l, ms_x = wino_roofline(dev, B)
+            ax = fl_g / (ms_x * 1e-3) / 1e12                   # algorithmic (fp32) TFLOP/s
             ag = fl_g / (ms_g * 1e-3) / 1e12
             rec["roofline"] = {
-                "kernel": "wino_gemm_kernel: the 16 per-bin fp32 MFMA GEMMs [%d x 512] x [512 x 512] of the Winograd F(2x2,3x3) "
-                          "3x3 s1 512->512 layer, B=%d 16x52 (level 3)" % (B * 8 * 26, B),
-                "bound": "mfma", "achieved": round(ag, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ag / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("r02_wino_gemm_pmc.json"),
-                "gflop_per_launch": round(fl_g / 1e9, 2), "ms_per_launch": round(ms_g, 4),
+                "kernel": "gemm_x3_nt_kernel: the 16 per-bin fp32 GEMMs [%d x 512] x [512 x 512] of the Winograd F(2x2,3x3) 3x3 s1 "
+                          "512->512 layer, B=%d 16x52 (level 3), as bf16 x 3 split products (6 bf16 MFMA products per fp32 "
+                          "product, fp32 accumulate)" % (B * 8 * 26, B),
+                "bound": "mfma", "unit": "TFLOP/s",
+                "achieved": round(ax, 2), "peak": round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1), "frac": round(6.0 * ax / PEAK_BF16_MFMA_TFLOPS, 4),
+                "note": "achieved = ALGORITHMIC fp32 FLOPs (2 M N K per bin) / time; peak = what the pipe the kernel runs on can "
+                        "deliver of them: the dense bf16 MFMA peak (2500) / 6 products.  frac is therefore also executed bf16 "
+                        "FLOPs / bf16 peak.  Against the fp32 MFMA instruction this kernel replaces (157.3 TFLOP/s peak) the "
+                        "same figure is frac_of_fp32_mfma_peak",
+                "executed_bf16_tflops": round(6.0 * ax, 1), "bf16_peak": PEAK_BF16_MFMA_TFLOPS,
+                "frac_of_fp32_mfma_peak": round(ax / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": pmc_traffic("r03_gemm_x3_pmc.json"),
+                "gflop_per_launch": round(fl_g / 1e9, 2), "ms_per_launch": round(ms_x, 4),
+                "fp32_mfma_kernel": {"kernel": "wino_gemm_kernel<64,64> (round 2's dominant kernel; GDN_X3=0)", "ms_per_launch": round(ms_g, 4),
+                                     "achieved": round(ag, 2), "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(ag / PEAK_F32_MFMA_TFLOPS, 4),
+                                     "traffic": pmc_traffic("r02_wino_gemm_pmc.json")},
                 "layer_forward": {"ms": round(ms_l, 4), "direct_conv_gflop": round(fl_l / 1e9, 2),
                                   "direct_equiv_tflops": round(fl_l / (ms_l * 1e-3) / 1e12, 2),
                                   "note": "whole layer forward (transforms + GEMMs + BN-stats epilogue) counted in the direct "

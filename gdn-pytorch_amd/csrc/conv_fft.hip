@@ -489,13 +489,15 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
         for (int ty = 0; ty < K; ++ty) { gr[ty] = 0.f; gi[ty] = 0.f; }
 #pragma unroll
         for (int ky = 0; ky < NP; ++ky) {
-            float2 v = *F;
-            const float2* Fs = F;
-            for (int sp = 1; sp < nsplit; ++sp) {        // P[0] + P[1] + ... in order, as fft_sum_splits did
-                Fs += ssp;
-                const float2 u = *Fs;
-                v.x += u.x; v.y += u.y;
-            }
+            // P[0] + P[1] + ... in order, as fft_sum_splits did; at most four partial sets (tn_splits), loaded unconditionally
+            // from clamped addresses so that the NP x 4 loads are all in flight instead of one dependent group per ky
+            float2 u[4];
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) u[sp] = F[(size_t)(sp < nsplit ? sp : nsplit - 1) * ssp];
+            float2 v = u[0];
+#pragma unroll
+            for (int sp = 1; sp < 4; ++sp)
+                if (sp < nsplit) { v.x += u[sp].x; v.y += u[sp].y; }
             F += sky; GDN_KEEP(F);
 #pragma unroll
             for (int ty = 0; ty < K; ++ty) {

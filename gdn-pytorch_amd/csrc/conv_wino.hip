@@ -186,8 +186,11 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 // The same transform written as bf16 x 3 packed panels (gemm_x3.h) for the GEMMs that run on the bf16 matrix pipe.
 // swap = 0: rows = n (output channel), k = c -- the forward's B operand U[bin][n][c];  swap = 1: rows = c, k = n from the
 // flipped taps -- the data gradient's.  thread = (row, 8 consecutive k): 9 taps x 8 values in, 16 bins x 3 planes x 16 bytes out.
-__global__ __launch_bounds__(256) void wino_weights_x3_kernel(const float* __restrict__ w, unsigned char* __restrict__ Up, int N, int C,
-                                                              int swap) {
+// grid.y selects the set: y = 0 -> (Up, swap), y = 1 -> (Up1, swap1): a forward that will run backward writes both in one launch.
+__global__ __launch_bounds__(256) void wino_weights_x3_kernel(const float* __restrict__ w, unsigned char* __restrict__ Up0, int N, int C,
+                                                              int swap0, unsigned char* __restrict__ Up1, int swap1) {
+    unsigned char* __restrict__ Up = blockIdx.y ? Up1 : Up0;
+    const int swap = blockIdx.y ? swap1 : swap0;
     const int rows = swap ? C : N, K = swap ? N : C, k8n = K / 8;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * k8n) return;
@@ -421,9 +424,15 @@ extern "C" int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t 
     if (!x3f || (Usw && !x3d))
         hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, x3f ? (float*)nullptr : U, f.N,
                            f.C, 0, x3d ? (float*)nullptr : Usw);
-    if (x3f) hipLaunchKernelGGL(wino_weights_x3_kernel, dim3(cdiv(f.N * f.C / 8, 256)), dim3(256), 0, st, w, (unsigned char*)U, f.N, f.C, 0);
-    if (Usw && x3d)
-        hipLaunchKernelGGL(wino_weights_x3_kernel, dim3(cdiv(f.N * f.C / 8, 256)), dim3(256), 0, st, w, (unsigned char*)Usw, f.N, f.C, 1);
+    if (x3f && Usw && x3d)
+        hipLaunchKernelGGL(wino_weights_x3_kernel, dim3(cdiv(f.N * f.C / 8, 256), 2), dim3(256), 0, st, w, (unsigned char*)U, f.N, f.C, 0,
+                           (unsigned char*)Usw, 1);
+    else if (x3f)
+        hipLaunchKernelGGL(wino_weights_x3_kernel, dim3(cdiv(f.N * f.C / 8, 256)), dim3(256), 0, st, w, (unsigned char*)U, f.N, f.C, 0,
+                           (unsigned char*)nullptr, 0);
+    else if (Usw && x3d)
+        hipLaunchKernelGGL(wino_weights_x3_kernel, dim3(cdiv(f.N * f.C / 8, 256)), dim3(256), 0, st, w, (unsigned char*)Usw, f.N, f.C, 1,
+                           (unsigned char*)nullptr, 0);
     if (x3f) launch_gemm_x3_nt((const float*)V, U, Mo, WINO_BINS, f.M, f.N, f.C, st);
     else launch_wino_gemm((const float*)V, (const float*)U, Mo, f.M, f.N, f.C, st);
     hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, (const float*)Mo, y, ldy, addsrc,
@@ -500,7 +509,8 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
         // reflection layer has more tiles but the same N and K, so eligibility is the same)
         const bool x3d = x3_on() && gemm_x3_ok(f.M, f.C, f.N);
         if (state) Ud = (const float*)((const char*)state + v_bytes(f));      // transformed by the forward's launch
-        else if (x3d) hipLaunchKernelGGL(wino_weights_x3_kernel, dim3(cdiv(f.N * f.C / 8, 256)), dim3(256), 0, st, w, (unsigned char*)U, f.N, f.C, 1);
+        else if (x3d) hipLaunchKernelGGL(wino_weights_x3_kernel, dim3(cdiv(f.N * f.C / 8, 256)), dim3(256), 0, st, w, (unsigned char*)U, f.N, f.C, 1,
+                                         (unsigned char*)nullptr, 0);
         else hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, U, f.N, f.C, 1, (float*)nullptr);
         if (x3d) launch_gemm_x3_nt((const float*)Vd, Ud, Eo, WINO_BINS, fd.M, f.C, f.N, st);
         else launch_wino_gemm((const float*)Vd, Ud, Eo, fd.M, f.C, f.N, st);

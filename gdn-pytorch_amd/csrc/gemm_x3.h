@@ -12,8 +12,9 @@
 //
 // Packed operand ("panel") layout, one per bin: rows in tiles of 128, k in blocks of 32:
 //     [row tile][k block][plane 0..2][row 0..127][64 bytes = 32 bf16]
-// with the four 16-byte chunks of a row XOR-permuted by ((row >> 2) & 3): the ds_read_b128 of an MFMA fragment (32 rows x 16
-// bytes per lane half) then touches every bank once.  A (row tile, k block) stage is 24 KB contiguous: staged by a linear copy.
+// with the four 16-byte chunks of a row XOR-permuted by x3_sw(row): the ds_read_b128 of an MFMA fragment (32 rows x 16
+// bytes per lane half) then touches every bank once, and so does a ds_write_b128 of eight consecutive rows at one chunk (the
+// transposing loader of the reduction GEMM).  A (row tile, k block) stage is 24 KB contiguous: staged by a linear copy.
 #pragma once
 #include "common.h"
 
@@ -22,9 +23,13 @@
 
 typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
 
+// chunk permutation of a row (bits b4 .. b0 of the row): ((b1 ^ b4) << 1) | b2.  Reads: the 16 lanes of a ds_read_b128 group hold
+// the row quads {0,3,5,6} or {1,2,4,7} of 32 rows -- four distinct values for every (b1, b0).  Writes of rows r .. r + 7 at one
+// chunk: bijective in (b2, b1), so with b0 the eight 16-byte slots of a 128-byte bank window are all different.
+__host__ __device__ static inline int x3_sw(int row) { return ((((row >> 1) ^ (row >> 4)) & 1) << 1) | ((row >> 2) & 1); }
 // byte offset of element (row, k) of plane p inside one bin's packed operand (KB = K / 32 k blocks)
 __host__ __device__ static inline size_t x3_off(int row, int k, int p, int KB) {
-    const int t = row >> 7, r = row & 127, kb = k >> 5, ch = ((k >> 3) & 3) ^ ((r >> 2) & 3);
+    const int t = row >> 7, r = row & 127, kb = k >> 5, ch = ((k >> 3) & 3) ^ x3_sw(r);
     return ((((size_t)t * KB + kb) * 3 + p) * 128 + r) * 64 + ch * 16 + (k & 7) * 2;
 }
 // bytes of one bin's packed operand with `rows` rows (padded to whole tiles) and reduction depth K

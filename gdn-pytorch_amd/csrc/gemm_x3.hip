@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(const float* __restr
             unsigned h0[3], h1[3];
             x3_split2(ra[v][0], ra[v][1], h0[0], h0[1], h0[2]);
             x3_split2(ra[v][2], ra[v][3], h1[0], h1[1], h1[2]);
-            const int off = row * 64 + (((k4 >> 1) ^ ((row >> 2) & 3)) * 16) + (k4 & 1) * 8;
+            const int off = row * 64 + (((k4 >> 1) ^ x3_sw(row)) * 16) + (k4 & 1) * 8;
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 const uint2 w = {h0[p], h1[p]};
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(const float* __restr
     };
     // fragment addresses: lane (r = lane & 31, h = lane >> 5) reads 16 B of row (tile row base + r) at chunk (2 s + h) ^ swz(row)
     const int r32 = lane & 31, h = lane >> 5;
-    const int f_sw = (r32 >> 2) & 3;                                   // tile row bases are multiples of 32: same swizzle
+    const int f_sw = x3_sw(r32);                                       // tile row bases are multiples of 32: same swizzle
     const int a_base = (wm * 64 + r32) * 64, b_base = (wn * 64 + r32) * 64;
 
     gload(0);
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_nt8_kernel(const float* __rest
             unsigned h0[3], h1[3];
             x3_split2(ra[v][0], ra[v][1], h0[0], h0[1], h0[2]);
             x3_split2(ra[v][2], ra[v][3], h1[0], h1[1], h1[2]);
-            const int off = row * 64 + (((k4 >> 1) ^ ((row >> 2) & 3)) * 16) + (k4 & 1) * 8;
+            const int off = row * 64 + (((k4 >> 1) ^ x3_sw(row)) * 16) + (k4 & 1) * 8;
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 const uint2 w = {h0[p], h1[p]};
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_nt8_kernel(const float* __rest
         for (int v = 0; v < 3; ++v) *reinterpret_cast<f32x4*>(&Bs[buf][v * 8192 + tid * 16]) = rb[v];
     };
     const int r32 = lane & 31, h = lane >> 5;
-    const int f_sw = (r32 >> 2) & 3;
+    const int f_sw = x3_sw(r32);
     const int a_base = (wm * (TM / 2) + r32) * 64, b_base = (wn * 32 + r32) * 64;
     gload(0);
     lstore(0);
@@ -283,31 +283,38 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(const float* __restr
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; cor[i][j][r] = 0.f; }
-    // staging: thread = (t8 = tid >> 6: rows t8*8 .. t8*8+7 of the stage, cp = tid & 63: channels 2 cp, 2 cp + 1)
+    // staging: thread = (t8 = tid >> 6: rows t8*8 .. t8*8+7 of the stage, cp = tid & 63: channels cp and cp + 64) -- a wave
+    // instruction reads 64 consecutive channels of one row (256 B), and the eight lanes of a ds_write_b128 group write eight
+    // CONSECUTIVE LDS rows at one chunk: conflict-free under x3_sw (with channels 2 cp, 2 cp + 1 per thread -- 8-byte loads --
+    // the groups wrote even rows only: two-way conflicts on a third of all LDS cycles, profiles/r03_gemm_x3_pmc.json)
     const int t8 = tid >> 6, cp = tid & 63;
-    const float* ap = A + ((size_t)bin * T) * NI + i0 + cp * 2;
-    const float* bp = Bm + ((size_t)bin * T) * NJ + j0 + cp * 2;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 ra[8], rb[8];
+    const float* ap = A + ((size_t)bin * T) * NI + i0 + cp;
+    const float* bp = Bm + ((size_t)bin * T) * NJ + j0 + cp;
+    float ra[2][8], rb[2][8];
     auto gload = [&](int t0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int t = t0 + t8 * 8 + e;
-            const f32x2 z = {0.f, 0.f};
-            ra[e] = t < te ? *reinterpret_cast<const f32x2*>(ap + (size_t)t * NI) : z;
-            rb[e] = t < te ? *reinterpret_cast<const f32x2*>(bp + (size_t)t * NJ) : z;
+            const bool in = t < te;
+            const size_t ta = (size_t)(in ? t : tb) * NI, tbo = (size_t)(in ? t : tb) * NJ;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float va = ap[ta + c * 64], vb = bp[tbo + c * 64];
+                ra[c][e] = in ? va : 0.f;
+                rb[c][e] = in ? vb : 0.f;
+            }
         }
     };
     auto lstore = [&]() {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {                    // the thread's two channels = two LDS rows
-            const int row = cp * 2 + c;
-            const int off = row * 64 + ((t8 ^ ((row >> 2) & 3)) * 16);
+            const int row = cp + c * 64;
+            const int off = row * 64 + ((t8 ^ x3_sw(row)) * 16);
             unsigned ha[3][4], hb[3][4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                x3_split2(ra[2 * q][c], ra[2 * q + 1][c], ha[0][q], ha[1][q], ha[2][q]);
-                x3_split2(rb[2 * q][c], rb[2 * q + 1][c], hb[0][q], hb[1][q], hb[2][q]);
+                x3_split2(ra[c][2 * q], ra[c][2 * q + 1], ha[0][q], ha[1][q], ha[2][q]);
+                x3_split2(rb[c][2 * q], rb[c][2 * q + 1], hb[0][q], hb[1][q], hb[2][q]);
             }
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(const float* __restr
         }
     };
     const int r32 = lane & 31, h = lane >> 5;
-    const int f_sw = (r32 >> 2) & 3;
+    const int f_sw = x3_sw(r32);
     const int a_base = (wm * 64 + r32) * 64, b_base = (wn * 64 + r32) * 64;
     gload(tb);
     for (int t0 = tb; t0 < te; t0 += 32) {

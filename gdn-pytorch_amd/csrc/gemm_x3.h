@@ -67,11 +67,12 @@ static inline bool gemm_x3_ok(int M, int N, int K) { return M >= 1 && N >= 128 &
 // [bins][T][NJ], both split on the fly); the caller sums the nsplit partial sets in a fixed order.  NI, NJ multiples of 128.
 void launch_gemm_x3_tn(const float* A, const float* Bm, float* P, int bins, int T, int NI, int NJ, int nsplit, hipStream_t st);
 static inline bool gemm_x3_tn_ok(int T, int NI, int NJ) { return T >= 1 && NI >= 128 && NI % 128 == 0 && NJ >= 128 && NJ % 128 == 0; }
-// splits of the reduction: two workgroups per CU fill the chip at 512 workgroups; chunks of at least 256 rows, at most 8
+// splits of the reduction: two workgroups per CU fill the chip at 512 workgroups; chunks of at least 256 rows, at most 16
+// (the 64 -> 128 stride-2 layer has 32 (bin, tile) pairs over 30800 rows: 8 splits left half the chip idle, 345 us)
 static inline int gemm_x3_tn_splits(int bins, int T, int NI, int NJ) {
     const int wgs = (NI / 128) * (NJ / 128) * bins;
     int s = (512 + wgs - 1) / wgs;
-    if (s > 8) s = 8;
+    if (s > 16) s = 16;
     while (s > 1 && T / s < 256) --s;
     return s < 1 ? 1 : s;
 }

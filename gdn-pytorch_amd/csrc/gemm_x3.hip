@@ -296,7 +296,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(const float* __restr
         for (int e = 0; e < 8; ++e) {
             const int t = t0 + t8 * 8 + e;
             const bool in = t < te;
-            const size_t ta = (size_t)(in ? t : tb) * NI, tbo = (size_t)(in ? t : tb) * NJ;
+            const int tc = t < T ? t : T - 1;               // rows past the chunk are read (and dropped) from a row that exists
+            const size_t ta = (size_t)tc * NI, tbo = (size_t)tc * NJ;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const float va = ap[ta + c * 64], vb = bp[tbo + c * 64];

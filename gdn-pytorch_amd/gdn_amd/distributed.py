@@ -38,7 +38,49 @@ def init(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        _guard_shared_gpu(rank, local_rank, world)
     return rank, local_rank, world
+
+
+SHARED_GPU_RANKS = 1       # ranks of this job (this one included) that drive the same physical GPU as this rank
+
+
+def device_identity(local_rank):
+    """What makes two ranks users of ONE physical GPU: host name + the device's UUID (PCI address as a fallback).  A
+    GDN_SINGLE_DEVICE run (test hook: every rank on device 0) resolves device 0."""
+    import socket
+    if not torch.cuda.is_available():
+        return None
+    n = torch.cuda.device_count()
+    idx = 0 if os.environ.get("GDN_SINGLE_DEVICE") == "1" else (local_rank % n if n else 0)
+    pr = torch.cuda.get_device_properties(idx)
+    ident = getattr(pr, "uuid", None)
+    ident = str(ident) if ident is not None else "%s:%s:%s" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", idx),
+                                                               getattr(pr, "pci_device_id", 0))
+    return socket.gethostname() + "/" + ident
+
+
+def _guard_shared_gpu(rank, local_rank, world):
+    """Several ranks on ONE MI355X (a 1-GPU test box with the gloo hook, or an oversubscribed launch): the bf16 x 3 GEMMs
+    are switched off for this process (GDN_X3=0: the Winograd per-bin GEMMs return to the fp32 matrix instruction).
+    Measured on this pool (profiles/r03_neighbour_mfma.txt): a kernel that alternates bursts of bf16
+    matrix instructions with workgroup barriers -- which is what a tiled bf16 GEMM is -- perturbs FFT-type kernels of
+    ANOTHER process that shares the GPU (16-lane pieces of their results change; reproduced with a 30-line kernel as the
+    neighbour and rocFFT as the victim), while one process per GPU -- the deployment this package is built for -- and the
+    fp32 matrix instruction are not affected.  An explicit GDN_X3 in the environment is respected."""
+    global SHARED_GPU_RANKS
+    if world < 2:
+        return
+    me = device_identity(local_rank)
+    ids = [None] * world
+    dist.all_gather_object(ids, me)
+    SHARED_GPU_RANKS = sum(1 for i in ids if i is not None and i == me) if me is not None else 1
+    if SHARED_GPU_RANKS > 1 and "GDN_X3" not in os.environ:
+        os.environ["GDN_X3"] = "0"            # read by the library at every call
+        if rank == 0:
+            import warnings
+            warnings.warn("%d ranks share one GPU: bf16 x 3 GEMMs disabled (GDN_X3=0) for this job; one process per GPU is "
+                          "the supported layout" % SHARED_GPU_RANKS, RuntimeWarning)
 
 
 def world_size():

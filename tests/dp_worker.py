@@ -29,19 +29,28 @@ def run(rank, world, port, steps, out_dir, overlap, global_berhu=False):
     model(x0, istrain=False)                             # builds the arena
     D.broadcast_parameters(model, src=0)
     opt = Adam(model.parameters(), 2e-4, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
-    losses = []
+    losses, trace = [], []             # (trace: per-step hashes for tests/diag/dp_debug.py, GDN_DP_DEBUG=1)
+    import hashlib
+    hsh = lambda t: hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:12]
     for s in range(steps):
         depth, _, sparse = [t.to(dev) for t in O.synthetic_batch(2, 32, 64, seed=10 * s + rank)]
         out = model(depth, istrain=False)
         loss, _, _ = U.dtod_loss(out, depth, sparse)
         opt.zero_grad()
         loss.backward()
+        if os.environ.get("GDN_DP_DEBUG"):
+            trace.append(("grad_local", s, hsh(model._gdn_param_arena.grad)))
         D.sync_gradients(model, opt)
+        if os.environ.get("GDN_DP_DEBUG"):
+            trace.append(("grad_reduced", s, hsh(model._gdn_param_arena.grad)))
         opt.step()
+        if os.environ.get("GDN_DP_DEBUG"):
+            trace.append(("weights", s, hsh(model._gdn_param_arena.data)))
         losses.append(float(loss.detach()))
     torch.cuda.synchronize()
-    torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "losses": losses,
-                "reducer": getattr(model, "_gdn_reducer", None) is not None},
+    torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "losses": losses, "trace": trace,
+                "reducer": getattr(model, "_gdn_reducer", None) is not None,
+                "x3": os.environ.get("GDN_X3"), "shared": D.SHARED_GPU_RANKS},
                os.path.join(out_dir, "rank%d.pt" % rank))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

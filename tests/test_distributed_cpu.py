@@ -251,3 +251,47 @@ def test_launch_ranks_leaves_no_child_behind_on_timeout(tmp_path):
     for r in range(2):
         pid = int((tmp_path / ("pid%d" % r)).read_text())
         assert subprocess.run(["kill", "-0", str(pid)], capture_output=True).returncode != 0, "rank %d survived" % r
+
+
+def _shared_gpu_worker(rank, world, port, q, same):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("GDN_X3", None)
+    import sys
+    import pathlib
+    import warnings
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root)); sys.path.insert(0, str(root / "gdn-pytorch_amd"))
+    from gdn_amd import distributed as D
+    try:
+        # (no GPU here: the identity of "the device this rank drives" is injected)
+        D.device_identity = lambda local_rank: "box/GPU-0" if same else "box/GPU-%d" % local_rank
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            D.init(backend="gloo")
+        q.put((rank, D.SHARED_GPU_RANKS, os.environ.get("GDN_X3"), sum("share one GPU" in str(w.message) for w in seen)))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception as e:      # noqa: BLE001
+        q.put((rank, "error", repr(e), 0))
+
+
+@pytest.mark.parametrize("same", [True, False])
+def test_ranks_sharing_one_gpu_switch_the_bf16x3_gemms_off(same):
+    """distributed.init: ranks whose device identities coincide (a 1-GPU box under the gloo hook, an oversubscribed
+    launch) run with GDN_X3=0 -- the measured cross-process interference of barrier-paced bf16 matrix bursts with a
+    neighbour's FFT kernels -- and rank 0 says so once; ranks on different GPUs change nothing."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_shared_gpu_worker, args=(r, 2, port, q, same)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert all(g[1] != "error" for g in got), got
+    if same:
+        assert [(g[1], g[2]) for g in got] == [(2, "0"), (2, "0")] and got[0][3] == 1 and got[1][3] == 0
+    else:
+        assert [(g[1], g[2], g[3]) for g in got] == [(1, None, 0), (1, None, 0)]

@@ -308,7 +308,7 @@ def test_guide_fast_path_identical(gpu):
 
 
 @pytest.mark.parametrize("overlap,global_berhu", [(True, False), (False, False), (True, True)])
-def test_data_parallel_two_ranks(gpu, tmp_path, overlap, global_berhu):
+def test_data_parallel_two_ranks(gpu, tmp_path, monkeypatch, overlap, global_berhu):
     """Two real processes (one per rank, gloo, both on cuda:0) train 3 steps on their own shards with
     broadcast_parameters + sync_gradients (+ the overlapped GradReducer) + the fused Adam's 1/world scale.
     A single process that runs both shards with the same weights, sums the two gradient arenas and applies the
@@ -325,6 +325,10 @@ def test_data_parallel_two_ranks(gpu, tmp_path, overlap, global_berhu):
     mp.spawn(dp_worker.run, args=(2, port, steps, str(tmp_path), overlap, global_berhu), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert r0["reducer"] == overlap
+    # the two ranks share this box's one GPU: distributed.init saw it and took the bf16 x 3 GEMMs out (a
+    # neighbour process's barrier-paced bf16 matrix bursts perturb FFT-type kernels on this hardware); same switch here
+    assert r0["shared"] == 2 and r0["x3"] == "0" and r1["x3"] == "0"
+    monkeypatch.setenv("GDN_X3", "0")
     # single-process emulation: replica A plays rank 0, replica B rank 1 (own BN buffers, shared weights)
     torch.manual_seed(0)
     A = M.AutoEncoder_DtoD(input_dim=1, height=32, width=64).to(gpu).train()

@@ -453,7 +453,10 @@ __global__ __launch_bounds__(256, 4) void cgemm_tn_bins_kernel(const float* __re
 // layer, 388 us for 1.3 MB of output).  grid = (N*C/64, ceil(NK/4)): a workgroup is 64 (n, c) pairs x 4 kx, the ky loop is
 // fully unrolled so every twiddle of the first stage is a literal (no scalar table lookups), the partial spectra of a split
 // reduction GEMM are summed while they are loaded (fixed order; fft_sum_splits is gone), the four waves meet in LDS and the
-// workgroup writes its partial tap set part[blockIdx.y][tap][n][c]; fft_taps_reduce sums the ceil(NK/4) partial sets in order.
+// workgroup writes its partial tap set part[z * groups + y][tap][n][c]; fft_taps_reduce sums the partial sets in order.
+// 40-point tiles (the 64-channel 9x9 layers: 384 workgroups otherwise) run with grid.z = 2: each workgroup transforms one half
+// of the ky rows with literal twiddles of the LOCAL row index, the half's phase is one complex rotation of the K row sums
+// (172 -> 127 us; the same split made the 32-point 7x7 kernel slower, 106 -> 157 us, and is not used there).
 template <int NP>
 __device__ __forceinline__ constexpr float tw_lit_cos(int q) {         // cos(2 pi q / NP), q in [0, NP): folded after unrolling
     constexpr float C40[11] = {1.0f, 0.98768834059513777f, 0.95105651629515353f, 0.89100652418836790f, 0.80901699437494745f,
@@ -471,7 +474,7 @@ __device__ __forceinline__ constexpr float tw_lit_sin(int q) { return tw_lit_cos
 template <int K, int NP>
 __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __restrict__ P, float* __restrict__ part, int N, int C,
                                                              int nsplit) {
-    constexpr int NK = FFT_NK_OF(NP), BINS = FFT_BINS_OF(NP);
+    constexpr int NK = FFT_NK_OF(NP), BINS = FFT_BINS_OF(NP), KYH = NP == 40 ? NP / 2 : NP;   // 40-point tiles: blockIdx.z = which half of the ky rows
     __shared__ float red[3][K][64];                 // one filter row at a time: 7 KB, so the kernel never crowds a 107 KB
                                                     // transform workgroup of the other stream off a CU (the old 62 KB did)
     const int pl = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -482,13 +485,14 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
 #pragma unroll
     for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
     if (kx < NK) {
-        const float2* F = reinterpret_cast<const float2*>(P) + (size_t)kx * bs + i;
+        const int ky0 = blockIdx.z * KYH;
         const size_t sky = (size_t)NK * bs, ssp = (size_t)BINS * bs;
+        const float2* F = reinterpret_cast<const float2*>(P) + (size_t)kx * bs + i + (size_t)ky0 * sky;
         float gr[K], gi[K];
 #pragma unroll
         for (int ty = 0; ty < K; ++ty) { gr[ty] = 0.f; gi[ty] = 0.f; }
 #pragma unroll
-        for (int ky = 0; ky < NP; ++ky) {
+        for (int ky = 0; ky < KYH; ++ky) {            // (local row index: the half's phase e^{+i 2 pi ky0 ty / NP} is applied once, below)
             // P[0] + P[1] + ... in order, as fft_sum_splits did; at most four partial sets (tn_splits), loaded unconditionally
             // from clamped addresses so that the NP x 4 loads are all in flight instead of one dependent group per ky
             float2 u[4];
@@ -506,6 +510,15 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
                 gi[ty] += v.x * sn + v.y * cs;
             }
         }
+        if (ky0) {
+#pragma unroll
+            for (int ty = 0; ty < K; ++ty) {
+                const float cs = tw_cos<NP>(ky0 * ty), sn = tw_sin<NP>(ky0 * ty);
+                const float a = gr[ty], b = gi[ty];
+                gr[ty] = a * cs - b * sn;
+                gi[ty] = a * sn + b * cs;
+            }
+        }
         const float alpha = (kx == 0 || kx == NP / 2) ? 1.f : 2.f;
 #pragma unroll
         for (int tx = 0; tx < K; ++tx) {
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
             for (int ty = 0; ty < K; ++ty) acc[ty * K + tx] = gr[ty] * cs - gi[ty] * sn;
         }
     }
-    float* dst = part + (size_t)blockIdx.y * K * K * bs + i;
+    float* dst = part + (size_t)(blockIdx.z * gridDim.y + blockIdx.y) * K * K * bs + i;
 #pragma unroll
     for (int ty = 0; ty < K; ++ty) {
         if (ty > 0) __syncthreads();
@@ -948,7 +961,8 @@ inline int tn_splits(const FftGeom& f) {
 // weight-spectrum / weight-gradient-product region of the backward workspace: the weight planes (data gradient without a saved
 // state), or the per-split products of the reduction GEMM followed by the partial tap sets of fft_wgrad_taps
 inline size_t tn_prod_bytes(const FftGeom& f) { return al256((size_t)tn_splits(f) * f.bins * 2 * f.C * f.N * 4); }
-inline int taps_groups(const FftGeom& f) { return cdiv(f.np / 2 + 1, 4); }
+inline int taps_kyh(const FftGeom& f) { return f.np == 40 ? 2 : 1; }                // ky halves (fft_wgrad_taps: 40-point tiles only)
+inline int taps_groups(const FftGeom& f) { return taps_kyh(f) * cdiv(f.np / 2 + 1, 4); }     // partial tap sets: (kx group) x (ky half)
 inline size_t wf_region_bytes(const FftGeom& f) {
     const size_t planes = (size_t)f.bins * 3 * f.C * f.N * 4;
     const size_t prod = tn_prod_bytes(f) + al256((size_t)taps_groups(f) * f.k * f.k * f.C * f.N * 4);
@@ -1100,7 +1114,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * f.bins * ns), dim3(256), 0, st,
                            (const float*)Df, (const float*)xf, P, f.M, f.N, f.C, ns, f.bins);
         float* part = (float*)((char*)P + tn_prod_bytes(f));
-        const dim3 gt(f.N * f.C / 64, taps_groups(f));
+        const dim3 gt(f.N * f.C / 64, taps_groups(f) / taps_kyh(f), taps_kyh(f));
 #define GDN_TAPS(KK) case KK: \
             if (f.np == 16) hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 16>), gt, dim3(256), 0, st, (const float*)P, part, f.N, f.C, ns); \
             else if (f.np == 40) hipLaunchKernelGGL((fft_wgrad_taps_kernel<KK, 40>), gt, dim3(256), 0, st, (const float*)P, part, f.N, f.C, ns); \

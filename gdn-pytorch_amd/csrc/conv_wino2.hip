@@ -331,37 +331,38 @@ __global__ __launch_bounds__(256) void w2_lift_kernel(const float* __restrict__ 
 
 // ---- weight gradient output: dw[(2u+a)*4 + (2v+b)][..] = (G^T P_ab G)[u][v],  P[bin][n][(a*2+b)*Cx + c].
 // transposed = 0: dw[tap][n][c] (conv);  1: dw[tap][c][n] (ConvTranspose: [tap][Cout_T = large-image channel][Cin_T]) ----
+// grid.y = the phase (a, b): the smallest layer (64 x 128 channel pairs) is 32 workgroups per phase, and its reduction over up to
+// 16 splits is 16 independent loads per split -- issued together, summed in split order (round 3: was one thread per channel
+// pair walking all four phases with one dependent load at a time, 235 us for 0.5 MB of output).
 __global__ __launch_bounds__(256) void w2_wgrad_output_kernel(const float* __restrict__ P, float* __restrict__ dw, int Ny, int Cx, int transposed,
                                                               int nsplit) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Ny * Cx) return;
     const int c = i % Cx, n = i / Cx;
+    const int a = blockIdx.y >> 1, b = blockIdx.y & 1;
     const int K = 4 * Cx;
     const size_t bs = (size_t)Ny * K, ts = (size_t)Ny * Cx;
     const size_t o = transposed ? (size_t)c * Ny + n : (size_t)n * Cx + c;
+    float p[16];
+    const float* src = P + (size_t)n * K + (a * 2 + b) * Cx + c;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int q = 0; q < 16; ++q) p[q] = src[(size_t)q * bs];
+    for (int sp = 1; sp < nsplit; ++sp) {                       // split reduction, fixed order
+        src += (size_t)WINO_BINS * bs;
+        float v[16];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            float p[4][4];
-            const float* src = P + (size_t)n * K + (a * 2 + b) * Cx + c;
+        for (int q = 0; q < 16; ++q) v[q] = src[(size_t)q * bs];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 16; ++q) p[q] += v[q];
+    }
+    float r[2][4];                  // G^T along rows: (p0 + (p1 + p2)/2, (p1 - p2)/2 + p3)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = *src;
-                    for (int sp = 1; sp < nsplit; ++sp) v += src[(size_t)sp * WINO_BINS * bs];      // split reduction, fixed order
-                    p[q][e] = v; src += bs; GDN_KEEP(src);
-                }
-            float r[2][4];                  // G^T along rows: (p0 + (p1 + p2)/2, (p1 - p2)/2 + p3)
+    for (int e = 0; e < 4; ++e) { r[0][e] = p[e] + 0.5f * (p[4 + e] + p[8 + e]); r[1][e] = 0.5f * (p[4 + e] - p[8 + e]) + p[12 + e]; }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { r[0][e] = p[0][e] + 0.5f * (p[1][e] + p[2][e]); r[1][e] = 0.5f * (p[1][e] - p[2][e]) + p[3][e]; }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                dw[(size_t)((2 * u + a) * 4 + b) * ts + o] = r[u][0] + 0.5f * (r[u][1] + r[u][2]);
-                dw[(size_t)((2 * u + a) * 4 + 2 + b) * ts + o] = 0.5f * (r[u][1] - r[u][2]) + r[u][3];
-            }
-        }
+    for (int u = 0; u < 2; ++u) {
+        dw[(size_t)((2 * u + a) * 4 + b) * ts + o] = r[u][0] + 0.5f * (r[u][1] + r[u][2]);
+        dw[(size_t)((2 * u + a) * 4 + 2 + b) * ts + o] = 0.5f * (r[u][1] - r[u][2]) + r[u][3];
+    }
 }
 
 bool w2_geom(const gdn_conv_geom* g, W2Geom& f) {
@@ -536,7 +537,7 @@ extern "C" int gdn_wino2conv_bwd(const gdn_conv_geom* g, const float* dy, int32_
             hipLaunchKernelGGL(w2_lift_kernel, dim3(cdiv(f.Ma, 4) << f.yq), dim3(256), 0, st, x, ldx_in, Dv, f);
             const int ns = w2_splits(f);
             w2_gemm_tn(f, (const float*)Dv, (const float*)V, P, ns, st);
-            hipLaunchKernelGGL(w2_wgrad_output_kernel, dim3(cdiv(f.Cy * f.Cx, 256)), dim3(256), 0, st, (const float*)P, dw, f.Cy, f.Cx, 1, ns);
+            hipLaunchKernelGGL(w2_wgrad_output_kernel, dim3(cdiv(f.Cy * f.Cx, 256), 4), dim3(256), 0, st, (const float*)P, dw, f.Cy, f.Cx, 1, ns);
         }
         return gdn_launch_status();
     }
@@ -551,7 +552,7 @@ extern "C" int gdn_wino2conv_bwd(const gdn_conv_geom* g, const float* dy, int32_
         hipLaunchKernelGGL(w2_lift_kernel, dim3(cdiv(f.Ma, 4) << f.yq), dim3(256), 0, st, dy, ldy, Dv, f);
         const int ns = w2_splits(f);
         w2_gemm_tn(f, (const float*)Dv, (const float*)state, P, ns, st);
-        hipLaunchKernelGGL(w2_wgrad_output_kernel, dim3(cdiv(f.Cy * f.Cx, 256)), dim3(256), 0, st, (const float*)P, dw, f.Cy, f.Cx, 0, ns);
+        hipLaunchKernelGGL(w2_wgrad_output_kernel, dim3(cdiv(f.Cy * f.Cx, 256), 4), dim3(256), 0, st, (const float*)P, dw, f.Cy, f.Cx, 0, ns);
     }
     if (dx) {
         if (f.reflect) {

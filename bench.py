@@ -17,9 +17,15 @@ each rank trains its own batch-20 shard and the gradient arena is all-reduced
 with RCCL (weak scaling).  Rank 0 prints ONE JSON line.
 
 The same line carries
-  roofline     -- the fused 3x3 512->512 convolution kernel (north_star) timed
-                  with HIP events on the launch stream: algorithmic FLOP / time
-                  against the fp32 MFMA peak (157.3 TFLOP/s);
+  roofline     -- the dominant kernel of the step, `gemm_x3_nt_kernel`: the 16 per-bin GEMMs of the level-3 Winograd
+                  3x3 512->512 layer (north_star's fused 3x3 convolution) as bf16 x 3 split
+                  products, timed with HIP events on the launch stream: algorithmic fp32 FLOP / time against the
+                  bf16 MFMA peak / 6 (six bf16 products per fp32 product; 2500 / 6 = 416.7 TFLOP/s), the executed bf16
+                  rate and the replaced fp32 MFMA kernel beside it; `traffic` from the committed PMC pass;
+  roofline_direct3x3, roofline_fftconv -- the direct fused 3x3 kernel (fp32 MFMA peak 157.3 TFLOP/s) and a 9x9
+                  frequency-domain layer (HBM-bound, 8 TB/s) measured the same way;
+  mfma_util    -- whole-step MFMA utilisation replayed from profiles/ (with the commit it was collected at);
+  other_configs -- RtoD fp32 / bf16 (BASELINE configs[2]), DtoD bf16, inference B = 64 256x832 under a hipGraph;
   cpu_baseline -- the CPU oracle (same step, reference semantics, torch CPU) on a
                   bounded sample, N=1 rank 0 only.
 """

@@ -228,7 +228,16 @@ __global__ void wgrad_bf16_reduce_kernel(const float* __restrict__ part, float* 
     const int64_t n = (int64_t)KK * R * C;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float sum = 0.f;
-        for (int sp = 0; sp < S; ++sp) sum += part[(size_t)sp * n + i];
+        // eight slabs per trip, loaded together (from clamped addresses) and added in slab order: the launches with few outputs
+        // and hundreds of slabs (16-61 workgroups) were one dependent load at a time, 120-150 us for a few KB of gradient
+        for (int sp = 0; sp < S; sp += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(sp + q < S ? sp + q : S - 1) * n + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (sp + q < S) sum += v[q];
+        }
         const int c = (int)(i % C);
         const int64_t t2 = i / C;
         const int r = (int)(t2 % R);

@@ -73,7 +73,12 @@ def _guard_shared_gpu(rank, local_rank, world):
         return
     me = device_identity(local_rank)
     ids = [None] * world
-    dist.all_gather_object(ids, me)
+    try:
+        dist.all_gather_object(ids, me)
+    except Exception as e:      # noqa: BLE001 -- the guard must never be what stops a job
+        import warnings
+        warnings.warn("could not compare the ranks' devices (%r); assuming one process per GPU" % (e,), RuntimeWarning)
+        return
     SHARED_GPU_RANKS = sum(1 for i in ids if i is not None and i == me) if me is not None else 1
     if SHARED_GPU_RANKS > 1 and "GDN_X3" not in os.environ:
         os.environ["GDN_X3"] = "0"            # read by the library at every call

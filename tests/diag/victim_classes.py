@@ -15,11 +15,11 @@ side = torch.cuda.Stream()
 sink = torch.zeros(4, device=dev)
 names = ["scalar fp32 FMA chain", "packed fp32 FMA chain", "LDS transpose + barriers", "192-register working set (~200 VGPRs)",
          "scratch array, dynamic index", "global gather + multiply", "LDS transpose + barriers + packed math",
-         "torch.fft.rfft2 (rocFFT)", "table look-ups, wave-uniform (scalar cache)", "table look-ups, per-lane (L1 hits)"]
+         "torch.fft.rfft2 (rocFFT)", "table look-ups, wave-uniform (scalar cache)", "table look-ups, per-lane (L1 hits)", "register butterflies + twiddles (v_pk_add/mul)"]
 img = torch.randn(8, 64, 64, 64, device=dev, generator=g)
 main = torch.cuda.current_stream()
 for neighbour in (False, True):
-    for v in range(10):
+    for v in range(11):
         out = torch.empty(1 << 20, device=dev)
         ref, bad = None, 0
         for it in range(n):

@@ -5,6 +5,7 @@
 //   4 private-memory (scratch) array, dynamic index   5 global copy with a multiply
 //   6 LDS transpose + barriers + packed math (an FFT-like butterfly stage)
 //   8 table look-ups, wave-uniform index (scalar cache)   9 table look-ups, per-lane index (vector L1 hits)
+//   10 radix-2 butterflies with twiddles on float2 registers (v_pk_add / v_pk_mul with swaps), no LDS, no tables
 //   7 a 192-register working set (statically indexed array kept live across a long chain): ~200 VGPRs per lane
 //   3 was removed (its wave-private LDS exchange raced with itself)
 #include <hip/hip_runtime.h>
@@ -58,6 +59,24 @@ __global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ i
         x = 0.f;
 #pragma unroll
         for (int q = 0; q < 192; ++q) x += r[q];
+    } else if (V == 10) {                 // complex rotations on eight independent float2 values: v_pk_mul_f32 / v_pk_add_f32 with lane swaps,
+        float2 v[8];                       // the instruction mix of a register FFT (no LDS, no tables)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = make_float2(x + q * 0.125f, y - q * 0.0625f);
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {                    // radix-2 butterfly + twiddle
+                const float2 a = v[q], b = v[q + 1];
+                const float2 s = make_float2(a.x + b.x, a.y + b.y), d = make_float2(a.x - b.x, a.y - b.y);
+                const float cs = 0.92387953f, sn = -0.38268343f;
+                v[q] = make_float2(s.x * 0.5f, s.y * 0.5f);
+                v[q + 1] = make_float2((d.x * cs - d.y * sn) * 0.5f, (d.x * sn + d.y * cs) * 0.5f);
+            }
+            const float2 t = v[0]; v[0] = v[3]; v[3] = v[6]; v[6] = v[5]; v[5] = t;
+        }
+        x = 0.f; y = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { x += v[q].x; y += v[q].y; }
     } else if (V == 8) {                  // table look-ups with a wave-uniform index: scalar loads through the scalar cache
         for (int i = 0; i < iters; ++i) x = fmaf(x, kTab[(blockIdx.x + i * 7) & 255], y * 1e-3f) * 0.7f;
     } else if (V == 9) {                  // table look-ups with a per-lane index: vector loads that hit the L1 cache
@@ -87,6 +106,7 @@ extern "C" int victim(int variant, const void* in, void* out, int blocks, int it
         case 2: hipLaunchKernelGGL(victim_kernel<2>, dim3(blocks), dim3(256), 0, st, i, o, iters); break;
         case 3: hipLaunchKernelGGL(victim_kernel<7>, dim3(blocks), dim3(256), 0, st, i, o, iters); break;
         case 4: hipLaunchKernelGGL(victim_kernel<4>, dim3(blocks), dim3(256), 0, st, i, o, iters); break;
+        case 10: hipLaunchKernelGGL(victim_kernel<10>, dim3(blocks), dim3(256), 0, st, i, o, iters); break;
         case 8: hipLaunchKernelGGL(victim_kernel<8>, dim3(blocks), dim3(256), 0, st, i, o, iters); break;
         case 9: hipLaunchKernelGGL(victim_kernel<9>, dim3(blocks), dim3(256), 0, st, i, o, iters); break;
         case 5: hipLaunchKernelGGL(victim_kernel<5>, dim3(blocks), dim3(256), 0, st, i, o, iters); break;

@@ -3,6 +3,7 @@
 // variant: 0 v_mfma_f32_32x32x16_bf16, 4 accumulators round robin     1 the same, ONE accumulator (dependent chain)
 //          2 v_mfma_f32_16x16x32_bf16, 4 accumulators                  3 v_mfma_f32_32x32x2_f32, 4 accumulators
 //          4 v_mfma_f32_32x32x16_f16, 4 accumulators                   5 variant 0 with a workgroup barrier every 12 instructions
+//          6 variant 3 (fp32) with the barrier                          7 variant 4 (f16) with the barrier
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -28,10 +29,10 @@ __global__ __launch_bounds__(256, 2) void mfma_loop_kernel(float* sink, int iter
             const int i = (V == 1) ? 0 : (u & 3);
             if (V == 0 || V == 1 || V == 5) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c[i], 0, 0, 0);
             if (V == 2) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, d[i], 0, 0, 0);
-            if (V == 3) c[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(s, 1.f - s, c[i], 0, 0, 0);
-            if (V == 4) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c[i], 0, 0, 0);
+            if (V == 3 || V == 6) c[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(s, 1.f - s, c[i], 0, 0, 0);
+            if (V == 4 || V == 7) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c[i], 0, 0, 0);
         }
-        if (V == 5) __syncthreads();
+        if (V >= 5) __syncthreads();
     }
     float t = 0.f;
     for (int i = 0; i < 4; ++i) {
@@ -49,6 +50,8 @@ extern "C" int mfma_loop(int variant, int blocks, int iters, void* sink, void* s
         case 2: hipLaunchKernelGGL(mfma_loop_kernel<2>, dim3(blocks), dim3(256), 0, st, (float*)sink, iters, 0.5f); break;
         case 3: hipLaunchKernelGGL(mfma_loop_kernel<3>, dim3(blocks), dim3(256), 0, st, (float*)sink, iters, 0.5f); break;
         case 4: hipLaunchKernelGGL(mfma_loop_kernel<4>, dim3(blocks), dim3(256), 0, st, (float*)sink, iters, 0.5f); break;
+        case 6: hipLaunchKernelGGL(mfma_loop_kernel<6>, dim3(blocks), dim3(256), 0, st, (float*)sink, iters, 0.5f); break;
+        case 7: hipLaunchKernelGGL(mfma_loop_kernel<7>, dim3(blocks), dim3(256), 0, st, (float*)sink, iters, 0.5f); break;
         default: hipLaunchKernelGGL(mfma_loop_kernel<5>, dim3(blocks), dim3(256), 0, st, (float*)sink, iters, 0.5f); break;
     }
     return hipGetLastError() == hipSuccess ? 0 : 1;

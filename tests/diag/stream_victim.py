@@ -26,8 +26,8 @@ for it in range(n):
     if kind != "none":
         with torch.cuda.stream(side):
             for _ in range(6):
-                if kind == "mfma5":
-                    mf.mfma_loop(5, 1024, 200, sink.data_ptr(), side.cuda_stream)
+                if kind.startswith("mfma"):
+                    mf.mfma_loop(int(kind[4:]), 1024, 200, sink.data_ptr(), side.cuda_stream)
                 else:
                     ops.gemm_x3_nt(A, Bp, 512, out=C)
     outs = {"fft": torch.view_as_real(torch.fft.rfft2(img)), "elementwise": torch.tanh(x * 1.0001 + 0.5) * x}

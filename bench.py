@@ -463,6 +463,12 @@ def self_launch(args, argv):
     return rc
 
 
+def ops_x3():
+    """Whether the Winograd per-bin GEMMs run as bf16 x 3 split products in this process (ranks that share a GPU switch it off)."""
+    from gdn_amd import ops
+    return ops.x3_enabled()
+
+
 def dist_info():
     """(ranks, backend) of the process group the gradient all-reduce runs on ("nccl" is RCCL on ROCm)."""
     import torch.distributed as dist
@@ -518,6 +524,9 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="storage dtype of activations/MFMA operands; bf16 = BASELINE configs[2] (fp32 accumulate, fp32 "
                          "master weights/BN statistics/losses/Adam). The headline line is fp32 DtoD.")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="data parallel: one all-reduce of the whole gradient arena after backward instead of the bucketed "
+                         "reduction overlapped with it (= GDN_OVERLAP_ALLREDUCE=0), to read a scaling curve against")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)   # CPU test of the self-launcher
@@ -527,6 +536,8 @@ def main():
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
 
+    if args.no_overlap:
+        os.environ["GDN_OVERLAP_ALLREDUCE"] = "0"        # (inherited by self-launched ranks)
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # one command, N GPUs: this process becomes the launcher and never touches the GPU
         return self_launch(args, sys.argv[1:])
@@ -564,16 +575,32 @@ def main():
         step()
     torch.cuda.synchronize()
     barrier()
+    if D.active():
+        D.stats_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank's own loop, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
+    dp = None
+    if D.active():
+        # a multi-rank record that explains itself: the spread of the ranks' own step times, what the gradient all-reduce
+        # cost beyond backward (time the compute stream stood still for it), how it was bucketed, which switches were on
+        dp = D.stats_report(args.steps)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        own = [torch.zeros(2, device=dev, dtype=torch.float64) for _ in range(world)]
+        torch.distributed.all_gather(own, torch.tensor([dt_own / args.steps * 1e3,
+                                                        dp["allreduce_exposed_ms"] if dp["allreduce_exposed_ms"] is not None
+                                                        else dp["allreduce_host_wait_ms"]], device=dev, dtype=torch.float64))
+        per_rank = sorted(float(o[0].item()) for o in own)
+        dp["step_ms_per_rank"] = {"min": round(per_rank[0], 3), "median": round(per_rank[len(per_rank) // 2], 3),
+                                  "max": round(per_rank[-1], 3), "all": [round(float(o[0].item()), 3) for o in own]}
+        dp["allreduce_exposed_ms_per_rank"] = [round(float(o[1].item()), 4) for o in own]
     final_loss = float(loss.item())
     flush_c_stdio()                  # every rank: library banners out before rank 0 prints the result line
     barrier()
@@ -588,6 +615,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
             "rccl_ranks": dist_info()[0], "dist_backend": dist_info()[1],
+            "data_parallel": dp,
             "config": {"workload": "%s training step (fwd + losses + bwd + fused Adam), batch %d per GPU, 128x416, "
                                    "%s, BASELINE configs[%d]" % (args.mode, B, args.dtype, 1 if args.mode == "DtoD" else (3 if world > 1 else 2)),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
@@ -598,6 +626,7 @@ def main():
                                                  "multiplies on the k>=5 layers (frequency domain) and 2.25x fewer on the "
                                                  "3x3 ones (Winograd), so it exceeds the 157 TFLOP/s MFMA peak; the "
                                                  "utilisation figures are roofline.frac and mfma_util",
+                       "x3": bool(ops_x3()), "shared_gpu_ranks": D.SHARED_GPU_RANKS,
                        "final_loss": round(final_loss, 6)},
         }
         if not args.no_roofline and args.dtype == "fp32":

@@ -471,6 +471,8 @@ __device__ __forceinline__ constexpr float tw_lit_cos(int q) {         // cos(2 
 template <int NP>
 __device__ __forceinline__ constexpr float tw_lit_sin(int q) { return tw_lit_cos<NP>((q + 3 * NP / 4) % NP); }   // sin x = cos(x - pi/2)
 
+constexpr int FFT_TN_MAX_SPLITS = 4;    // reduction splits of the weight-gradient GEMM: the cap of tn_splits() AND the size of the tap kernel's load group
+
 template <int K, int NP>
 __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __restrict__ P, float* __restrict__ part, int N, int C,
                                                              int nsplit) {
@@ -495,12 +497,12 @@ __global__ __launch_bounds__(256) void fft_wgrad_taps_kernel(const float* __rest
         for (int ky = 0; ky < KYH; ++ky) {            // (local row index: the half's phase e^{+i 2 pi ky0 ty / NP} is applied once, below)
             // P[0] + P[1] + ... in order, as fft_sum_splits did; at most four partial sets (tn_splits), loaded unconditionally
             // from clamped addresses so that the NP x 4 loads are all in flight instead of one dependent group per ky
-            float2 u[4];
+            float2 u[FFT_TN_MAX_SPLITS];
 #pragma unroll
-            for (int sp = 0; sp < 4; ++sp) u[sp] = F[(size_t)(sp < nsplit ? sp : nsplit - 1) * ssp];
+            for (int sp = 0; sp < FFT_TN_MAX_SPLITS; ++sp) u[sp] = F[(size_t)(sp < nsplit ? sp : nsplit - 1) * ssp];
             float2 v = u[0];
 #pragma unroll
-            for (int sp = 1; sp < 4; ++sp)
+            for (int sp = 1; sp < FFT_TN_MAX_SPLITS; ++sp)
                 if (sp < nsplit) { v.x += u[sp].x; v.y += u[sp].y; }
             F += sky; GDN_KEEP(F);
 #pragma unroll
@@ -954,7 +956,7 @@ inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 inline int tn_splits(const FftGeom& f) {
     const int wgs = (f.N / 64) * (f.C / 64) * f.bins;
     int s = (4096 + wgs - 1) / wgs;
-    if (s > 4) s = 4;
+    if (s > FFT_TN_MAX_SPLITS) s = FFT_TN_MAX_SPLITS;
     while (s > 1 && f.M / s < 64) --s;
     return s < 1 ? 1 : s;
 }
@@ -1111,6 +1113,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     if (dw && (phases & GDN_FFT_BWD_DW)) {
         float* P = Wf;
         const int ns = tn_splits(f);
+        if (ns > FFT_TN_MAX_SPLITS) return GDN_ERR_UNSUPPORTED;          // (the tap kernel sums at most that many partial sets)
         hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * f.bins * ns), dim3(256), 0, st,
                            (const float*)Df, (const float*)xf, P, f.M, f.N, f.C, ns, f.bins);
         float* part = (float*)((char*)P + tn_prod_bytes(f));

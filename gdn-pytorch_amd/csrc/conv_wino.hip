@@ -28,6 +28,7 @@ struct WinoGeom {
     int reflect;                  // input border: 0 zeros, 1 mirror (ReflectionPad2d(1) + conv)
     int tiles_y, tiles_x, M;      // 2x2 output tiles; M = B * tiles_y * tiles_x
     int cq_shift, nq_shift;       // log2(C / 64), log2(N / 64)
+    int x3;                       // per-bin GEMMs as bf16 x 3 split products (gemm_x3.h) unless the caller set GDN_HINT_NO_X3
 };
 
 // V = B^T d B of the 4x4 patch whose top-left corner is (2a - pad_off, 2b - pad_off)
@@ -354,6 +355,7 @@ bool wino_geom(const gdn_conv_geom* g, WinoGeom& f) {
     f.M = g->B * f.tiles_y * f.tiles_x;
     f.cq_shift = 0; while ((64 << f.cq_shift) < f.C) ++f.cq_shift;
     f.nq_shift = 0; while ((64 << f.nq_shift) < f.N) ++f.nq_shift;
+    f.x3 = (g->hints & GDN_HINT_NO_X3) ? 0 : 1;
     return true;
 }
 
@@ -367,12 +369,13 @@ inline size_t u_bytes(const WinoGeom& f) {
     if (p2 > b) b = p2;
     return al256(b);
 }
-// GDN_X3=0 keeps every per-bin GEMM on the fp32 MFMA (A/B measurements, accuracy studies)
-inline bool x3_on() { const char* e = getenv("GDN_X3"); return !(e && e[0] == '0'); }
+// GDN_HINT_NO_X3 in the geometry keeps every per-bin GEMM on the fp32 MFMA (ranks that share a GPU, A/B measurements, accuracy
+// studies).  It is part of the layer's geometry, so the forward that writes the saved weight set and the backward that reads
+// it agree on its form by construction.
 inline size_t m_bytes(const WinoGeom& f) { return al256((size_t)WINO_BINS * f.M * f.N * 4); }
-inline bool tn_x3(const WinoGeom& f) { return x3_on() && gemm_x3_tn_ok(f.M, f.N, f.C); }
+inline bool tn_x3(const WinoGeom& f) { return f.x3 && gemm_x3_tn_ok(f.M, f.N, f.C); }
 inline int tn_splits(const WinoGeom& f) { return tn_x3(f) ? gemm_x3_tn_splits(WINO_BINS, f.M, f.N, f.C) : wino_tn_splits(f.M, f.N, f.C); }
-// (workspace sizing: the larger of the two kernels' split counts, so GDN_X3 may change between the query and the call)
+// (workspace sizing: the larger of the two kernels' split counts)
 inline int tn_splits_max(const WinoGeom& f) {
     const int a = wino_tn_splits(f.M, f.N, f.C), b = gemm_x3_tn_ok(f.M, f.N, f.C) ? gemm_x3_tn_splits(WINO_BINS, f.M, f.N, f.C) : 1;
     return a > b ? a : b;
@@ -420,7 +423,7 @@ extern "C" int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t 
                        in_relu, in_up2x);
     // the per-bin GEMMs run as bf16 x 3 split products on the bf16 matrix pipe where the shape allows (gemm_x3.h); the data
     // gradient's weight set (its GEMM has N = Cin) is written in the form ITS kernel will read
-    const bool x3f = x3_on() && gemm_x3_ok(f.M, f.N, f.C), x3d = x3_on() && gemm_x3_ok(f.M, f.C, f.N);
+    const bool x3f = f.x3 && gemm_x3_ok(f.M, f.N, f.C), x3d = f.x3 && gemm_x3_ok(f.M, f.C, f.N);
     if (!x3f || (Usw && !x3d))
         hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, w, x3f ? (float*)nullptr : U, f.N,
                            f.C, 0, x3d ? (float*)nullptr : Usw);
@@ -507,7 +510,7 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
         const float* Ud = U;
         // (the forward decided the form of its saved set from the FORWARD tile count f.M; the padded-domain gradient of a
         // reflection layer has more tiles but the same N and K, so eligibility is the same)
-        const bool x3d = x3_on() && gemm_x3_ok(f.M, f.C, f.N);
+        const bool x3d = f.x3 && gemm_x3_ok(f.M, f.C, f.N);
         if (state) Ud = (const float*)((const char*)state + v_bytes(f));      // transformed by the forward's launch
         else if (x3d) hipLaunchKernelGGL(wino_weights_x3_kernel, dim3(cdiv(f.N * f.C / 8, 256)), dim3(256), 0, st, w, (unsigned char*)U, f.N, f.C, 1,
                                          (unsigned char*)nullptr, 0);

@@ -40,6 +40,7 @@ struct W2Geom {
     int ta_y, ta_x, Ma;           // form A tiling: 3x3 tiles of the small image
     int tb_y, tb_x, Mb;           // form B tiling: 6x6 blocks of the large image (+ border when padded-domain)
     int xq, yq;                   // log2(Cx / 64), log2(Cy / 64)
+    int x3;                       // per-bin GEMMs as bf16 x 3 split products unless GDN_HINT_NO_X3
 };
 
 // ---- form A input: V[bin][t][(a*2+b)*Cx + c] = (B^T X_ab B)[bin], X_ab[p][q] = xpad[6ty + 2p + a][6tx + 2q + b] ----
@@ -384,6 +385,7 @@ bool w2_geom(const gdn_conv_geom* g, W2Geom& f) {
     f.tb_y = cdiv(f.Hx + ext, 6); f.tb_x = cdiv(f.Wx + ext, 6); f.Mb = f.B * f.tb_y * f.tb_x;
     f.xq = 0; while ((64 << f.xq) < f.Cx) ++f.xq;
     f.yq = 0; while ((64 << f.yq) < f.Cy) ++f.yq;
+    f.x3 = (g->hints & GDN_HINT_NO_X3) ? 0 : 1;
     return true;
 }
 
@@ -399,8 +401,7 @@ inline size_t ux_bytes(const W2Geom& f) {
     const size_t pa = (size_t)WINO_BINS * x3_packed_bytes(f.Cy, 4 * f.Cx), pb = (size_t)WINO_BINS * x3_packed_bytes(4 * f.Cx, f.Cy);
     return ua_bytes(f) + al256(pa > pb ? pa : pb);
 }
-inline bool x3_on() { const char* e = getenv("GDN_X3"); return !(e && e[0] == '0'); }
-inline bool w2_tn_x3(const W2Geom& f) { return x3_on() && gemm_x3_tn_ok(f.Ma, f.Cy, 4 * f.Cx); }
+inline bool w2_tn_x3(const W2Geom& f) { return f.x3 && gemm_x3_tn_ok(f.Ma, f.Cy, 4 * f.Cx); }
 inline int w2_splits(const W2Geom& f) {
     return w2_tn_x3(f) ? gemm_x3_tn_splits(WINO_BINS, f.Ma, f.Cy, 4 * f.Cx) : wino_tn_splits(f.Ma, f.Cy, 4 * f.Cx);
 }
@@ -419,7 +420,7 @@ inline size_t p_bytes(const W2Geom& f) {                                        
 }
 // the 16 per-bin GEMMs Cm = A * U^T: as bf16 x 3 split products on the bf16 matrix pipe where the shape allows, else fp32 MFMA
 void w2_gemm(const W2Geom& f, const float* A, float* U, float* Cm, int M, int N, int K, hipStream_t st) {
-    if (x3_on() && gemm_x3_ok(M, N, K)) {
+    if (f.x3 && gemm_x3_ok(M, N, K)) {
         void* Up = (char*)U + ua_bytes(f);
         launch_x3_pack_rows(U, Up, WINO_BINS, N, K, st);
         launch_gemm_x3_nt(A, Up, Cm, WINO_BINS, M, N, K, st);

@@ -102,26 +102,13 @@ class _Bridge(torch.autograd.Function):
         ctx, outs, arena = fctx.gdn
         fctx.gdn = None
         trainable = any(p.requires_grad for p in fctx.gdn_module.parameters())
-        pending = arena.bind_grads() if trainable else []      # a frozen network (the guide) only passes dx through
-        red = getattr(fctx.gdn_module, "_gdn_reducer", None)
-        # the overlapped reducer hands buckets to async all-reduces while the tape is still running; a carried gradient
-        # (backward without zero_grad: finish_grads adds it to the arena AFTER the tape) or a caller-owned .grad would be
-        # added behind those reductions' backs -- then sync_gradients reduces the whole arena after finish_grads instead
-        if red is not None and red.arena is arena and not pending and not getattr(arena, "_bound_before", None):
-            red.begin()
-            ctx.reducer = red
+        pending = E.begin_backward(fctx.gdn_module, arena, ctx, trainable)
         for o, g in zip(outs, gouts):
             if g is None:
                 continue
             ctx.add_grad(o, E.grad_to_nhwc(g))
         ctx.backward()
-        if trainable:
-            arena.finish_grads()
-        for p, old in pending:       # a caller-owned .grad existed: accumulate like autograd would
-            if p.grad is None:
-                p.grad = old
-            else:
-                p.grad.add_(old)
+        E.end_backward(arena, pending, trainable)
         dx = None
         if ctx.input_needs_grad:
             g = ctx.pop_grad(ctx.input)

@@ -46,46 +46,72 @@ SHARED_GPU_RANKS = 1       # ranks of this job (this one included) that drive th
 
 
 def device_identity(local_rank):
-    """What makes two ranks users of ONE physical GPU: host name + the device's UUID (PCI address as a fallback).  A
-    GDN_SINGLE_DEVICE run (test hook: every rank on device 0) resolves device 0."""
+    """What makes two ranks users of ONE physical GPU: host name + the device's UUID + its PCI address.  None when it
+    cannot be told (no GPU, or a runtime that reports neither a UUID nor a PCI address: an all-zero identity would make
+    every rank of a healthy multi-GPU host look like a neighbour).  A GDN_SINGLE_DEVICE run (test hook: every rank on
+    device 0) resolves device 0."""
     import socket
     if not torch.cuda.is_available():
         return None
     n = torch.cuda.device_count()
     idx = 0 if os.environ.get("GDN_SINGLE_DEVICE") == "1" else (local_rank % n if n else 0)
     pr = torch.cuda.get_device_properties(idx)
-    ident = getattr(pr, "uuid", None)
-    ident = str(ident) if ident is not None else "%s:%s:%s" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", idx),
-                                                               getattr(pr, "pci_device_id", 0))
-    return socket.gethostname() + "/" + ident
+    uuid = str(getattr(pr, "uuid", "") or "")
+    if not uuid.strip("0-") or uuid == "None":           # all zeros / absent: not an identity
+        uuid = ""
+    pci = [getattr(pr, a, None) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    pci = "" if any(v is None for v in pci) or (not uuid and not any(pci)) else "%x:%x:%x" % tuple(pci)
+    if not uuid and not pci:
+        return None
+    return "%s/%s/%s" % (socket.gethostname(), uuid, pci)
+
+
+def exchange_through_store(rank, world, value, key="gdn/dev", timeout_s=120.0):
+    """Every rank's `value` (a short string), gathered through the rendezvous STORE of the default process group -- host
+    TCP traffic the group's construction has already exercised -- rather than through a collective of the group's backend:
+    at start-up nothing has yet proven that RCCL can run one, and a device-identity check must not be the first to try."""
+    from datetime import timedelta
+    store = dist.distributed_c10d._get_default_store()
+    store.set("%s/%d" % (key, rank), value if value is not None else "")
+    keys = ["%s/%d" % (key, r) for r in range(world)]
+    store.wait(keys, timedelta(seconds=timeout_s))
+    out = []
+    for k in keys:
+        v = store.get(k)
+        v = v.decode("utf-8", "replace") if isinstance(v, (bytes, bytearray)) else str(v)
+        out.append(v or None)
+    return out
 
 
 def _guard_shared_gpu(rank, local_rank, world):
     """Several ranks on ONE MI355X (a 1-GPU test box with the gloo hook, or an oversubscribed launch): the bf16 x 3 GEMMs
-    are switched off for this process (GDN_X3=0: the Winograd per-bin GEMMs return to the fp32 matrix instruction).
+    are switched off for this process (ops.set_x3(False): every layer planned from now on carries GDN_HINT_NO_X3 and its
+    Winograd per-bin GEMMs return to the fp32 matrix instruction).
     Measured on this pool (profiles/r03_neighbour_mfma.txt): a kernel that alternates bursts of bf16
     matrix instructions with workgroup barriers -- which is what a tiled bf16 GEMM is -- perturbs FFT-type kernels of
     ANOTHER process that shares the GPU (16-lane pieces of their results change; reproduced with a 30-line kernel as the
     neighbour and rocFFT as the victim), while one process per GPU -- the deployment this package is built for -- and the
-    fp32 matrix instruction are not affected.  An explicit GDN_X3 in the environment is respected."""
+    fp32 matrix instruction are not affected.  An explicit choice (GDN_X3 in the environment) is respected.
+    The identities travel through the rendezvous store, not through a collective (exchange_through_store)."""
     global SHARED_GPU_RANKS
     if world < 2:
         return
     me = device_identity(local_rank)
-    ids = [None] * world
     try:
-        dist.all_gather_object(ids, me)
+        ids = exchange_through_store(rank, world, me)
     except Exception as e:      # noqa: BLE001 -- the guard must never be what stops a job
         import warnings
         warnings.warn("could not compare the ranks' devices (%r); assuming one process per GPU" % (e,), RuntimeWarning)
         return
     SHARED_GPU_RANKS = sum(1 for i in ids if i is not None and i == me) if me is not None else 1
-    if SHARED_GPU_RANKS > 1 and "GDN_X3" not in os.environ:
-        os.environ["GDN_X3"] = "0"            # read by the library at every call
-        if rank == 0:
-            import warnings
-            warnings.warn("%d ranks share one GPU: bf16 x 3 GEMMs disabled (GDN_X3=0) for this job; one process per GPU is "
-                          "the supported layout" % SHARED_GPU_RANKS, RuntimeWarning)
+    if SHARED_GPU_RANKS > 1:
+        from . import ops
+        if not ops.x3_explicit():
+            ops.set_x3(False)
+            if rank == 0:
+                import warnings
+                warnings.warn("%d ranks share one GPU: bf16 x 3 GEMMs disabled for this job (GDN_HINT_NO_X3); one process "
+                              "per GPU is the supported layout" % SHARED_GPU_RANKS, RuntimeWarning)
 
 
 def world_size():
@@ -121,6 +147,56 @@ def allreduce_flat(flat, bucket_elems=BUCKET_ELEMS, async_op=True):
             w.wait()
         return []
     return works
+
+
+class _Stats:
+    """What the all-reduce cost a step, for bench.py's multi-rank record: off unless stats_begin()."""
+
+    def __init__(self):
+        self.on = False
+        self.reset()
+
+    def reset(self):
+        self.syncs = self.buckets = self.bytes = self.fired_early = 0
+        self.host_wait_s = 0.0
+        self.events = []               # (before, after) event pairs on the compute stream around the waits
+
+    def waits(self, works, arena_grad):
+        """Wait for `works`; account the host time spent (gloo blocks the host) and, on a GPU, how long the COMPUTE stream
+        stood still for them (RCCL's wait() is a stream dependency, not a host wait): the exposed all-reduce time."""
+        import time
+        ev = None
+        if self.on and arena_grad.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        t0 = time.perf_counter()
+        for w in works:
+            w.wait()
+        if self.on:
+            self.host_wait_s += time.perf_counter() - t0
+            if ev is not None:
+                ev[1].record()
+                self.events.append(ev)
+
+
+STATS = _Stats()
+
+
+def stats_begin():
+    STATS.reset()
+    STATS.on = True
+
+
+def stats_report(steps):
+    """Per-step means since stats_begin() (call after torch.cuda.synchronize())."""
+    STATS.on = False
+    dev_ms = sum(a.elapsed_time(b) for a, b in STATS.events) if STATS.events else None
+    n = max(1, steps)
+    return {"allreduce_exposed_ms": None if dev_ms is None else round(dev_ms / n, 4),
+            "allreduce_host_wait_ms": round(STATS.host_wait_s * 1e3 / n, 4),
+            "buckets": STATS.buckets // max(1, STATS.syncs), "buckets_in_flight_before_backward_returned": STATS.fired_early // max(1, STATS.syncs),
+            "bytes_reduced": STATS.bytes // max(1, STATS.syncs), "syncs": STATS.syncs,
+            "overlap": os.environ.get("GDN_OVERLAP_ALLREDUCE", "1") != "0"}
 
 
 class GradReducer:
@@ -173,11 +249,14 @@ class GradReducer:
         """Reduce whatever has not been sent yet (parameters that got no gradient this step) and wait."""
         if not self.active:
             return False
+        if STATS.on:
+            STATS.fired_early += sum(1 for f in self.fired if f)
+            STATS.buckets += len(self.buckets)
+            STATS.bytes += 4 * sum(e - s_ for s_, e, _ in self.buckets)
         for i, f in enumerate(self.fired):
             if not f:
                 self._fire(i)
-        for w in self.works:
-            w.wait()
+        STATS.waits(self.works, self.arena.grad)
         self.works = []
         self.active = False
         return True
@@ -208,13 +287,27 @@ def sync_gradients(model, optimizer=None):
     if ar is None:
         raise RuntimeError("sync_gradients: model has no gradient arena yet (run a forward/backward first)")
     red = attach_reducer(model)          # active from the NEXT backward on
+    if STATS.on:
+        STATS.syncs += 1
     if not (red is not None and red.arena is ar and red.finish()):
-        for w in allreduce_flat(ar.grad):
-            w.wait()
+        works = allreduce_flat(ar.grad)
+        if STATS.on:
+            STATS.buckets += len(works)
+            STATS.bytes += 4 * ar.grad.numel()
+        STATS.waits(works, ar.grad)
     if optimizer is not None and hasattr(optimizer, "grad_scale"):
-        optimizer.grad_scale = 1.0 / ws
+        optimizer.grad_scale = 1.0 / ws          # the arena holds SUMS over the ranks
+        scale = 1.0
     else:
-        ar.grad.mul_(1.0 / ws)
+        ar.grad.mul_(1.0 / ws)                   # the arena holds MEANS
+        scale = 1.0 / ws
+    if getattr(ar, "carry_reduced", None) is not None:
+        # gradient accumulation across a sync: the earlier, already reduced gradient was kept out of the arena (as a sum)
+        # while the new local contribution was reduced (engine.ParamArena.finish_grads); they meet here, each summed over the
+        # ranks exactly once
+        ar.grad.add_(ar.carry_reduced, alpha=scale)
+        ar.carry_reduced = None
+    ar.reduced, ar.reduced_scale = True, scale
 
 
 def broadcast_parameters(model, src=0):
@@ -309,8 +402,10 @@ def launch_ranks(argv, devices, module="gdn_amd.GDN_main", extra_env=None, timeo
     capture_rank0: rank 0's stdout is piped and returned as text -> (rc, text); the other ranks' stdout goes to this
     process's stderr, so a caller can forward rank 0's result line as the last line of its own stdout.
 
-    Whatever ends the wait -- success, a failed rank, the timeout, an exception, SIGINT / SIGTERM in the parent -- no child
-    survives it: terminate, a grace period, then kill (each child is a session leader, signalled as a group)."""
+    Whatever ends the wait -- success, a failed rank, the timeout, an exception, SIGINT / SIGTERM / SIGHUP / SIGQUIT in the
+    parent -- no child survives it: terminate, a grace period, then kill (each child is a session leader, signalled as a
+    group; further signals are ignored while that runs).  A launcher that is SIGKILLed takes its ranks with it through
+    PR_SET_PDEATHSIG."""
     import signal
     import subprocess
     import sys
@@ -327,8 +422,18 @@ def launch_ranks(argv, devices, module="gdn_amd.GDN_main", extra_env=None, timeo
 
     in_main = threading.current_thread() is threading.main_thread()
     if in_main:
-        for sg in (signal.SIGTERM, signal.SIGINT):
+        # SIGHUP / SIGQUIT too: the children lead sessions of their own, so a terminal or ssh drop no longer reaches them
+        # through the process group -- the parent has to pass it on
+        for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP, signal.SIGQUIT):
             prev[sg] = signal.signal(sg, on_signal)
+
+    def die_with_parent():
+        # a SIGKILLed launcher cannot run its `finally`: the kernel delivers SIGKILL to the rank when the launcher's thread ends
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)      # PR_SET_PDEATHSIG
+        except Exception:  # noqa: BLE001
+            pass
     rc = 0
     try:
         for r in range(world):
@@ -345,7 +450,7 @@ def launch_ranks(argv, devices, module="gdn_amd.GDN_main", extra_env=None, timeo
             out = None
             if capture_rank0:
                 out = subprocess.PIPE if r == 0 else sys.stderr
-            procs.append(subprocess.Popen(cmd, env=env, stdout=out, start_new_session=True))
+            procs.append(subprocess.Popen(cmd, env=env, stdout=out, start_new_session=True, preexec_fn=die_with_parent))
         if capture_rank0:
             def pump():
                 for line in procs[0].stdout:
@@ -368,6 +473,9 @@ def launch_ranks(argv, devices, module="gdn_amd.GDN_main", extra_env=None, timeo
                 rc = rc or 124
             time.sleep(0.05)
     finally:
+        if in_main:                      # a second signal must not abort the clean-up itself
+            for sg in prev:
+                signal.signal(sg, signal.SIG_IGN)
         _stop(procs)
         if reader is not None:
             reader.join(timeout=5.0)

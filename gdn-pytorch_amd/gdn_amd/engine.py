@@ -87,6 +87,13 @@ class ParamArena:
         self.ptr0 = self.items[0][0].data_ptr() if self.items else 0
         self.generation = 0
         self.data16, self._key16, self._v16 = None, None, {}
+        # data parallelism (distributed.py): `reduced` -- the gradient arena holds sums over the ranks (an all-reduce ran
+        # since the last fresh backward) rather than this rank's local gradients; `carry_reduced` -- an already reduced
+        # gradient carried across a further backward (accumulation without zero_grad), kept OUT of the arena until the new
+        # local contribution has been reduced too (sync_gradients adds it back), so nothing is summed over the ranks twice
+        self.reduced = False
+        self.reduced_scale = 1.0       # 1: the reduced arena holds sums over the ranks; 1/world: means (sync_gradients without an optimizer)
+        self.carry_reduced = None      # always kept as a SUM over the ranks
 
     @staticmethod
     def _view(flat, off, shape, tr):
@@ -165,6 +172,9 @@ class ParamArena:
             for p, o, n, tr in self.items:
                 if id(p) not in self._bound_before:
                     self._carry[o:o + n].zero_()
+        else:
+            self.reduced = False               # a fresh backward overwrites the arena with this rank's local gradients
+            self.carry_reduced = None
         return accumulate
 
     def mark_written(self, params):
@@ -182,8 +192,46 @@ class ParamArena:
             else:
                 p.grad = None
         if self._carry is not None:
-            self.grad.add_(self._carry)
+            if self.reduced:
+                # the carry is a sum over the ranks, what the tape just wrote is local: they meet after the next all-reduce
+                if self.reduced_scale != 1.0:
+                    self._carry.mul_(1.0 / self.reduced_scale)
+                self.carry_reduced = self._carry if self.carry_reduced is None else self.carry_reduced.add_(self._carry)
+                self.reduced = False
+            else:
+                self.grad.add_(self._carry)
             self._carry = None
+
+
+def begin_backward(module, arena, ctx, trainable=True):
+    """Gradient bookkeeping before a model's tape replays (the bridge's backward; also driven directly by the CPU tests of
+    the data-parallel accumulation semantics).  Returns the caller-owned gradients to accumulate afterwards."""
+    red = getattr(module, "_gdn_reducer", None)
+    mine = red is not None and red.arena is arena
+    if mine and red.active:
+        # a previous backward's overlapped all-reduces are still in flight (backward, backward, ... without a
+        # sync_gradients in between): wait for them before bind_grads() reads the arena; it then holds reduced sums
+        red.finish()
+        arena.reduced, arena.reduced_scale = True, 1.0
+    pending = arena.bind_grads() if trainable else []      # a frozen network (the guide) only passes dx through
+    # the overlapped reducer hands buckets to async all-reduces while the tape is still running; a carried gradient
+    # (backward without zero_grad: finish_grads adds it AFTER the tape) or a caller-owned .grad would be added behind
+    # those reductions' backs -- such a backward leaves its local gradients in the arena and sync_gradients reduces the
+    # whole arena afterwards (an already REDUCED carry is kept aside until then: ParamArena.carry_reduced)
+    if mine and trainable and not pending and not arena._bound_before:
+        red.begin()
+        ctx.reducer = red
+    return pending
+
+
+def end_backward(arena, pending, trainable=True):
+    if trainable:
+        arena.finish_grads()
+    for p, old in pending:       # a caller-owned .grad existed: accumulate like autograd would
+        if p.grad is None:
+            p.grad = old
+        else:
+            p.grad.add_(old)
 
 
 def ensure_arena(module, device):
@@ -494,6 +542,12 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     use_fft = (_FFT_MIN_K > 0 and ldt == torch.float32 and x2 is None and conv.kernel_size[0] >= _FFT_MIN_K
                and conv.stride[0] == 1
                and op.fft_ok(x.shape[0], x.shape[1], x.shape[2], backward=ctx.record, train=fft_train))
+    if use_fft and ctx.dtype == torch.bfloat16:
+        # A model that computes in bf16 runs barrier-paced 16-bit matrix kernels (conv_*_bf16) and must never have a
+        # frequency-domain kernel in flight beside them (measured interference on this hardware; the
+        # frequency-domain backward uses a second stream).  No layer of a bf16 model qualifies today (ldt is fp32 only for the
+        # 3-channel input conv); this keeps it that way by construction (tools/check_no_mfma16_beside_fft.py checks traces).
+        raise GdnError("internal: a bf16 model selected a frequency-domain layer")
     use_wino = (not use_fft and _WINOGRAD and ldt == torch.float32 and x2 is None
                 and conv.kernel_size[0] == 3 and conv.stride[0] == 1 and op.wino_ok(x.shape[0], x.shape[1], x.shape[2]))
     use_wino2 = (not use_fft and not use_wino and _WINO2_MIN_C > 0 and ldt == torch.float32 and x2 is None

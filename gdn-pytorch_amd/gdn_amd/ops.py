@@ -40,6 +40,37 @@ def _chk(t, name="tensor", bf16_ok=False):
 
 
 CFG_BF16 = 0x10000      # GDN_CFG_BF16
+HINT_TRAIN, HINT_NO_X3 = 1, 2      # GDN_HINT_* bits of gdn_conv_geom.hints
+
+# bf16 x 3 split products for the Winograd per-bin GEMMs.  The switch lives HERE, not in the library: the
+# environment variable GDN_X3 is read once, at import; distributed._guard_shared_gpu (ranks sharing one GPU), tests and
+# measurements call set_x3().  Every geometry handed to the C ABI carries the decision as GDN_HINT_NO_X3, and a forward's
+# saved state remembers the hints it was written with, so its backward reads the weight set in the form it was written in
+# even if the switch moved in between.
+_x3 = os.environ.get("GDN_X3", "1")[:1] != "0"
+_x3_explicit = "GDN_X3" in os.environ
+
+
+def x3_enabled():
+    return _x3
+
+
+def x3_explicit():
+    """True when the user chose (GDN_X3 in the environment at import, or set_x3(explicit=True))."""
+    return _x3_explicit
+
+
+def set_x3(on, explicit=False):
+    """Switch the bf16 x 3 GEMMs on / off for every layer planned from now on; returns the previous setting."""
+    global _x3, _x3_explicit
+    prev, _x3 = _x3, bool(on)
+    _x3_explicit = _x3_explicit or explicit
+    return prev
+
+
+def _state_x3(state):
+    """The switch a forward wrote `state` under (None: stateless call, use the current one)."""
+    return getattr(state, "_gdn_x3", None) if state is not None else None
 
 
 def _bf(t):
@@ -106,7 +137,10 @@ class Conv:
         self._geom = {}
         self._fwd_ws = {}
 
-    def geom(self, B, H, W, hints=0):
+    def geom(self, B, H, W, hints=0, x3=None):
+        """x3: None = the current switch; a saved state's backward passes what its forward used."""
+        if not (_x3 if x3 is None else x3):
+            hints |= HINT_NO_X3
         key = (B, H, W, hints)
         g = self._geom.get(key)
         if g is None:
@@ -292,6 +326,8 @@ class Conv:
         st = torch.empty((int(lib.gdn_winoconv_stats_slots(ref)), 2, self.cout), dtype=torch.float32,
                          device=x.device) if stats else None
         sv = torch.empty(int(lib.gdn_winoconv_state_bytes(ref)), dtype=torch.uint8, device=x.device) if state else None
+        if sv is not None:
+            sv._gdn_x3 = _x3                 # the form of the saved weight set (fp32 / bf16 x 3 panels) follows the switch
         ws = workspace(nb, x.device, "fft")
         lib.gdn_winoconv_fwd(ref, _p(x), _ld(x), _p(w_tap), _p(y), _ld(y), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
                              _p(st), _p(affine[0]) if affine else None, _p(affine[1]) if affine else None, int(act),
@@ -311,7 +347,7 @@ class Conv:
         _chk(dy, "dy")
         B = dy.shape[0]
         H, W = in_hw
-        _, ref, Ho, Wo = self.geom(B, H, W)
+        _, ref, Ho, Wo = self.geom(B, H, W, x3=_state_x3(state))
         nb = int(lib.gdn_winoconv_bwd_workspace_bytes(ref))
         if nb == 0:
             raise GdnError("winoconv: unsupported layer k=%d stride=%d" % (self.k, self.stride))

@@ -48,31 +48,43 @@ class Adam(torch.optim.Optimizer):
                 loose.append(p)
         return arenas, loose
 
+    def _ensure_dev(self, st, group, device):
+        """Device-side step state of the capturable path for one state store: hyper float32[6] and {double beta1^t, double
+        beta2^t, int32 t, float bc1, float bc2s}; a host-side step count from before (resume) is folded in by advancing the
+        powers on the host first."""
+        if "hyper" not in st:
+            import struct
+            b1, b2 = group["betas"]
+            st["hyper"] = torch.zeros(6, dtype=torch.float32, device=device)
+            t = st["step"] - 1
+            raw = struct.pack("<ddiff", float(b1) ** t, float(b2) ** t, t, 0.0, 0.0)
+            st["state"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+            st["group"] = group
+        self._push_hyper(st, group)
+
     def _apply(self, pdata, grad, st, group, device):
         b1, b2 = group["betas"]
         if self.capturable:
-            if "hyper" not in st:
-                import struct
-                st["hyper"] = torch.zeros(6, dtype=torch.float32, device=device)
-                # {double beta1^t, double beta2^t, int32 t, float bc1, float bc2s}; a host-side step count from before
-                # (resume) is folded in by advancing the powers on the host first
-                t = st["step"] - 1
-                raw = struct.pack("<ddiff", float(b1) ** t, float(b2) ** t, t, 0.0, 0.0)
-                st["state"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
-                st["group"] = group
-            self._push_hyper(st, group)
+            self._ensure_dev(st, group, device)
             ops.adam_step_dev(pdata, grad, st["m"], st["v"], st["hyper"], st["state"])
         else:
             ops.adam_step(pdata, grad, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"],
                           st["step"], self.grad_scale)
 
     def _step_partial(self, ar, st, group):
-        if self.capturable:
-            raise GdnError("capturable Adam needs a gradient for every parameter of the arena (its step counter is one device "
-                           "scalar); a partially covered step cannot be captured")
+        """Per-tensor updates ON SLICES OF THE FLAT MOMENTS for the parameters that have a gradient (torch.optim.Adam skips
+        the others).  Host path: per-parameter step counts (`pstep`), back to the one-launch update once every parameter
+        THAT TAKES GRADIENTS is level again.  Capturable path: the step counter is device memory, so each parameter gets a
+        device state of its own -- a stream-ordered copy of the arena's when the one-launch path ran before -- and the
+        arena stays on per-tensor launches from then on (replays advance those counters behind the host's back, so the
+        host cannot tell when they are level)."""
         if st["pstep"] is None:
             st["pstep"] = {id(p): st["step"] for p, _, _, _ in ar.items}
         b1, b2 = group["betas"]
+        if self.capturable:
+            had_dev = "hyper" in st
+            self._ensure_dev(st, group, ar.device)
+            pdev = st.setdefault("pdev", {})
         for p, o, n, tr in ar.items:
             if p.grad is None:
                 continue
@@ -82,11 +94,28 @@ class Adam(torch.optim.Optimizer):
                 # a caller-owned gradient: bring it into the parameter's physical (tap-major) order
                 gslice = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
             st["pstep"][id(p)] += 1
-            ops.adam_step(ar.data[o:o + n], gslice, st["m"][o:o + n], st["v"][o:o + n], group["lr"], b1, b2, group["eps"],
-                          group["weight_decay"], st["pstep"][id(p)], self.grad_scale)
-        counts = set(st["pstep"].values())
-        if len(counts) == 1:              # everyone level again: back to the one-launch update
-            st["step"], st["pstep"] = counts.pop(), None
+            if self.capturable:
+                ds = pdev.get(id(p))
+                if ds is None:
+                    if had_dev:
+                        ds = st["state"].clone()          # the arena's device counter so far (no host read)
+                    else:
+                        import struct
+                        t = st["pstep"][id(p)] - 1
+                        raw = struct.pack("<ddiff", float(b1) ** t, float(b2) ** t, t, 0.0, 0.0)
+                        ds = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(ar.device)
+                    pdev[id(p)] = ds
+                ops.adam_step_dev(ar.data[o:o + n], gslice, st["m"][o:o + n], st["v"][o:o + n], st["hyper"], ds)
+            else:
+                ops.adam_step(ar.data[o:o + n], gslice, st["m"][o:o + n], st["v"][o:o + n], group["lr"], b1, b2, group["eps"],
+                              group["weight_decay"], st["pstep"][id(p)], self.grad_scale)
+        if self.capturable:
+            return
+        counts = {st["pstep"][id(p)] for p, _, _, _ in ar.items if p.requires_grad}     # (a frozen parameter never levels)
+        if len(counts) == 1:              # everyone who steps is level again: back to the one-launch update
+            lvl = counts.pop()
+            if all(st["pstep"][id(p)] == lvl for p, _, _, _ in ar.items):
+                st["step"], st["pstep"] = lvl, None
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 from oracle import gdn_oracle as O
 import gdn_amd.AE_model_unet as M
+from gdn_amd import ops
 dev = torch.device("cuda:0")
 H, W = 128, 416
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
@@ -47,7 +48,7 @@ for seed in range(2):
 
     score("oracle fp32", out32, g32)
     for x3 in ("1", "0"):
-        os.environ["GDN_X3"] = x3
+        ops.set_x3(x3 == "1")
         model = M.AutoEncoder_DtoD(input_dim=1, height=H, width=W)
         model.load_state_dict(sd)
         model = model.to(dev).train()

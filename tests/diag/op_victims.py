@@ -17,7 +17,7 @@ C = torch.empty(16, 2080, 512, device=dev)
 cases = {}
 # frequency-domain layer (known victim), Winograd F(2,3) with fp32 GEMMs, F(3x3,2x2), direct fp32 conv, conv_c1, BN passes, losses, Adam
 import os
-os.environ["GDN_X3"] = "0"          # the victims' own GEMMs on the fp32 instruction
+ops.set_x3(False)          # the victims' own GEMMs on the fp32 instruction
 cv = ops.Conv(128, 128, 7, 1, 3); x7 = rn(4, 32, 64, 128); w7 = rn(49, 128, 128) * 0.02
 cases["frequency-domain 7x7 forward"] = lambda: cv.fft_fwd(x7, w7, stats=True)[0]
 c3 = ops.Conv(512, 512, 3, 1, 1); x3 = rn(4, 16, 52, 512); w3 = rn(9, 512, 512) * 0.02
@@ -59,10 +59,8 @@ for neighbour in (False, True):
         for it in range(n):
             if neighbour:
                 with torch.cuda.stream(side):
-                    os.environ["GDN_X3"] = "1"
                     for _ in range(3):
                         ops.gemm_x3_nt(A, Bp, 512, out=C)
-                    os.environ["GDN_X3"] = "0"
             res = fn()
             torch.cuda.synchronize()
             if ref is None:

@@ -16,6 +16,7 @@ def run(rank, world, port, steps, out_dir, overlap, global_berhu=False):
                       WORLD_SIZE=str(world), GDN_OVERLAP_ALLREDUCE="1" if overlap else "0")
     import gdn_amd.AE_model_unet as M
     from gdn_amd import distributed as D
+    from gdn_amd import ops
     from gdn_amd import utils as U
     from gdn_amd.optim import Adam
     from oracle import gdn_oracle as O
@@ -50,7 +51,7 @@ def run(rank, world, port, steps, out_dir, overlap, global_berhu=False):
     torch.cuda.synchronize()
     torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "losses": losses, "trace": trace,
                 "reducer": getattr(model, "_gdn_reducer", None) is not None,
-                "x3": os.environ.get("GDN_X3"), "shared": D.SHARED_GPU_RANKS},
+                "x3": "1" if ops.x3_enabled() else "0", "shared": D.SHARED_GPU_RANKS},
                os.path.join(out_dir, "rank%d.pt" % rank))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

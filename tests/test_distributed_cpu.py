@@ -269,7 +269,10 @@ def _shared_gpu_worker(rank, world, port, q, same):
         with warnings.catch_warnings(record=True) as seen:
             warnings.simplefilter("always")
             D.init(backend="gloo")
-        q.put((rank, D.SHARED_GPU_RANKS, os.environ.get("GDN_X3"), sum("share one GPU" in str(w.message) for w in seen)))
+        from gdn_amd import ops
+        # the switch is a Python-side setting handed to the library as GDN_HINT_NO_X3, not an environment variable
+        q.put((rank, D.SHARED_GPU_RANKS, "1" if ops.x3_enabled() else "0", sum("share one GPU" in str(w.message) for w in seen),
+               os.environ.get("GDN_X3")))
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     except Exception as e:      # noqa: BLE001
@@ -279,7 +282,7 @@ def _shared_gpu_worker(rank, world, port, q, same):
 @pytest.mark.parametrize("same", [True, False])
 def test_ranks_sharing_one_gpu_switch_the_bf16x3_gemms_off(same):
     """distributed.init: ranks whose device identities coincide (a 1-GPU box under the gloo hook, an oversubscribed
-    launch) run with GDN_X3=0 -- the measured cross-process interference of barrier-paced bf16 matrix bursts with a
+    launch) switch the bf16 x 3 GEMMs off (ops.set_x3(False) -> GDN_HINT_NO_X3 on every geometry) -- the measured cross-process interference of barrier-paced bf16 matrix bursts with a
     neighbour's FFT kernels -- and rank 0 says so once; ranks on different GPUs change nothing."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -294,4 +297,187 @@ def test_ranks_sharing_one_gpu_switch_the_bf16x3_gemms_off(same):
     if same:
         assert [(g[1], g[2]) for g in got] == [(2, "0"), (2, "0")] and got[0][3] == 1 and got[1][3] == 0
     else:
-        assert [(g[1], g[2], g[3]) for g in got] == [(1, None, 0), (1, None, 0)]
+        assert [(g[1], g[2], g[3]) for g in got] == [(1, "1", 0), (1, "1", 0)]
+    assert all(g[4] is None for g in got), "the guard must not touch the environment"
+
+
+def _accum_worker(rank, world, port, q, overlap):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), GDN_OVERLAP_ALLREDUCE="1" if overlap else "0")
+    import sys
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root)); sys.path.insert(0, str(root / "gdn-pytorch_amd"))
+    torch.set_num_threads(1)
+    from gdn_amd import distributed as D
+    from gdn_amd import engine as E
+    try:
+        D.init(backend="gloo")
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Conv2d(4, 8, 3, bias=False), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 8, 1, bias=False),
+                                    torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 2, 3, bias=False))
+        arena = E.ParamArena(model, torch.device("cpu"))
+        model._gdn_param_arena = arena
+        params = list(model.parameters())
+
+        def g(step, r):                                   # the "local gradient" of rank r in backward number `step`
+            gen = torch.Generator().manual_seed(1000 * step + r)
+            return [torch.randn(p.shape, generator=gen) for p in params]
+
+        def backward(step):
+            """What _Bridge.backward does around the tape, with a tape that writes this rank's gradients in reverse order."""
+            ctx = E.Ctx(record=True, arena=arena)
+            pending = E.begin_backward(model, arena, ctx)
+            for p, gp in reversed(list(zip(params, g(step, rank)))):
+                p.grad.copy_(gp)
+                ctx.grads_done(p)
+            E.end_backward(arena, pending)
+            return ctx.reducer is not None
+
+        def zero():
+            for p in params:
+                p.grad = None
+
+        def want(steps):
+            return [sum(g(s, r)[i] for s in steps for r in range(world)) for i in range(len(params))]
+
+        def check(steps, what):
+            """sync_gradients(model, None) leaves the MEAN over the ranks of the accumulated gradient"""
+            for p, w in zip(params, want(steps)):
+                torch.testing.assert_close(p.grad * world, w, rtol=1e-5, atol=1e-6, msg=lambda m: what + ": " + m)
+
+        if overlap:
+            assert D.attach_reducer(model) is not None
+            model._gdn_reducer = D.GradReducer(arena, bucket_elems=200)       # several buckets for this tiny arena
+            assert len(model._gdn_reducer.buckets) > 2
+        # (a) backward, backward, sync: the second backward meets reductions of the first still in flight
+        assert backward(1) == overlap
+        assert backward(2) is False                        # an accumulating backward never overlaps
+        D.sync_gradients(model, None)
+        check((1, 2), "backward, backward, sync")
+        # (b) backward, sync, backward, sync: the first sum must not be reduced (or averaged) a second time
+        zero()
+        backward(3); D.sync_gradients(model, None)
+        check((3,), "backward, sync")
+        backward(4); D.sync_gradients(model, None)
+        check((3, 4), "backward, sync, backward, sync")
+        # (c) three backwards, one sync; then (d) a fresh step after zero_grad overlaps again
+        zero()
+        backward(5); backward(6); backward(7)
+        D.sync_gradients(model, None)
+        check((5, 6, 7), "three backwards, one sync")
+        zero()
+        assert backward(8) == overlap
+        D.sync_gradients(model, None)
+        check((8,), "fresh step after zero_grad")
+        # (e) with an optimizer the arena keeps SUMS and the 1/world rides in its grad_scale
+        class _Opt:
+            grad_scale = 1.0
+        opt = _Opt()
+        zero()
+        backward(9); D.sync_gradients(model, opt); backward(10); D.sync_gradients(model, opt)
+        assert opt.grad_scale == 1.0 / world
+        for p, w in zip(params, want((9, 10))):
+            torch.testing.assert_close(p.grad, w, rtol=1e-5, atol=1e-6)
+        assert arena.carry_reduced is None and arena.reduced
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("overlap", [True, False])
+def test_gradient_accumulation_under_data_parallelism(overlap):
+    """backward without zero_grad under data parallelism.  Every rank's contributions must be summed over the
+    ranks exactly once, whichever way backwards and sync_gradients interleave, with and without the overlapped reducer."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, q, overlap)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _store_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "gdn-pytorch_amd"))
+    from gdn_amd import distributed as D
+    import torch.distributed as dist
+    try:
+        calls = []
+        real = dist.all_gather_object
+        dist.all_gather_object = lambda *a, **k: calls.append("all_gather_object") or real(*a, **k)
+        D.device_identity = lambda lr: None if lr == 2 else "host/uuid-%d/0:%d:0" % (lr // 2, lr // 2)
+        D.init(backend="gloo")
+        ids = D.exchange_through_store(rank, world, "second-%d" % rank, key="gdn/test")
+        q.put((rank, D.SHARED_GPU_RANKS, ids, calls))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:      # noqa: BLE001
+        q.put((rank, "error", repr(e), []))
+
+
+def test_device_identities_travel_through_the_store_not_a_collective():
+    """the start-up guard compares (host, device) identities through the rendezvous store; no
+    collective of the group's backend runs before the first real one.  Three ranks: 0 and 1 share a device, rank 2's
+    identity is unknown (None) and therefore shares with nobody."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_store_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert all(g[1] != "error" for g in got), got
+    assert [g[1] for g in got] == [2, 2, 1]
+    assert all(g[2] == ["second-0", "second-1", "second-2"] and g[3] == [] for g in got), got
+
+
+@pytest.mark.parametrize("sig", ["HUP", "KILL"])
+def test_launcher_death_takes_the_ranks_along(tmp_path, sig):
+    """the ranks lead sessions of their own, so SIGHUP to the launcher (a dropped terminal) must be passed on, and
+    a SIGKILLed launcher -- which runs no clean-up -- must still not leave GPU ranks behind (PR_SET_PDEATHSIG)."""
+    import pathlib
+    import signal
+    import subprocess
+    import sys
+    import time
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sleeper = tmp_path / "sleeper.py"
+    sleeper.write_text("import os, sys, time\n"
+                       "open(sys.argv[1] + '/pid%s' % os.environ['RANK'], 'w').write(str(os.getpid()))\n"
+                       "time.sleep(600)\n")
+    launcher = tmp_path / "launcher.py"
+    launcher.write_text("import sys\nsys.path.insert(0, %r)\nfrom gdn_amd import distributed as D\n"
+                        "sys.exit(D.launch_ranks([%r], [None, None], script=%r, timeout=300))\n"
+                        % (str(root / "gdn-pytorch_amd"), str(tmp_path), str(sleeper)))
+    lp = subprocess.Popen([sys.executable, str(launcher)])
+    try:
+        t0 = time.time()
+        while not all((tmp_path / ("pid%d" % r)).exists() and (tmp_path / ("pid%d" % r)).read_text() for r in range(2)):
+            assert time.time() - t0 < 120 and lp.poll() is None
+            time.sleep(0.1)
+        pids = [int((tmp_path / ("pid%d" % r)).read_text()) for r in range(2)]
+        lp.send_signal(getattr(signal, "SIG" + sig))
+        lp.wait(timeout=60)
+        t0 = time.time()
+        while any(subprocess.run(["kill", "-0", str(p)], capture_output=True).returncode == 0 for p in pids):
+            assert time.time() - t0 < 30, "ranks %s survived SIG%s of the launcher" % (pids, sig)
+            time.sleep(0.1)
+    finally:
+        if lp.poll() is None:
+            lp.kill()

@@ -328,7 +328,7 @@ def test_data_parallel_two_ranks(gpu, tmp_path, monkeypatch, overlap, global_ber
     # the two ranks share this box's one GPU: distributed.init saw it and took the bf16 x 3 GEMMs out (a
     # neighbour process's barrier-paced bf16 matrix bursts perturb FFT-type kernels on this hardware); same switch here
     assert r0["shared"] == 2 and r0["x3"] == "0" and r1["x3"] == "0"
-    monkeypatch.setenv("GDN_X3", "0")
+    monkeypatch.setattr(ops, "_x3", False)              # ops.set_x3(False), undone after the test
     # single-process emulation: replica A plays rank 0, replica B rank 1 (own BN buffers, shared weights)
     torch.manual_seed(0)
     A = M.AutoEncoder_DtoD(input_dim=1, height=32, width=64).to(gpu).train()

@@ -530,6 +530,18 @@ def test_bench_gpus_2_self_launch_trains_two_ranks(gpu, mode, dtype):
     assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2" and rec["scaling"] == "weak"
     assert rec["dtype"] == ("f32" if dtype == "fp32" else "bf16") and mode in rec["config"]["workload"]
     assert sum(ln.startswith("{") for ln in lines) == 1
+    # the multi-rank record explains itself: per-rank step spread, exposed all-reduce time, bucketing, switches
+    dp = rec["data_parallel"]
+    assert dp["overlap"] is True and dp["syncs"] == 2 and dp["buckets"] >= 2 and dp["bytes_reduced"] > 4 * 60e6
+    assert len(dp["step_ms_per_rank"]["all"]) == 2 and dp["step_ms_per_rank"]["min"] <= dp["step_ms_per_rank"]["max"]
+    assert dp["allreduce_exposed_ms"] is not None and dp["allreduce_exposed_ms"] >= 0.0 and len(dp["allreduce_exposed_ms_per_rank"]) == 2
+    shared = torch.cuda.device_count() < 2
+    assert rec["config"]["shared_gpu_ranks"] == (2 if shared else 1) and rec["config"]["x3"] is (not shared)
+    # ... and --no-overlap gives the curve to read it against: one whole-arena all-reduce after backward
+    r2 = subprocess.run(cmd + ["--no-overlap"], capture_output=True, text=True, env=env, timeout=900, cwd=str(root))
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    dp2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.strip()][-1])["data_parallel"]
+    assert dp2["overlap"] is False and dp2["buckets_in_flight_before_backward_returned"] == 0 and abs(dp2["bytes_reduced"] - dp["bytes_reduced"]) < 0.01 * dp["bytes_reduced"]
 
 
 def _diag_child(script, args, timeout=600):

@@ -13,6 +13,8 @@ timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCL
 cd $R
 python3 - $out <<'PY'
 import csv, glob, json, os, sys, collections, re
+sys.path.insert(0, "tools")
+from kernel_family import family
 out = sys.argv[1]
 files = glob.glob(out + "/p/*/*counter_collection.csv") + glob.glob(out + "/p/*counter_collection.csv")
 if not files:
@@ -23,8 +25,7 @@ nd = 0
 for r in csv.DictReader(open(files[0])):
     n, c, v = r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])
     tot[c] += v
-    f = ("fft chain" if re.search(r"cgemm|fft", n) else "winograd" if ("wino" in n or re.search(r"\bw2_", n)) else
-         "direct wgrad" if "wgrad" in n else "direct conv" if re.search(r"conv_igemm|conv_rowpatch|conv_c1|conv_head|splitk", n) else "other")
+    f = family(n)
     fam[f][c] += v
     nd += c == "GRBM_GUI_ACTIVE"
 util = 100.0 * tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * tot["GRBM_GUI_ACTIVE"] / 8)

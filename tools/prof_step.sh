@@ -23,17 +23,8 @@ grp = collections.Counter()
 tot = collections.Counter()
 torch_k = 0
 adam_at = []
-def family(n):
-    if re.search(r"cgemm|fft", n): return "fft chain"
-    if "wino" in n or re.search(r"\bw2_", n): return "winograd"
-    if re.search(r"conv_igemm|conv_rowpatch|conv_head|conv_c1|splitk", n) and "wgrad" not in n: return "direct conv (igemm/rowpatch/c1/head/splitk)"
-    if "wgrad" in n: return "direct wgrad"
-    if re.search(r"bn_", n): return "batchnorm"
-    if re.search(r"berhu|sobel|smooth|sqdiff|finalize_sum|absdiff|zero_u32", n): return "losses/metrics"
-    if "adam" in n: return "adam"
-    if "at::native" in n or n.startswith("void at::"): return "torch (at::native)"
-    if "rocclr" in n or "copyBuffer" in n or "fillBuffer" in n: return "runtime copies/fills (set-up, outside the steps)"
-    return "other gdn"
+sys.path.insert(0, "tools")
+from kernel_family import family, is_ours
 for i, r in enumerate(rows):
     n = r["Kernel_Name"]
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
@@ -52,8 +43,7 @@ if steps >= 2:
     inner = rows[a + 1:b + 1]
     span = (int(rows[b]["End_Timestamp"]) - int(rows[a]["End_Timestamp"])) / 1e6
     busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in inner) / 1e6
-    foreign = [r["Kernel_Name"] for r in inner if not family(r["Kernel_Name"]).split()[0] in
-               ("fft", "winograd", "direct", "batchnorm", "losses/metrics", "adam", "other")]
+    foreign = [r["Kernel_Name"] for r in inner if not is_ours(r["Kernel_Name"])]
     print("steady-state step (between the last two adam kernels): %d dispatches, %.2f ms span, %.2f ms sum of kernel time, "
           "%d not from libgdn_hip.so%s" % (len(inner), span, busy, len(foreign), (": " + ", ".join(sorted(set(foreign))[:4])) if foreign else ""))
 print("%-48s %10s %8s %8s" % ("family", "ms/step", "%", "launches/step"))
@@ -61,4 +51,6 @@ for k, v in grp.most_common():
     print("%-48s %10.2f %8.1f %8.1f" % (k, v / 1e3 / max(steps, 1), 100 * v / T, tot[k] / max(steps, 1)))
 print("%-48s %10.2f" % ("sum of kernel time per step", T / 1e3 / max(steps, 1)))
 PY
-head -c 400 $out/bench.json; echo; cat $out/step_summary.txt; head -45 $out/by_kernel_and_grid.txt
+python3 tools/check_no_mfma16_beside_fft.py $tr --label "$tag ($*)" > $out/mfma16_vs_fft.txt; chk=$?
+head -c 400 $out/bench.json; echo; cat $out/step_summary.txt; cat $out/mfma16_vs_fft.txt; head -45 $out/by_kernel_and_grid.txt
+exit $chk

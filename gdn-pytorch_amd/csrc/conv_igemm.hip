@@ -901,6 +901,8 @@ __global__ __launch_bounds__(256, 3) void conv_rowpatch_bf16(const IgemmParams p
     }
 }
 
+#include "conv_ring.h"
+
 // ---------------------------------------------------------------------------
 // Host side: geometry -> phases / tap lists, tile selection, launch.
 // ---------------------------------------------------------------------------
@@ -962,15 +964,27 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
 
 namespace {
 
+// CU count of the current device (a device attribute, read once per process: 256 on MI355X)
+int gdn_num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
+        (void)hipGetLastError();
+        return v > 0 ? v : 256;
+    }();
+    return n;
+}
+
 // Buffer descriptors address 32 bits; out-of-range sentinels sit just below 4 GiB.
 const uint64_t kMaxBufBytes = 0xFF000000ull;
 
 struct TileCfg { int bm, bn; };
 // cfg ids: 1: 128x128  2: 128x64  3: 64x64  4: 128x32  (5: scalar-gather 128x64)  6: 32x128  7: 64x128
 //          8: row-patch 256x128  9: row-patch 256x64 (bf16, stride-1 layers with k >= 3)
-#define NUM_CFG 10
+//          10: LDS-DMA ring 256x64  11: LDS-DMA ring 256x128 (conv_ring.h: bf16, stride-1 layers with k in {3,5,7,9})
+#define NUM_CFG 12
 const TileCfg kCfg[NUM_CFG] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 64}, {32, 128}, {64, 128},
-                               {256, 128}, {256, 64}};
+                               {256, 128}, {256, 64}, {256, 64}, {256, 128}};
 
 // Row-patch kernel eligibility (geometry only, so the slot/workspace queries agree with the launch): one phase,
 // stride 1, >= 3 taps per filter row with consecutive dx, 64-channel slabs, and a 256-pixel tile whose touched
@@ -995,11 +1009,45 @@ bool rowpatch_ok(const IgemmParams& P) {
     return nrows_max <= RP_NRMAX && RP_BM + nrows_max * (kw - 1) <= RP_PMAX;
 }
 
+// LDS-DMA ring kernel eligibility (geometry only): as the row-patch kernel, with an odd window of 3..9 taps per row (the
+// instantiated schedules), whole BN-channel tiles, and the touched rows' halos within the 64 spare positions of the patch.
+int ring_kw(const IgemmParams& P) {
+    if (P.nphase != 1 || P.stride != 1 || (P.Cred % 64)) return 0;
+    const IgemmPhase& ph = P.ph[0];
+    const int ntap = ph.tap_end - ph.tap_begin;
+    int kw = 1;
+    while (kw < ntap && P.tdy[ph.tap_begin + kw] == P.tdy[ph.tap_begin]) ++kw;
+    if (!(kw == 3 || kw == 5 || kw == 7 || kw == 9) || ntap % kw || ntap / kw > RG_KMAX) return 0;
+    // every filter row: the same dx sequence, +-1 per tap, weights consecutive (the kernel derives a tap from its row's first)
+    const int dir = P.tdx[ph.tap_begin + 1] - P.tdx[ph.tap_begin];
+    if (dir != 1 && dir != -1) return 0;
+    for (int r = 0; r < ntap / kw; ++r)
+        for (int t = 0; t < kw; ++t) {
+            const int i = ph.tap_begin + r * kw + t, i0 = ph.tap_begin + r * kw;
+            if (P.tdy[i] != P.tdy[i0] || P.tdx[i] != P.tdx[ph.tap_begin] + dir * t || P.twi[i] != P.twi[i0] + t) return 0;
+        }
+    const int nrows_max = (RG_BM - 1 + ph.Wo - 1) / ph.Wo + 1;
+    if (nrows_max > RG_NRMAX || RG_BM + nrows_max * (kw - 1) > RG_APOS) return 0;
+    return kw;
+}
+bool ring_ok(const IgemmParams& P, int bn) { return ring_kw(P) != 0 && P.N % bn == 0 && !P.x2; }
+
 // bf16: the MFMA is 16x faster, so tiles must be large enough to amortise the staging of a k-step.
 int pick_cfg_bf16(const IgemmParams& P, int64_t M, int N, int forced) {
     const bool rp = rowpatch_ok(P);
     if (forced >= 1 && forced <= 3) return forced;
     if ((forced == 8 || forced == 9) && rp) return forced;
+    if (forced == 10 && ring_ok(P, 64)) return 10;
+    if (forced == 11 && ring_ok(P, 128)) return 11;
+    // round 4 (tests/diag/ring_check.py, ring_probe.py at B = 20): the LDS-DMA ring kernel (conv_ring.h) beats both round-1
+    // kernels on every stride-1 layer with a 3..9 window -- 9x9 / 64 ch 1070 vs 930, 7x7 / 128 ch 1045 vs 886, 5x5 / 256 ch 885
+    // vs 725, 3x3 / 512 ch at 8x26 418 vs 266 TFLOP/s, level with them at 16x52 (603) -- and its data gradients with a residual
+    // by more (coalesced epilogue).  256 x 128 tiles where they still fill the chip's 256 persistent workgroups twice, else
+    // 256 x 64 (more, smaller units for the tail: B = 20 gives 65/64 of a power of two tiles at every level).
+    if (forced == 0 && ring_kw(P) != 0 && !P.x2 && N % 64 == 0) {
+        if (N % 128 == 0 && cdiv64(M, RG_BM) * (N / 128) >= 1024) return 11;
+        return 10;
+    }
     // measured (profiles/r01_tune_conv_bf16_rowpatch.txt, _v5.txt): the 256x64 row-patch kernel at three workgroups per
     // CU wins on the layers with <= 128 output channels (9x9 64ch: 1000 vs 640, 7x7 128ch: 900 vs 800 TFLOP/s); with 256+
     // output channels the 128x128 tap-major tile re-uses each activation tile more and stays ahead; the 256x128 row-patch
@@ -1148,6 +1196,17 @@ int launch_igemm(IgemmParams& P, int cfg, hipStream_t st, int ksplit = 1, void* 
             case 3: hipLaunchKernelGGL((conv_igemm_bf16<64, 64, 2, 2>), grid, dim3(256), 0, st, P); break;
             case 8: hipLaunchKernelGGL((conv_rowpatch_bf16<128, 2, 2>), dim3(gm_pad * P.grid_n), dim3(256), 0, st, P); break;
             case 9: hipLaunchKernelGGL((conv_rowpatch_bf16<64, 4, 1>), dim3(gm_pad * P.grid_n), dim3(256), 0, st, P); break;
+            case 10: case 11: {
+                // persistent workgroups, one per CU: every XCD (workgroups b, b + 8, ...) walks its band of tiles
+                const int units_xcd = cdiv(P.grid_m, 8) * P.grid_n, cus_xcd = gdn_num_cus() / 8 > 0 ? gdn_num_cus() / 8 : 32;
+                const dim3 g1(8 * (units_xcd < cus_xcd ? units_xcd : cus_xcd)), b1(512);
+#define GDN_RING(BNV, KWV) hipLaunchKernelGGL((conv_ring_bf16<BNV, KWV>), g1, b1, 0, st, P)
+                const int kw = ring_kw(P);
+                if (cfg == 10) { if (kw == 3) GDN_RING(64, 3); else if (kw == 5) GDN_RING(64, 5); else if (kw == 7) GDN_RING(64, 7); else if (kw == 9) GDN_RING(64, 9); else return GDN_ERR_UNSUPPORTED; }
+                else { if (kw == 3) GDN_RING(128, 3); else if (kw == 5) GDN_RING(128, 5); else if (kw == 7) GDN_RING(128, 7); else if (kw == 9) GDN_RING(128, 9); else return GDN_ERR_UNSUPPORTED; }
+#undef GDN_RING
+                break;
+            }
             default: return GDN_ERR_BAD_ARG;
         }
     } else
@@ -1328,6 +1387,7 @@ extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const void* xv, int32_t ldx,
     const int cfg = pick_cfg(P, P.N, scalar, tile_cfg);
     // the row-patch kernel reads one input tensor; a fused concat with k >= 3 has no call site in the networks
     if (cfg >= 8 && x2) return GDN_ERR_UNSUPPORTED;
+    if (cfg >= 10) P.kc = (tile_cfg >> 12) & 15;             // conv_ring_bf16: measurement knobs (0 in production)
     const int ksplit = pick_ksplit(P, cfg, scalar, tile_cfg);
     if (ksplit > 1 && (!workspace || workspace_bytes < ksplit_bytes(P, ksplit))) return GDN_ERR_WORKSPACE;
     if (ksplit > 1 && ((ldy % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
@@ -1403,6 +1463,7 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t l
     else { P.y = dx; P.ldy = ldx; P.addsrc = addsrc; P.ld_add = ld_add; }
     if (ksplit > 1 && ((P.ldy % 4) || (P.addsrc && (P.ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
     P.kc = (!scalar && g->Cout % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
+    if (cfg >= 10) P.kc = (tile_cfg >> 12) & 15;
     int rc = launch_igemm(P, cfg, st, ksplit, ksplit > 1 ? (char*)workspace + fb : nullptr);
     if (rc != GDN_OK) return rc;
     if (fold && (g->Cin % 4)) {

@@ -1,0 +1,492 @@
+// conv_ring_bf16: the bf16 implicit-GEMM core of the stride-1 layers with a k x k window, k >= 3 (round 4).
+// (included by conv_igemm.hip after IgemmParams / bf16x8)
+//
+// What the round-1 kernels (conv_rowpatch_bf16 / conv_igemm_bf16) left on the table: a k-step of 16 MFMAs between TWO
+// workgroup barriers, operands staged global -> registers -> LDS, and three resident workgroups per CU as the only means of
+// hiding the barriers, the LDS refill and the fragment-read latency (MFMA pipe 36 % busy).  This kernel is the
+// other structure:
+//
+//   * ONE persistent 512-thread workgroup per CU (8 waves, two per SIMD) walks tiles of 256 consecutive output pixels x BN
+//     output channels.  Outside its tap loop a tile costs ~10 us of 40 (tables, the first LDS-DMA round trip, the epilogue's
+//     stores -- measured with the loop skipped), and one workgroup per CU has nobody to hide that behind: so the NEXT tile's
+//     first patch and weight tiles are requested before the epilogue of the current one starts, and the epilogue writes whole
+//     128-byte lines (accumulators transposed through LDS) instead of 2-byte scattered stores.
+//   * The row-patch idea is kept: per (filter row, 64-channel slab) -- a STAGE -- the input rows those pixels need, each with
+//     its k-1 halo, are staged once; the k taps of the row read that image at a shifted position.
+//   * Everything is staged by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write.  The A patch is
+//     double-buffered (2 x 40 KB), the weight tiles (BN x 64 channels per tap) go through a ring of NSLOT slots
+//     (8 x 8 KB for BN = 64, 4 x 16 KB for BN = 128): 147 KB of the CU's 160 KB.
+//   * ONE raw s_barrier per tap step and counted s_waitcnt vmcnt(N): the pieces of tap t+1 are waited for at the start of step
+//     t, become visible to every wave at that step's barrier and are first read one phase later (the read-ahead of step t+1's
+//     first fragments, issued under the last MFMAs of step t); the pieces of tap t+1+DP are issued right after the barrier
+//     into the slot whose last reader was step t-1 or earlier.  Nothing ever drains to vmcnt(0) inside the loop.
+//   * LDS images are row-major 128-byte rows (64 channels) with the 16-byte chunks of a row XOR-permuted by (row >> 1) & 7:
+//     a ds_read_b128 fragment read of 16 rows out of any 28 consecutive ones then touches 16 different 16-byte bank slots
+//     (conflict-free, also at every tap shift).  An LDS-DMA piece writes 1 KB = 8 rows linearly, so the permutation is applied
+//     to the per-lane SOURCE address (same 128-byte line: the global side stays fully coalesced) and again on the read.
+//   * BN = 64 (the 9x9 / 64-channel layers): the 8 waves are 4 (pixels) x 2 (halves of the 64-channel slab): every wave keeps
+//     a 64 x 64 accumulator tile -- one 16-byte fragment read per MFMA, as a 128 x 128 GEMM tile -- and the two halves meet once,
+//     through LDS, in the epilogue.  BN = 128: 4 (pixels) x 2 (64 output channels each).
+//
+// Epilogue fusions are the ones of conv_igemm_bf16: BatchNorm sum / sum-of-squares partials, eval-BN affine, ReLU, residual.
+#pragma once
+
+#define RG_BM 256
+#define RG_APOS 320                       // staged patch positions per A buffer: 5 LDS-DMA pieces (8 positions each) per wave
+#define RG_ABYTES (RG_APOS * 128)
+#define RG_NRMAX 12                       // image rows a 256-pixel tile may touch (W >= 26)
+#define RG_KMAX 9
+#define RG_AV 5                           // A pieces per wave and stage
+
+// Which LDS-DMA pieces a wave issues at which tap step: its BV pieces of the weight tile of step u + 1 + DP at every step, and
+// its RG_AV pieces of the NEXT stage's patch at tap steps 0 .. KW-1-DP (they must have landed when the stage's last barrier
+// publishes them), spread as evenly as that allows.  (Measured and not kept: the two halves of the workgroup issuing one stream
+// each -- vmcnt retires a wave's loads in order, so a weight tile waits for an older patch piece of the same wave -- and the two
+// waves of a SIMD issuing at different points of the step: no difference, 1013-1018 TFLOP/s either way.)
+template <int KW, int DP>
+struct RingSched {
+    static constexpr int last = KW - 1 - DP;
+    static constexpr int a_cnt(int kx) { return kx <= last ? RG_AV / (last + 1) + (kx < RG_AV % (last + 1) ? 1 : 0) : 0; }
+    static constexpr int a_first(int kx) { int n = 0; for (int k = 0; k < kx; ++k) n += a_cnt(k); return n; }
+    // loads this thread may still have in flight after the wait at tap step kx: those issued at the DP-1 previous steps
+    static constexpr int wait_n(int kx, int bv) {
+        int n = 0;
+        for (int i = 1; i <= DP - 1; ++i) n += bv + a_cnt(((kx - i) % KW + KW) % KW);
+        return n;
+    }
+};
+
+template <int N> __device__ __forceinline__ void rg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+typedef __attribute__((address_space(3))) void* rg_lds_ptr;
+
+// The kernel body is compiled in the DEVICE pass only: the host pass of hipcc needs the kernel's stub, not its body, and it
+// gives up on the stub without a diagnostic when the body uses the LDS-DMA builtin inside nested lambdas (ROCm 7.2).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RG_DEVICE_BODY 1
+#else
+#define RG_DEVICE_BODY 0
+#endif
+
+template <int BN, int KW, int DPO = 0>
+__global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
+#if RG_DEVICE_BODY
+    constexpr int BM = RG_BM;
+    constexpr int NSLOT = BN == 64 ? 8 : 4, TILE_B = BN * 128;
+    constexpr int DPA = NSLOT - 2 < KW - 1 ? NSLOT - 2 : KW - 1;
+    constexpr int DPD = DPA < 4 ? DPA : 4;
+    constexpr int DP = DPO ? (DPO < DPA ? DPO : DPA) : DPD;  // prefetch distance in tap steps (>= 1); DPO: measurement override
+    constexpr int BV = BN / 64;                              // B pieces per wave and step
+    constexpr int NG = BN == 64 ? 2 : 4;                     // 16-channel k-substeps per wave and step
+    using S = RingSched<KW, DP>;
+    static_assert(DP >= 1 && S::last >= 0, "schedule");
+    // LDS map: [A buffer 0 | weight ring | A buffer 1 | two table sets].  The next tile's prologue lands in A buffer 0 and ring
+    // slots 0 .. DP; what is behind them (64 KB: the last ring slots and A buffer 1) is the epilogue's scratch meanwhile.
+    constexpr int A0 = 0, B0 = RG_ABYTES, A1 = B0 + NSLOT * TILE_B, TAB0 = A1 + RG_ABYTES;
+    constexpr int SC0 = B0 + (DP + 1) * TILE_B;              // epilogue scratch: [SC0, TAB0)
+    constexpr int TABN = BM + RG_KMAX * RG_NRMAX + RG_NRMAX + 1 + RG_NRMAX + 3;     // ints per table set (392)
+    static_assert(TAB0 - SC0 >= 34 * 1024 && TABN * 4 <= 1600, "LDS map");
+    // ONE shared object: the compiler must see a single LDS array beside the LDS-DMA instructions
+    __shared__ __attribute__((aligned(16))) unsigned char sm[TAB0 + 2 * 1600 + 64];
+    int* const wirow = reinterpret_cast<int*>(sm + TAB0 + 2 * 1600);      // [RG_KMAX] weight index of the first tap of each filter row
+    auto tab = [&](int b) { return reinterpret_cast<int*>(sm + TAB0 + b * 1600); };
+    // a table set: row_out[256] output pixel index or -1 | rowoff[RG_KMAX][RG_NRMAX] byte offset of input row or -1 |
+    //              rbase[RG_NRMAX + 1] first patch position of each touched image row | rxlo[RG_NRMAX] first output column of
+    //              the tile in that row | {nrows, b_first}
+    constexpr int T_ROWOFF = BM, T_RBASE = T_ROWOFF + RG_KMAX * RG_NRMAX, T_RXLO = T_RBASE + RG_NRMAX + 1, T_MISC = T_RXLO + RG_NRMAX;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wz = wave >> 2;
+    const IgemmPhase ph = p.ph[0];
+    const int Wo = ph.Wo, Ho = ph.Ho;
+    const int M = p.B * Ho * Wo;
+    const int ntap = ph.tap_end - ph.tap_begin;
+    const int kh = ntap / KW;
+    // taps of a filter row are consecutive in the weight tensor and in dx (ring_kw() checked it): ascending dx for a forward
+    // convolution, descending for a data gradient -- no per-tap table is read inside the loop (a kernarg table indexed at run
+    // time becomes a vector-memory load, whose wait would drain the LDS-DMA pipeline)
+    const int dx_first = p.tdx[ph.tap_begin], dx_last = p.tdx[ph.tap_begin + KW - 1];
+    const int dxmin = min(dx_first, dx_last);
+    const bool dx_up = dx_last >= dx_first;
+    const int nchunks = p.Cred / 64;
+    const int nstage = (p.kc & 1) ? 0 : kh * nchunks;   // (filter row, channel slab); knob bit 0: skip the loop (what a tile costs outside it)
+    const int tap2 = p.w_tap_stride * 2;
+
+    // ---- this workgroup's tiles.  Workgroups b, b + 8, ... share an XCD (its L2): an XCD owns a contiguous band of M-tiles
+    // (neighbouring tiles re-read each other's halo rows), walked by its workgroups side by side ----
+    const int bid = blockIdx.x, xcd = bid & 7, wg_in_xcd = bid >> 3, wgs_per_xcd = (int)gridDim.x >> 3;
+    const int per_xcd = (p.grid_m + 7) >> 3;
+    const int units_xcd = per_xcd * p.grid_n;                // (M-tile, N-tile) units of this XCD's band, N-tiles adjacent
+    auto unit_mt = [&](int q) { return xcd * per_xcd + q / p.grid_n; };
+
+    // tables of the tile with first pixel m0 into set b (every thread takes part; the caller orders them with a barrier)
+    auto setup_tables = [&](int b, int m0) {
+        int* t = tab(b);
+        const int mlast = min(m0 + BM, M) - 1;
+        const int row0 = m0 / Wo, nrows = mlast / Wo - row0 + 1;
+        const int b_first = row0 / Ho;
+        if (tid < BM) {
+            const int m = m0 + tid;
+            int v = -1;
+            if (m < M) {
+                const int ox = m % Wo, tt = m / Wo, oy = tt % Ho, b_ = tt / Ho;
+                v = (b_ * p.Hy + oy * p.osy + ph.oy0) * p.Wy + ox * p.osx + ph.ox0;
+            }
+            t[tid] = v;
+        }
+        if (tid <= nrows) {
+            const int xlo0 = m0 - row0 * Wo;
+            const int before = tid == 0 ? 0 : (Wo - xlo0) + (tid - 1) * Wo;
+            t[T_RBASE + tid] = (tid == nrows ? min(BM, M - m0) : before) + tid * (KW - 1);
+            if (tid < nrows) t[T_RXLO + tid] = tid == 0 ? xlo0 : 0;
+        }
+        if (tid == 511) { t[T_MISC] = nrows; t[T_MISC + 1] = b_first; }
+        if (tid >= 256 && tid < 256 + kh * RG_NRMAX) {
+            const int i = tid - 256;
+            const int ky = i / RG_NRMAX, j = i - ky * RG_NRMAX;
+            int off = -1;
+            if (j < nrows) {
+                const int tt = row0 + j, oy = tt % Ho, b_ = tt / Ho;
+                int iy = oy * p.stride + p.tdy[ph.tap_begin + ky * KW];
+                if (p.pad_mode == 1) iy = reflect_idx(iy, p.Hi);
+                if ((unsigned)iy < (unsigned)p.Hi) off = (((b_ - b_first) * p.Hi + iy) * p.Wi) * p.ldx1 * 2;
+            }
+            t[T_ROWOFF + i] = off;
+        }
+    };
+
+    // ---- per-tile state ----
+    const unsigned OOB = 0xFFFFFF00u;
+    constexpr int NA = RG_AV, NB = BV;
+    unsigned pk[NA];             // patch piece e of this wave = piece e * 8 + wave of the stage's 40 (8 positions x 8 chunks): per-lane
+                                 // column offset, with the image-row index j of the position in its low 4 bits (the offset is a multiple of 16)
+    unsigned boff[NB];           // weight-tile piece e of this wave = piece e * 8 + wave of the tile's 8 BV (8 rows x 8 chunks)
+    unsigned a_vo[NA];           // per-lane source offsets of the patch pieces of one stage
+    __amdgpu_buffer_rsrc_t rs_x;
+    // (p.kc carries measurement knobs for this kernel: bit 1 / bit 2 give the weight / activation descriptor zero records, so
+    //  the range check drops every LDS-DMA through it while the instruction stream, the waits and the barriers stay: what the
+    //  loop costs without that operand's traffic.  Timing only -- the results are wrong.)
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (p.kc & 2) ? 0 : (int)p.w_bytes, 0x00020000);
+
+    auto tile_dma_state = [&](int b, int n0) {      // pk / boff / the activation descriptor of the tile whose tables are set b
+        const int* t = tab(b);
+        const int nrows = __builtin_amdgcn_readfirstlane(t[T_MISC]), b_first = __builtin_amdgcn_readfirstlane(t[T_MISC + 1]);
+        const int npatch = t[T_RBASE + nrows];
+#pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            const int q = (e * 8 + wave) * 8 + (lane >> 3);
+            int j = 0;
+            for (int jj = 1; jj < nrows; ++jj) j += (q >= t[T_RBASE + jj]) ? 1 : 0;
+            int ix = t[T_RXLO + j] + dxmin + (q - t[T_RBASE + j]);
+            if (p.pad_mode == 1) ix = reflect_idx(ix, p.Wi);
+            const bool ok = q < npatch && (unsigned)ix < (unsigned)p.Wi;
+            const unsigned lc = (unsigned)((lane & 7) ^ ((q >> 1) & 7));              // logical chunk stored at this physical slot
+            pk[e] = ok ? ((unsigned)(ix * p.ldx1) * 2u + lc * 16u) | (unsigned)j : OOB;
+        }
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            const int n = (e * 8 + wave) * 8 + (lane >> 3);
+            const unsigned lc = (unsigned)((lane & 7) ^ ((n >> 1) & 7));
+            boff[e] = (n0 + n) < p.N ? (unsigned)((n0 + n) * p.Cred) * 2u + lc * 16u : OOB;
+        }
+        // (descriptor words through readfirstlane: a descriptor the compiler cannot PROVE wave-uniform gets a waterfall loop
+        //  around every LDS-DMA instruction)
+        const unsigned long long img1 = (unsigned long long)p.Hi * p.Wi * p.ldx1 * 2ull * b_first;
+        const unsigned long long rem1 = p.x_bytes - img1, cap = 0xFF000000ull;
+        const unsigned long long xb = reinterpret_cast<unsigned long long>(p.x) + img1;
+        const unsigned long long xbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+        const int xlen = __builtin_amdgcn_readfirstlane((p.kc & 4) ? 0 : (int)(unsigned)(rem1 < cap ? rem1 : cap));
+        rs_x = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(xbu), 0, xlen, 0x00020000);
+    };
+    auto a_offsets = [&](int b, int ky) {                    // (read from the row table once per stage, not under the MFMAs)
+        const int* t = tab(b);
+#pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            const int ro = t[T_ROWOFF + ky * RG_NRMAX + (int)(pk[e] & 15u)];
+            a_vo[e] = (ro >= 0 && pk[e] != OOB) ? (unsigned)ro + (pk[e] & ~15u) : OOB;
+        }
+    };
+    auto dma_a = [&](int par, int cc, int e) {               // piece e of the patch whose offsets are in a_vo -> A buffer `par`
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (rg_lds_ptr)(sm + (par ? A1 : A0) + (e * 8 + wave) * 1024), 16, a_vo[e], cc * 128, 0, 0);
+    };
+    auto dma_b = [&](int v, int soff) {                      // this wave's pieces of the weight tile at scalar offset soff -> ring slot v % NSLOT
+        const int slot = v & (NSLOT - 1);
+#pragma unroll
+        for (int e = 0; e < NB; ++e)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (rg_lds_ptr)(sm + B0 + slot * TILE_B + (e * 8 + wave) * 1024), 16, boff[e], soff, 0, 0);
+    };
+    // The weight tile of tap step v = stage * KW + kx lies at scalar offset soff(stage) + kx * tap2: with KW unrolled, the
+    // tile that step (stage, kx) prefetches -- step v + 1 + DP -- is tap (kx + 1 + DP) % KW of this stage or of the next one
+    // (DP < KW), so two scalars per stage replace all per-step bookkeeping.  Past the last step the "next" stage is the last
+    // stage again: harmless reloads into free slots keep the number of loads per step -- what the counted waits rely on -- fixed.
+    auto stage_soff = [&](int ky_, int cc_) { return __builtin_amdgcn_readfirstlane(wirow[ky_]) * tap2 + cc_ * 128; };
+    int ky_n = 0, cc_n = 0, soff_c = 0, soff_n = 0;
+    auto issue_prologue = [&](int b) {                       // stage 0's patch and the weight tiles of steps 0 .. DP of the tile in set b
+        ky_n = 0; cc_n = 0;
+        if (nstage > 1) { if (++cc_n == nchunks) { cc_n = 0; ++ky_n; } }
+        soff_c = stage_soff(0, 0); soff_n = stage_soff(ky_n, cc_n);
+        a_offsets(b, 0);
+#pragma unroll
+        for (int e = 0; e < NA; ++e) dma_a(0, 0, e);
+#pragma unroll
+        for (int v = 0; v <= DP; ++v) dma_b(v, (v < KW ? soff_c : soff_n) + (v % KW) * tap2);
+    };
+
+    // ---- fragment addressing ----
+    const unsigned hbit = (unsigned)(lane >> 5) << 6;                 // chunk 4h of the slab: lane half h owns channels [32h, 32h+32)
+    const int ncol0 = BN == 64 ? 0 : wz * 64;                         // first output channel of this wave's column tiles
+    unsigned bfix[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned n = (unsigned)(ncol0 + j * 32 + (lane & 31));
+        bfix[j] = ((n << 7) ^ (((n >> 1) & 7u) << 4)) ^ hbit;
+    }
+    const int g_first = BN == 64 ? 2 * wz : 0;
+    unsigned apos[2];                                // A: pixel r of the tile sits at patch position r + j(r) * (KW - 1) (+ the tap's shift)
+    f32x16 acc[2][2];
+    bf16x8 fa[2][2], fb[2][2];                       // [register set][row tile / column tile]
+    auto load_frags = [&](int set, int par, int kx, int slot, int g) {     // fragments of (A buffer par, tap kx, ring slot, k-substep g)
+        const unsigned sh = (unsigned)(dx_up ? kx : KW - 1 - kx);
+        const unsigned abase = (unsigned)(par ? A1 : A0);
+        const unsigned bbase = (unsigned)(B0 + slot * TILE_B);
+        const unsigned gx = (unsigned)(g_first + g) << 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned q = apos[i] + sh;
+            const unsigned a = abase + (((q << 7) ^ (((q >> 1) & 7u) << 4)) ^ hbit ^ gx);
+            fa[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(sm + a));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            fb[set][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(sm + bbase + (bfix[j] ^ gx)));
+    };
+
+    // ---- first tile ----
+    int q = wg_in_xcd;
+    if (q >= units_xcd || unit_mt(q) >= p.grid_m) return;
+    if (tid < kh) wirow[tid] = p.twi[ph.tap_begin + tid * KW];
+    setup_tables(0, unit_mt(q) * BM);
+    __syncthreads();
+    tile_dma_state(0, (q % p.grid_n) * BN);
+    issue_prologue(0);
+    int tb = 0;
+
+    for (;;) {
+        const int mt = unit_mt(q), nt = q % p.grid_n;
+        const int m0 = mt * BM, n0 = nt * BN;
+        const int qn = q + wgs_per_xcd;
+        const bool has_next = qn < units_xcd && unit_mt(qn) < p.grid_m;
+        const int* const t = tab(tb);
+        {
+            const int nrows_ = t[T_MISC];
+            (void)nrows_;
+            const int mlast = min(m0 + BM, M) - 1;
+            const int row0 = m0 / Wo;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wm * 64 + i * 32 + (lane & 31);
+                const int m = min(m0 + r, mlast);
+                apos[i] = (unsigned)(min(r, mlast - m0) + (m / Wo - row0) * (KW - 1));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if (has_next) setup_tables(tb ^ 1, unit_mt(qn) * BM);       // (the other set: ordered by the loop's barriers before anyone reads it)
+        rg_wait_vm<0>();                                            // the prologue pieces (and the previous epilogue's stores)
+        __builtin_amdgcn_s_barrier();
+        if (nstage > 0) load_frags(0, 0, 0, 0, 0);
+
+        for (int stage = 0; stage < nstage; ++stage) {
+            const int par = stage & 1;
+            const int ubase = stage * KW;
+            a_offsets(tb, ky_n);                               // (ky_n, cc_n): the NEXT stage; the last stage reloads itself into the idle buffer
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                // pieces issued DP or more steps ago have landed (this thread's); the barrier makes everyone's visible and says
+                // that every wave has finished the LDS reads of step u-1
+                switch (kx) {
+                    case 0: rg_wait_vm<S::wait_n(0, BV)>(); break;
+                    case 1: rg_wait_vm<S::wait_n(1, BV)>(); break;
+                    case 2: rg_wait_vm<S::wait_n(2, BV)>(); break;
+                    case 3: rg_wait_vm<S::wait_n(3 % KW, BV)>(); break;
+                    case 4: rg_wait_vm<S::wait_n(4 % KW, BV)>(); break;
+                    case 5: rg_wait_vm<S::wait_n(5 % KW, BV)>(); break;
+                    case 6: rg_wait_vm<S::wait_n(6 % KW, BV)>(); break;
+                    case 7: rg_wait_vm<S::wait_n(7 % KW, BV)>(); break;
+                    default: rg_wait_vm<S::wait_n(8 % KW, BV)>(); break;
+                }
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int cur = g & 1;
+                    // read-ahead: the next k-substep's fragments -- of the NEXT step under this step's last MFMAs
+                    if (g + 1 < NG) load_frags(cur ^ 1, par, kx, (ubase + kx) & (NSLOT - 1), g + 1);
+                    else if (stage + 1 < nstage || kx + 1 < KW)
+                        load_frags(cur ^ 1, kx + 1 < KW ? par : par ^ 1, kx + 1 < KW ? kx + 1 : 0, (ubase + kx + 1) & (NSLOT - 1), 0);
+                    // (pin the order: left alone the scheduler sinks these reads behind three of the four MFMAs below to save
+                    //  registers, and every group then waits for reads issued one MFMA earlier)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+                    if (g == 0) {
+                        // this step's LDS-DMA issue sits UNDER the first MFMAs (whose operands the read-ahead already delivered):
+                        // straight after the barrier the matrix pipe would idle while every wave issues its pieces
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int vb = kx + 1 + DP;                // compile-time after unrolling
+                        dma_b(ubase + vb, (vb < KW ? soff_c : soff_n) + (vb % KW) * tap2);
+#pragma unroll
+                        for (int e = 0; e < NA; ++e)
+                            if (e >= S::a_first(kx) && e < S::a_first(kx) + S::a_cnt(kx)) dma_a(par ^ 1, cc_n, e);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            soff_c = soff_n;
+            if (stage + 2 < nstage) { if (++cc_n == nchunks) { cc_n = 0; ++ky_n; } }
+            soff_n = stage_soff(ky_n, cc_n);
+        }
+        rg_wait_vm<0>();
+        __syncthreads();                             // every DMA landed, every fragment read done: LDS is free; the next tile's tables are visible
+
+        // ---- the next tile's prologue goes out before this tile's epilogue ----
+        if (has_next) {
+            tile_dma_state(tb ^ 1, (qn % p.grid_n) * BN);
+            issue_prologue(tb ^ 1);
+        }
+
+        // ---- epilogue (scratch: [SC0, TAB0), behind the LDS the next prologue lands in) ----
+        if (!(p.kc & 8)) {                           // knob bit 3: no epilogue (timing only)
+        // (lane_e: the epilogue's lane-dependent addresses are invariant across tiles, and hoisted out of the tile loop they would
+        //  occupy ~60 registers throughout the tap loop -- an opaque copy of the lane index keeps them inside the epilogue)
+        int lane_e = lane, tid_e = tid;
+        asm volatile("" : "+v"(lane_e), "+v"(tid_e));
+        const int col_l = lane_e & 31, rsh = 4 * (lane_e >> 5);
+        float* const sc = reinterpret_cast<float*>(sm + SC0);
+        constexpr int NI = BN == 64 ? 1 : 2;         // row tiles this wave finalises
+        if constexpr (BN == 64) {
+            // the two halves of the reduction meet: wave (wm, wz) hands row tile 1-wz to its partner and finalises row tile wz
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sc[wave * 2048 + (j * 16 + r) * 64 + lane_e] = wz == 0 ? acc[1][j][r] : acc[0][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float o = sc[(wave ^ 4) * 2048 + (j * 16 + r) * 64 + lane_e];
+                    if (wz == 0) acc[0][j][r] += o; else acc[0][j][r] = acc[1][j][r] + o;
+                }
+            __syncthreads();
+        }
+        // row tile ii of this wave covers tile rows rbeg(ii) + rowmap(r, lane_e)
+        auto rbeg = [&](int ii) { return BN == 64 ? wm * 64 + wz * 32 : wm * 64 + ii * 32; };
+        if (p.stats) {
+            float* red = sc;                         // [8 waves][64 columns][2]
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbeg(ii) + (r & 3) + 8 * (r >> 2) + rsh;
+                        const float v = t[row] >= 0 ? acc[ii][j][r] : 0.f;
+                        s1 += v; s2 += v * v;
+                    }
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lane_e < 32) {
+                    red[(wave * 64 + j * 32 + lane_e) * 2 + 0] = s1;
+                    red[(wave * 64 + j * 32 + lane_e) * 2 + 1] = s2;
+                }
+            }
+            __syncthreads();
+            if (tid_e < BN && n0 + tid_e < p.N) {
+                // columns [0, 64) of the tile are held by all eight waves (BN = 64) or by waves wz = 0 (BN = 128); [64, 128) by wz = 1
+                float s1 = 0.f, s2 = 0.f;
+                const int c = tid_e & 63, z = tid_e >> 6;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    if (BN == 128 && (w >> 2) != z) continue;
+                    s1 += red[(w * 64 + c) * 2];
+                    s2 += red[(w * 64 + c) * 2 + 1];
+                }
+                p.stats[((size_t)mt * 2 + 0) * p.N + n0 + tid_e] = s1;
+                p.stats[((size_t)mt * 2 + 1) * p.N + n0 + tid_e] = s2;
+            }
+            __syncthreads();
+        }
+        // output: 8192 values per round go through an fp32 LDS tile [pixel][BN + 4] and leave as whole 128-byte lines
+        // (16 bytes = 8 channels per lane_e); the eval-BN affine / ReLU are applied on the way in, the residual is read 16
+        // bytes at a time and added (in fp32, before the one rounding to bf16) on the way out
+        const bool has_affine = p.ep_scale != nullptr;
+        float es[2], et[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + ncol0 + j * 32 + col_l;
+            es[j] = (has_affine && n < p.N) ? p.ep_scale[n] : 1.f;
+            et[j] = (has_affine && n < p.N) ? p.ep_shift[n] : 0.f;
+        }
+        constexpr int RS = BN + 4;                   // row stride of the transposition tile in floats
+        constexpr int PXR = 8192 / BN;               // pixels per round: 128 (BN = 64: waves wm = 2 rr, 2 rr + 1) or 64 (BN = 128: waves wm = rr)
+        constexpr int NRND = BM / PXR;
+        constexpr int TPP = BN / 8;                  // threads per pixel on the way out
+        unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
+        const unsigned short* ad = reinterpret_cast<const unsigned short*>(p.addsrc);
+#pragma unroll 1
+        for (int rr = 0; rr < NRND; ++rr) {
+            if ((BN == 64 ? (wm >> 1) : wm) == rr) {
+#pragma unroll
+                for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbeg(ii) + (r & 3) + 8 * (r >> 2) + rsh - rr * PXR;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            float v = acc[ii][j][r];
+                            if (has_affine) v = v * es[j] + et[j];
+                            if (p.act & GDN_ACT_RELU) v = fmaxf(v, 0.f);
+                            sc[row * RS + ncol0 + j * 32 + col_l] = v;
+                        }
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < PXR * TPP / 512; ++ps) {
+                const int px = ps * (512 / TPP) + tid_e / TPP, cg = tid_e % TPP;
+                const int op = t[rr * PXR + px];
+                if (op >= 0 && n0 + cg * 8 < p.N) {
+                    f32x4 lo = *reinterpret_cast<const f32x4*>(sc + px * RS + cg * 8);
+                    f32x4 hi = *reinterpret_cast<const f32x4*>(sc + px * RS + cg * 8 + 4);
+                    if (ad) {
+                        f32x4 alo, ahi;
+                        ld8_any(ad, (size_t)op * p.ld_add + n0 + cg * 8, 1, alo, ahi);
+                        lo += alo; hi += ahi;
+                    }
+                    if (p.act & GDN_ACT_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { lo[e] = tanhf(lo[e]); hi[e] = tanhf(hi[e]); }
+                    }
+                    st8_any(yo, (size_t)op * p.ldy + n0 + cg * 8, lo, hi, 1);
+                }
+            }
+            __syncthreads();
+        }
+        }
+        if (!has_next) break;
+        q = qn;
+        tb ^= 1;
+    }
+#endif  // RG_DEVICE_BODY
+}

@@ -61,7 +61,8 @@ def test_conv_bf16_fwd_dgrad(gpu, case):
     yr = y_ref.detach().double()
     close(st[:, 0, :].double().sum(0).cpu(), yr.sum((0, 2, 3)), rtol=1e-3, atol_scale=1e-3, what=name + " stats sum")
     close(st[:, 1, :].double().sum(0).cpu(), (yr * yr).sum((0, 2, 3)), what=name + " stats sumsq")
-    for cfg in (1, 2, 3, 8, 9):       # 8, 9: row-patch kernel where the geometry allows it (else the automatic choice)
+    # 8, 9: row-patch kernel, 10, 11: LDS-DMA ring kernel (round 4) -- where the geometry allows it, else the automatic choice
+    for cfg in (1, 2, 3, 8, 9, 10, 11):
         yc, stc = op.fwd(xd, wd, stats=True, tile_cfg=cfg | 0x800)
         close(nchw(yc.float()), y_ref, rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=name + " fwd cfg%d" % cfg)
         close(stc[:, 0, :].double().sum(0).cpu(), yr.sum((0, 2, 3)), rtol=1e-3, atol_scale=1e-3, what=name + " stats sum cfg%d" % cfg)
@@ -75,7 +76,7 @@ def test_conv_bf16_fwd_dgrad(gpu, case):
     add = r16(torch.randn(B, H, W, ci, generator=torch.Generator().manual_seed(2)))
     dx2 = op.dgrad(gyd, wt, (H, W), addsrc=add.to(gpu).bfloat16())
     close(nchw(dx2.float()), x.grad + nchw(add), rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=name + " dgrad+addsrc")
-    for cfg in (8, 9):
+    for cfg in (1, 8, 9, 10, 11):
         dx3 = op.dgrad(gyd, wt, (H, W), addsrc=add.to(gpu).bfloat16(), tile_cfg=cfg)
         close(nchw(dx3.float()), x.grad + nchw(add), rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=name + " dgrad cfg%d" % cfg)
     # weight gradient: bf16 operands, fp32 accumulation and fp32 result -> only the summation order differs

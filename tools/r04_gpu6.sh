@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_hip_bf16.py -x -q 2>&1 | tail -8 > gpurun_out/r04_t6.log
+for cfg in "rtod_bf16:--mode RtoD --dtype bf16" "dtod_bf16:--dtype bf16"; do
+  tag=${cfg%%:*}; a=${cfg#*:}
+  bash tools/prof_step.sh r04b_$tag $a > gpurun_out/r04b_prof_$tag.log 2>&1
+  echo "$tag rc=$?" >> gpurun_out/r04_t6.log
+  head -c 300 gpurun_out/prof_step_r04b_$tag/bench.json >> gpurun_out/r04_t6.log; echo >> gpurun_out/r04_t6.log
+done
+cat gpurun_out/r04_t6.log
+cat gpurun_out/prof_step_r04b_rtod_bf16/step_summary.txt
+head -30 gpurun_out/prof_step_r04b_rtod_bf16/by_kernel_and_grid.txt

@@ -42,8 +42,9 @@ struct IgemmParams {
     int kc;                                // reduction slab per k-step (32 or 64)
     int bf16;                              // 1: x/x2/w/y/addsrc hold bf16 (fp32 accumulate, fp32 stats/partials)
     int ksplit;                            // split-K over taps (grid.z); >1: raw partials go to `part`
-    float* part;                           // [ksplit][npix_out][N]
+    float* part;                           // [ksplit][npix_out][N]  (conv_ring_bf16: the tail ranges' slabs [parts (x2)][tail pixels][N])
     long long npix_out;
+    int ring_main, ring_sp;                // conv_ring_bf16 with ksplit = parts > 1: units of the full rounds, stages per tail range
     IgemmPhase ph[MAX_PHASE];
     short tdy[MAX_TAPS], tdx[MAX_TAPS], twi[MAX_TAPS];
 };
@@ -928,7 +929,15 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
         if (ty < PY) {
             for (long long pix = p0 + ty; pix < p1; pix += PY) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)pix * N + c);
-                for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + z * zs + (size_t)pix * N + c);
+                int z = 1;
+                for (; z + 8 <= ksplit; z += 8) {        // eight slabs in flight, summed in slab order (same bits as one at a time)
+                    f32x4 u[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) u[e] = *reinterpret_cast<const f32x4*>(part + (z + e) * zs + (size_t)pix * N + c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v += u[e];
+                }
+                for (; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + z * zs + (size_t)pix * N + c);
                 s1 += v;
                 s2 += v * v;
                 if (ep_scale) v = v * *reinterpret_cast<const f32x4*>(ep_scale + c) + *reinterpret_cast<const f32x4*>(ep_shift + c);
@@ -966,6 +975,9 @@ namespace {
 
 // CU count of the current device (a device attribute, read once per process: 256 on MI355X)
 int gdn_num_cus() {
+    // GDN_RING_CUS=<n> (test hook, read per call): plan the persistent kernels as for a chip with n CUs, so that small test
+    // shapes reach the multi-round / tail-split paths
+    if (const char* e = getenv("GDN_RING_CUS")) { const int v = atoi(e); if (v >= 8) return v / 8 * 8; }
     static const int n = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
@@ -1032,6 +1044,40 @@ int ring_kw(const IgemmParams& P) {
 }
 bool ring_ok(const IgemmParams& P, int bn) { return ring_kw(P) != 0 && P.N % bn == 0 && !P.x2; }
 
+// How the persistent workgroups of conv_ring_bf16 cover the (M-tile, N-tile) units: G workgroups (one per CU), `main` units in
+// full rounds, and -- when the last round would be a small fraction of one (B = 20: 65/64 of a power of two tiles at every
+// level) -- its `tail` units cut into `parts` stage ranges of `sp` stages, one per workgroup, summed by splitk_combine_kernel.
+struct RingPlan { int G, grid_m, grid_n, main_units, tail_units, parts, sp, slabs, main_mtiles; int64_t tail_px; };
+RingPlan ring_plan(const IgemmParams& P, int bn) {
+    RingPlan r{};
+    const IgemmPhase& ph = P.ph[0];
+    const int64_t M = (int64_t)P.B * ph.Ho * ph.Wo;
+    r.grid_m = (int)cdiv64(M, RG_BM); r.grid_n = P.N / bn;
+    const int units = r.grid_m * r.grid_n, units_xcd = cdiv(r.grid_m, 8) * r.grid_n, cus_xcd = gdn_num_cus() / 8 > 0 ? gdn_num_cus() / 8 : 32;
+    r.G = 8 * (units_xcd < cus_xcd ? units_xcd : cus_xcd);
+    const int kw = ring_kw(P), nstage = kw ? (ph.tap_end - ph.tap_begin) / kw * (P.Cred / 64) : 0;
+    const int rounds = units / r.G, tail = units % r.G;
+    r.main_units = units; r.parts = 1; r.sp = nstage; r.slabs = 0; r.main_mtiles = r.grid_m; r.tail_px = 0;
+    const char* e = getenv("GDN_RING_TAIL");                           // measurement: 0 keeps the last round whole
+    if (e && e[0] == '0') return r;
+    if (rounds >= 1 && tail > 0 && 4 * tail <= r.G && nstage >= 2 && r.G % r.grid_n == 0) {
+        int parts = r.G / tail < nstage ? r.G / tail : nstage;
+        if (parts > 8) parts = 8;                 // (each range is one fp32 slab -- two with the 256 x 64 form -- that the combine pass reads back)
+        r.sp = cdiv(nstage, parts);
+        r.parts = cdiv(nstage, r.sp);
+        r.main_units = rounds * r.G; r.tail_units = tail;
+        r.main_mtiles = r.main_units / r.grid_n;
+        r.tail_px = M - (int64_t)r.main_mtiles * RG_BM;
+        r.slabs = r.parts * (bn == 64 ? 2 : 1);
+    }
+    return r;
+}
+size_t ring_ws_bytes(const IgemmParams& P, int cfg) {
+    if (cfg < 10) return 0;
+    const RingPlan r = ring_plan(P, cfg == 10 ? 64 : 128);
+    return r.parts > 1 ? (size_t)r.slabs * r.tail_px * P.N * sizeof(float) : 0;
+}
+
 // bf16: the MFMA is 16x faster, so tiles must be large enough to amortise the staging of a k-step.
 int pick_cfg_bf16(const IgemmParams& P, int64_t M, int N, int forced) {
     const bool rp = rowpatch_ok(P);
@@ -1045,13 +1091,11 @@ int pick_cfg_bf16(const IgemmParams& P, int64_t M, int N, int forced) {
     // by more (coalesced epilogue).  256 x 128 tiles where they still fill the chip's 256 persistent workgroups twice, else
     // 256 x 64 (more, smaller units for the tail: B = 20 gives 65/64 of a power of two tiles at every level).
     if (forced == 0 && ring_kw(P) != 0 && !P.x2 && N % 64 == 0) {
-        if (N % 128 == 0 && cdiv64(M, RG_BM) * (N / 128) >= 1024) return 11;
+        // 256 x 128 tiles (0.75 fragment reads per MFMA instead of 1, no exchange of reduction halves) wherever they give every
+        // CU at least one unit; else 256 x 64 (8x26 level: 68 units of 256 x 128 for 256 CUs)
+        if (N % 128 == 0 && cdiv64(M, RG_BM) * (N / 128) >= gdn_num_cus()) return 11;
         return 10;
     }
-    // measured (profiles/r01_tune_conv_bf16_rowpatch.txt, _v5.txt): the 256x64 row-patch kernel at three workgroups per
-    // CU wins on the layers with <= 128 output channels (9x9 64ch: 1000 vs 640, 7x7 128ch: 900 vs 800 TFLOP/s); with 256+
-    // output channels the 128x128 tap-major tile re-uses each activation tile more and stays ahead; the 256x128 row-patch
-    // form (cfg 8, tuning only) never wins
     if (rp && N <= 128 && cdiv64(M, RP_BM) * cdiv(N, 64) >= 448) return 9;
     if (N <= 64) return 2;
     return cdiv64(M, 128) * cdiv(N, 128) >= 384 ? 1 : 3;
@@ -1198,14 +1242,26 @@ int launch_igemm(IgemmParams& P, int cfg, hipStream_t st, int ksplit = 1, void* 
             case 9: hipLaunchKernelGGL((conv_rowpatch_bf16<64, 4, 1>), dim3(gm_pad * P.grid_n), dim3(256), 0, st, P); break;
             case 10: case 11: {
                 // persistent workgroups, one per CU: every XCD (workgroups b, b + 8, ...) walks its band of tiles
-                const int units_xcd = cdiv(P.grid_m, 8) * P.grid_n, cus_xcd = gdn_num_cus() / 8 > 0 ? gdn_num_cus() / 8 : 32;
-                const dim3 g1(8 * (units_xcd < cus_xcd ? units_xcd : cus_xcd)), b1(512);
+                const RingPlan rp = ring_plan(P, cfg == 10 ? 64 : 128);
+                const dim3 g1(rp.G), b1(512);
+                P.ksplit = rp.parts; P.ring_main = rp.main_units; P.ring_sp = rp.sp;
+                if (rp.parts > 1 && !split_ws) return GDN_ERR_WORKSPACE;
 #define GDN_RING(BNV, KWV) hipLaunchKernelGGL((conv_ring_bf16<BNV, KWV>), g1, b1, 0, st, P)
                 const int kw = ring_kw(P);
                 if (cfg == 10) { if (kw == 3) GDN_RING(64, 3); else if (kw == 5) GDN_RING(64, 5); else if (kw == 7) GDN_RING(64, 7); else if (kw == 9) GDN_RING(64, 9); else return GDN_ERR_UNSUPPORTED; }
                 else { if (kw == 3) GDN_RING(128, 3); else if (kw == 5) GDN_RING(128, 5); else if (kw == 7) GDN_RING(128, 7); else if (kw == 9) GDN_RING(128, 9); else return GDN_ERR_UNSUPPORTED; }
 #undef GDN_RING
-                break;
+                if (rp.parts > 1) {
+                    // the tail ranges' slabs -> y / stats for the pixels [main_mtiles * 256, M) (a dense pixel range: ring layers have
+                    // one phase and unit stride, so output pixel index == m)
+                    const int64_t p0 = (int64_t)rp.main_mtiles * RG_BM;
+                    const int blocks = (int)cdiv64(rp.tail_px, SK_ROWS);
+                    hipLaunchKernelGGL(splitk_combine_kernel, dim3(blocks), dim3(256), 0, st, (const float*)P.part, rp.slabs, (long long)rp.tail_px,
+                                       P.N, (void*)((unsigned short*)P.y + p0 * P.ldy), P.ldy,
+                                       P.addsrc ? (const void*)((const unsigned short*)P.addsrc + p0 * P.ld_add) : (const void*)nullptr, P.ld_add,
+                                       P.act, P.stats ? P.stats + (size_t)rp.main_mtiles * 2 * P.N : (float*)nullptr, 1, P.ep_scale, P.ep_shift);
+                }
+                return gdn_launch_status();
             }
             default: return GDN_ERR_BAD_ARG;
         }
@@ -1333,6 +1389,10 @@ extern "C" int64_t gdn_conv_stats_slots(const gdn_conv_geom* g, int32_t tile_cfg
     const bool scalar = (g->Cin % KC_MIN) != 0;
     const int cfg = pick_cfg(P, g->Cout, scalar, tile_cfg);
     if (pick_ksplit(P, cfg, scalar, tile_cfg) > 1) return cdiv64((int64_t)P.B * P.Hy * P.Wy, SK_ROWS);
+    if (cfg >= 10) {
+        const RingPlan rp = ring_plan(P, cfg == 10 ? 64 : 128);
+        if (rp.parts > 1) return rp.main_mtiles + cdiv64(rp.tail_px, SK_ROWS);
+    }
     return (int64_t)P.nphase * cdiv64(max_phase_m(P), kCfg[cfg].bm);
 }
 
@@ -1341,7 +1401,7 @@ extern "C" size_t gdn_conv_fwd_workspace_bytes(const gdn_conv_geom* g, int32_t t
     if (fill_fwd(g, P) != GDN_OK) return 0;
     const bool scalar = (g->Cin % KC_MIN) != 0;
     const int cfg = pick_cfg(P, g->Cout, scalar, tile_cfg);
-    return ksplit_bytes(P, pick_ksplit(P, cfg, scalar, tile_cfg));
+    return ksplit_bytes(P, pick_ksplit(P, cfg, scalar, tile_cfg)) + ring_ws_bytes(P, cfg);
 }
 
 extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const void* xv, int32_t ldx, const void* x2v, int32_t ldx2,
@@ -1390,7 +1450,8 @@ extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const void* xv, int32_t ldx,
     if (cfg >= 10) P.kc = (tile_cfg >> 12) & 15;             // conv_ring_bf16: measurement knobs (0 in production)
     const int ksplit = pick_ksplit(P, cfg, scalar, tile_cfg);
     if (ksplit > 1 && (!workspace || workspace_bytes < ksplit_bytes(P, ksplit))) return GDN_ERR_WORKSPACE;
-    if (ksplit > 1 && ((ldy % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
+    if (ring_ws_bytes(P, cfg) && (!workspace || workspace_bytes < ring_ws_bytes(P, cfg))) return GDN_ERR_WORKSPACE;
+    if ((ksplit > 1 || ring_ws_bytes(P, cfg)) && ((ldy % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
     return launch_igemm(P, cfg, (hipStream_t)stream, ksplit, workspace);
 }
 
@@ -1428,7 +1489,7 @@ extern "C" size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g, int32_t
     bool fold, scalar;
     if (!fill_dgrad(g, P, fold, scalar)) return 0;
     const int cfg = pick_cfg(P, P.N, scalar, tile_cfg);
-    return (fold ? fold_bytes(g) : 0) + ksplit_bytes(P, pick_ksplit(P, cfg, scalar, tile_cfg));
+    return (fold ? fold_bytes(g) : 0) + ksplit_bytes(P, pick_ksplit(P, cfg, scalar, tile_cfg)) + ring_ws_bytes(P, cfg);
 }
 
 extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t ldy, const void* wtv, void* dxv,
@@ -1457,14 +1518,15 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t l
     if (fold && (g->Cin % 4) && bf) return GDN_ERR_UNSUPPORTED;
     const int cfg = pick_cfg(P, P.N, scalar, tile_cfg);
     const int ksplit = pick_ksplit(P, cfg, scalar, tile_cfg);
-    const size_t fb = fold ? fold_bytes(g) : 0, need = fb + ksplit_bytes(P, ksplit);
+    const size_t rb = ring_ws_bytes(P, cfg);
+    const size_t fb = fold ? fold_bytes(g) : 0, need = fb + ksplit_bytes(P, ksplit) + rb;
     if (need && (!workspace || workspace_bytes < need)) return GDN_ERR_WORKSPACE;
     if (fold) { P.y = (float*)workspace; P.ldy = g->Cin; P.addsrc = nullptr; P.ld_add = 0; }
     else { P.y = dx; P.ldy = ldx; P.addsrc = addsrc; P.ld_add = ld_add; }
-    if (ksplit > 1 && ((P.ldy % 4) || (P.addsrc && (P.ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
+    if ((ksplit > 1 || rb) && ((P.ldy % 4) || (P.addsrc && (P.ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
     P.kc = (!scalar && g->Cout % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
     if (cfg >= 10) P.kc = (tile_cfg >> 12) & 15;
-    int rc = launch_igemm(P, cfg, st, ksplit, ksplit > 1 ? (char*)workspace + fb : nullptr);
+    int rc = launch_igemm(P, cfg, st, ksplit, (ksplit > 1 || rb) ? (char*)workspace + fb : nullptr);
     if (rc != GDN_OK) return rc;
     if (fold && (g->Cin % 4)) {
         const int64_t total = (int64_t)g->B * g->H * g->W * g->Cin;

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
     //              the tile in that row | {nrows, b_first}
     constexpr int T_ROWOFF = BM, T_RBASE = T_ROWOFF + RG_KMAX * RG_NRMAX, T_RXLO = T_RBASE + RG_NRMAX + 1, T_MISC = T_RXLO + RG_NRMAX;
 
+    const int knobs = p.kc;                                  // measurement knobs (0 in production)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wz = wave >> 2;
@@ -110,15 +111,40 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
     const int dxmin = min(dx_first, dx_last);
     const bool dx_up = dx_last >= dx_first;
     const int nchunks = p.Cred / 64;
-    const int nstage = (p.kc & 1) ? 0 : kh * nchunks;   // (filter row, channel slab); knob bit 0: skip the loop (what a tile costs outside it)
+    // (filter row, channel slab) stages; knob bit 0: skip the loop, bit 3: a third of it (what a tile costs outside / per stage)
+    const int nstage = (knobs & 1) ? 0 : (knobs & 8) ? kh * nchunks / 3 : kh * nchunks;
     const int tap2 = p.w_tap_stride * 2;
 
-    // ---- this workgroup's tiles.  Workgroups b, b + 8, ... share an XCD (its L2): an XCD owns a contiguous band of M-tiles
-    // (neighbouring tiles re-read each other's halo rows), walked by its workgroups side by side ----
+    // ---- this workgroup's work items.  Workgroups b, b + 8, ... share an XCD (its L2): an XCD owns a contiguous band of units
+    // ((M-tile, N-tile), N-tiles adjacent; neighbouring tiles re-read each other's halo rows), walked by its workgroups side by
+    // side.  B = 20 gives 65/64 of a power of two tiles at every level of the pyramid: the last, nearly empty round would cost
+    // a whole tile time.  So when the host planned a split (p.ksplit = parts > 1), the p.ring_main units of the full rounds are
+    // walked as bands and each unit of the last round is cut into `parts` ranges of p.ring_sp stages, one per workgroup, whose
+    // raw fp32 accumulators go to slabs in p.part; splitk_combine_kernel sums them and applies the epilogue for those pixels.
     const int bid = blockIdx.x, xcd = bid & 7, wg_in_xcd = bid >> 3, wgs_per_xcd = (int)gridDim.x >> 3;
+    const int parts = (knobs & 9) ? 1 : p.ksplit;
     const int per_xcd = (p.grid_m + 7) >> 3;
-    const int units_xcd = per_xcd * p.grid_n;                // (M-tile, N-tile) units of this XCD's band, N-tiles adjacent
-    auto unit_mt = [&](int q) { return xcd * per_xcd + q / p.grid_n; };
+    const int units_xcd = parts > 1 ? p.ring_main >> 3 : per_xcd * p.grid_n;
+    const int rounds_main = parts > 1 ? units_xcd / wgs_per_xcd : (units_xcd + wgs_per_xcd - 1) / wgs_per_xcd;
+    const int tail_items = parts > 1 ? (p.grid_m * p.grid_n - p.ring_main) * parts : 0;
+    // item k of this workgroup -> (M-tile, N-tile, stage range, slab index or -1); false: no such item
+    auto get_item = [&](int k, int& mt, int& nt, int& s0, int& s1, int& part) {
+        if (k < rounds_main) {
+            const int q = wg_in_xcd + k * wgs_per_xcd;
+            if (q >= units_xcd) return false;
+            const int u = parts > 1 ? xcd * units_xcd + q : (xcd * per_xcd + q / p.grid_n) * p.grid_n + q % p.grid_n;
+            mt = u / p.grid_n; nt = u % p.grid_n; s0 = 0; s1 = nstage; part = -1;
+            return mt < p.grid_m;
+        }
+        if (k == rounds_main && bid < tail_items) {
+            const int u = p.ring_main + bid / parts;
+            part = bid % parts;
+            mt = u / p.grid_n; nt = u % p.grid_n;
+            s0 = part * p.ring_sp; s1 = min(nstage, s0 + p.ring_sp);
+            return s0 < s1;
+        }
+        return false;
+    };
 
     // tables of the tile with first pixel m0 into set b (every thread takes part; the caller orders them with a barrier)
     auto setup_tables = [&](int b, int m0) {
@@ -167,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
     // (p.kc carries measurement knobs for this kernel: bit 1 / bit 2 give the weight / activation descriptor zero records, so
     //  the range check drops every LDS-DMA through it while the instruction stream, the waits and the barriers stay: what the
     //  loop costs without that operand's traffic.  Timing only -- the results are wrong.)
-    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (p.kc & 2) ? 0 : (int)p.w_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (knobs & 2) ? 0 : (int)p.w_bytes, 0x00020000);
 
     auto tile_dma_state = [&](int b, int n0) {      // pk / boff / the activation descriptor of the tile whose tables are set b
         const int* t = tab(b);
@@ -197,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
         const unsigned long long xb = reinterpret_cast<unsigned long long>(p.x) + img1;
         const unsigned long long xbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32) |
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb);
-        const int xlen = __builtin_amdgcn_readfirstlane((p.kc & 4) ? 0 : (int)(unsigned)(rem1 < cap ? rem1 : cap));
+        const int xlen = __builtin_amdgcn_readfirstlane((knobs & 4) ? 0 : (int)(unsigned)(rem1 < cap ? rem1 : cap));
         rs_x = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(xbu), 0, xlen, 0x00020000);
     };
     auto a_offsets = [&](int b, int ky) {                    // (read from the row table once per stage, not under the MFMAs)
@@ -223,13 +249,16 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
     // stage again: harmless reloads into free slots keep the number of loads per step -- what the counted waits rely on -- fixed.
     auto stage_soff = [&](int ky_, int cc_) { return __builtin_amdgcn_readfirstlane(wirow[ky_]) * tap2 + cc_ * 128; };
     int ky_n = 0, cc_n = 0, soff_c = 0, soff_n = 0;
-    auto issue_prologue = [&](int b) {                       // stage 0's patch and the weight tiles of steps 0 .. DP of the tile in set b
-        ky_n = 0; cc_n = 0;
-        if (nstage > 1) { if (++cc_n == nchunks) { cc_n = 0; ++ky_n; } }
-        soff_c = stage_soff(0, 0); soff_n = stage_soff(ky_n, cc_n);
-        a_offsets(b, 0);
+    // (measured and not kept: every workgroup starting at another filter row, so that the workgroups of an XCD read different
+    //  weight tiles at any moment: 1049 vs 1100 TFLOP/s -- sharing the lines helps)
+    auto issue_prologue = [&](int b, int s0, int ns) {       // first stage's patch and the weight tiles of steps 0 .. DP of the item in table set b
+        const int ky0 = s0 / nchunks, cc0 = s0 - ky0 * nchunks;
+        ky_n = ky0; cc_n = cc0;
+        if (ns > 1) { if (++cc_n == nchunks) { cc_n = 0; ++ky_n; } }
+        soff_c = stage_soff(ky0, cc0); soff_n = stage_soff(ky_n, cc_n);
+        a_offsets(b, ky0);
 #pragma unroll
-        for (int e = 0; e < NA; ++e) dma_a(0, 0, e);
+        for (int e = 0; e < NA; ++e) dma_a(0, cc0, e);
 #pragma unroll
         for (int v = 0; v <= DP; ++v) dma_b(v, (v < KW ? soff_c : soff_n) + (v % KW) * tap2);
     };
@@ -263,25 +292,26 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
             fb[set][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(sm + bbase + (bfix[j] ^ gx)));
     };
 
-    // ---- first tile ----
-    int q = wg_in_xcd;
-    if (q >= units_xcd || unit_mt(q) >= p.grid_m) return;
+    // ---- first item ----
+    int k_item = 0, mt = 0, nt = 0, s0 = 0, s1 = 0, part = -1;
+    if (!get_item(0, mt, nt, s0, s1, part)) {
+        k_item = rounds_main;                        // (no main unit for this workgroup: it may still own a tail range)
+        if (!get_item(k_item, mt, nt, s0, s1, part)) return;
+    }
     if (tid < kh) wirow[tid] = p.twi[ph.tap_begin + tid * KW];
-    setup_tables(0, unit_mt(q) * BM);
+    setup_tables(0, mt * BM);
     __syncthreads();
-    tile_dma_state(0, (q % p.grid_n) * BN);
-    issue_prologue(0);
+    tile_dma_state(0, nt * BN);
+    issue_prologue(0, s0, s1 - s0);
     int tb = 0;
 
     for (;;) {
-        const int mt = unit_mt(q), nt = q % p.grid_n;
-        const int m0 = mt * BM, n0 = nt * BN;
-        const int qn = q + wgs_per_xcd;
-        const bool has_next = qn < units_xcd && unit_mt(qn) < p.grid_m;
+        const int m0 = mt * BM, n0 = nt * BN, ns = s1 - s0;
+        int mt_n = 0, nt_n = 0, s0_n = 0, s1_n = 0, part_n = -1, k_n = k_item + 1;
+        bool has_next = get_item(k_n, mt_n, nt_n, s0_n, s1_n, part_n);
+        if (!has_next && k_n < rounds_main) { k_n = rounds_main; has_next = get_item(k_n, mt_n, nt_n, s0_n, s1_n, part_n); }
         const int* const t = tab(tb);
         {
-            const int nrows_ = t[T_MISC];
-            (void)nrows_;
             const int mlast = min(m0 + BM, M) - 1;
             const int row0 = m0 / Wo;
 #pragma unroll
@@ -297,12 +327,12 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        if (has_next) setup_tables(tb ^ 1, unit_mt(qn) * BM);       // (the other set: ordered by the loop's barriers before anyone reads it)
+        if (has_next) setup_tables(tb ^ 1, mt_n * BM);              // (the other set: ordered by the loop's barriers before anyone reads it)
         rg_wait_vm<0>();                                            // the prologue pieces (and the previous epilogue's stores)
         __builtin_amdgcn_s_barrier();
-        if (nstage > 0) load_frags(0, 0, 0, 0, 0);
+        if (ns > 0) load_frags(0, 0, 0, 0, 0);
 
-        for (int stage = 0; stage < nstage; ++stage) {
+        for (int stage = 0; stage < ns; ++stage) {         // (stage: local index -- buffer parity and ring slots start at 0 for every item)
             const int par = stage & 1;
             const int ubase = stage * KW;
             a_offsets(tb, ky_n);                               // (ky_n, cc_n): the NEXT stage; the last stage reloads itself into the idle buffer
@@ -327,11 +357,12 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
                     const int cur = g & 1;
                     // read-ahead: the next k-substep's fragments -- of the NEXT step under this step's last MFMAs
                     if (g + 1 < NG) load_frags(cur ^ 1, par, kx, (ubase + kx) & (NSLOT - 1), g + 1);
-                    else if (stage + 1 < nstage || kx + 1 < KW)
+                    else if (stage + 1 < ns || kx + 1 < KW)
                         load_frags(cur ^ 1, kx + 1 < KW ? par : par ^ 1, kx + 1 < KW ? kx + 1 : 0, (ubase + kx + 1) & (NSLOT - 1), 0);
                     // (pin the order: left alone the scheduler sinks these reads behind three of the four MFMAs below to save
                     //  registers, and every group then waits for reads issued one MFMA earlier)
                     __builtin_amdgcn_sched_barrier(0);
+                    // (measured and not kept: the same operands through v_mfma_f32_16x16x32_bf16 -- 1080 vs 1092-1098 TFLOP/s)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -351,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
                 }
             }
             soff_c = soff_n;
-            if (stage + 2 < nstage) { if (++cc_n == nchunks) { cc_n = 0; ++ky_n; } }
+            if (stage + 2 < ns) { if (++cc_n == nchunks) { cc_n = 0; ++ky_n; } }
             soff_n = stage_soff(ky_n, cc_n);
         }
         rg_wait_vm<0>();
@@ -359,12 +390,30 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
 
         // ---- the next tile's prologue goes out before this tile's epilogue ----
         if (has_next) {
-            tile_dma_state(tb ^ 1, (qn % p.grid_n) * BN);
-            issue_prologue(tb ^ 1);
+            tile_dma_state(tb ^ 1, nt_n * BN);
+            issue_prologue(tb ^ 1, s0_n, s1_n - s0_n);
         }
 
+        // ---- a tail range: the raw fp32 accumulators go to this range's slab(s); splitk_combine_kernel does the rest ----
+        if (part >= 0) {
+            int lane_p = lane;
+            asm volatile("" : "+v"(lane_p));         // (as lane_e below: keep these addresses out of the tap loop's registers)
+            const int m_tail0 = (p.ring_main / p.grid_n) * BM;
+            const size_t tail_px = (size_t)(M - m_tail0);
+            float* slab = p.part + ((size_t)(BN == 64 ? part * 2 + wz : part) * tail_px + (size_t)(m0 - m_tail0)) * p.N + n0 + ncol0 + (lane_p & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane_p >> 5);
+                    if (t[row] >= 0) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) slab[(size_t)row * p.N + j * 32] = acc[i][j][r];
+                    }
+                }
+        } else
         // ---- epilogue (scratch: [SC0, TAB0), behind the LDS the next prologue lands in) ----
-        if (!(p.kc & 8)) {                           // knob bit 3: no epilogue (timing only)
+        {
         // (lane_e: the epilogue's lane-dependent addresses are invariant across tiles, and hoisted out of the tile loop they would
         //  occupy ~60 registers throughout the tap loop -- an opaque copy of the lane index keeps them inside the epilogue)
         int lane_e = lane, tid_e = tid;
@@ -485,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
         }
         }
         if (!has_next) break;
-        q = qn;
+        k_item = k_n; mt = mt_n; nt = nt_n; s0 = s0_n; s1 = s1_n; part = part_n;
         tb ^= 1;
     }
 #endif  // RG_DEVICE_BODY

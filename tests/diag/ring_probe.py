@@ -31,7 +31,7 @@ for name, ci, co, k, p, H, W in (("res64 k9", 64, 64, 9, 4, 128, 416), ("res128 
     gf = 2.0 * B * H * W * k * k * ci * co / 1e9
     tiles = (B * H * W + 255) // 256 * (co // 64)
     for label, knob in (("default (DP 4)", 0), ("no weight traffic", 2), ("no activation traffic", 4), ("neither", 6), 
-                        ("no loop (prologue + epilogue only)", 1), ("no epilogue", 8), ("no epilogue, no traffic", 14)):
+                        ("no loop (prologue + epilogue only)", 1), ("a third of the stages", 8), ("a third of the stages, no traffic", 14), ("no loop, no traffic", 7)):
         for rep in range(2):
             ms = timeit(lambda: op.fwd(x, w, stats=True, tile_cfg=10 | (knob << 12)))
         print("%-10s %-24s %7.3f ms  %7.1f TF   %.2f us per tile-round" % (name, label, ms, gf / ms, ms * 1e3 / -(-tiles // 256)), flush=True)

@@ -449,3 +449,48 @@ def test_bf16_rtod_vs_emulation(gpu, B):
     print("gradient distance (median / 90th pct): HIP-vs-emulation %.3f / %.3f, emulation-vs-fp32 %.3f / %.3f"
           % (np.median(dh), np.percentile(dh, 90), np.median(dc), np.percentile(dc, 90)))
     assert np.median(dh) <= 1.25 * np.median(dc) + 2e-2
+
+
+@pytest.mark.parametrize("case", [("k7_128", 128, 128, 7, 3, False, 2, 36, 64), ("k3_256", 256, 256, 3, 1, False, 3, 16, 48),
+                                  ("k5_refl", 128, 64, 5, 2, True, 2, 36, 64), ("k9_64", 64, 64, 9, 4, False, 1, 72, 64)],
+                         ids=lambda c: c[0])
+def test_ring_kernel_rounds_and_tail_split(gpu, case, monkeypatch):
+    """conv_ring_bf16 as the driver's B = 20 shapes run it -- persistent workgroups over SEVERAL rounds of tiles, the last
+    round's units cut into stage ranges whose fp32 slabs splitk_combine_kernel sums -- on shapes small enough for the CPU
+    reference: GDN_RING_CUS=16 plans for a 16-CU chip (9 or 18 tiles of 256 pixels -> full rounds + a split tail of 2-4 units).  Forward (+ BatchNorm
+    partials: the slot layout changes with the split), data gradient with a residual; against torch on the bf16-rounded
+    operands, and against the same launch with the split off (GDN_RING_TAIL=0): same sums in another order."""
+    from gdn_amd import ops
+    name, ci, co, k, p, refl, B, H, W = case
+    g = torch.Generator().manual_seed(5)
+    x = r16(torch.randn(B, ci, H, W, generator=g)).requires_grad_(True)
+    w = r16(torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).requires_grad_(True)
+    y_ref = ref_conv(x, w, k, 1, p, refl, False)
+    gy = r16(torch.randn(y_ref.shape, generator=torch.Generator().manual_seed(1)))
+    y_ref.backward(gy)
+    add = r16(torch.randn(B, H, W, ci, generator=torch.Generator().manual_seed(2)))
+    xd, wd = nhwc(x.detach()).to(gpu).bfloat16(), tapmajor(w.detach(), False).to(gpu).bfloat16()
+    gyd, wt = nhwc(gy).to(gpu).bfloat16(), ops.transpose_taps(tapmajor(w.detach(), False).to(gpu)).bfloat16()
+    yr = y_ref.detach().double()
+    res = {}
+    for tail in ("1", "0"):
+        monkeypatch.setenv("GDN_RING_CUS", "16")
+        monkeypatch.setenv("GDN_RING_TAIL", tail)
+        for cfg in (10, 11):
+            if co % (64 if cfg == 10 else 128):
+                continue
+            op = ops.Conv(ci, co, k, 1, p, reflect=refl)       # (a fresh op: its cached workspace size belongs to one plan)
+            y, st = op.fwd(xd, wd, stats=True, tile_cfg=cfg)
+            what = "%s cfg%d tail%s" % (name, cfg, tail)
+            close(nchw(y.float()), y_ref, rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=what + " fwd")
+            close(st[:, 0, :].double().sum(0).cpu(), yr.sum((0, 2, 3)), rtol=1e-3, atol_scale=1e-3, what=what + " stats sum")
+            close(st[:, 1, :].double().sum(0).cpu(), (yr * yr).sum((0, 2, 3)), what=what + " stats sumsq")
+            if not refl:
+                dx = op.dgrad(gyd, wt, (H, W), addsrc=add.to(gpu).bfloat16(), tile_cfg=cfg)
+                close(nchw(dx.float()), x.grad + nchw(add), rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=what + " dgrad")
+            res[(cfg, tail)] = (y.float().cpu(), st.shape[0])
+    for cfg in (10, 11):
+        if (cfg, "1") in res:
+            a, b = res[(cfg, "1")], res[(cfg, "0")]
+            assert a[1] != b[1], "the split did not happen (same slot count)"
+            assert (a[0] - b[0]).abs().max() <= 2 ** -7 * b[0].abs().max()      # one bf16 ulp of the largest value

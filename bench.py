@@ -153,6 +153,44 @@ def fftconv_roofline(dev, B, reps=10):
                 "bwd_ms": round(tb, 4), "bwd_bytes": tby_b, "bwd_achieved": round(tby_b / tb / 1e6, 1)}}
 
 
+def ring_roofline(dev, B, reps=20):
+    """BASELINE configs[2]'s dominant kernel (round 4): conv_ring_bf16<64, 9>, the 9x9 64->64 stride-1 layer at level 0
+    (128x416) on the bf16 matrix pipe -- forward with the BatchNorm partials, and the data gradient with a residual."""
+    from gdn_amd import ops
+    H, W, C, k = 128, 416, 64, 9
+    op = ops.Conv(C, C, k, 1, k // 2)
+    x = torch.randn(B, H, W, C, device=dev).bfloat16()
+    w = (torch.randn(k * k, C, C, device=dev) * 0.02).bfloat16()
+    wt = ops.transpose_taps(w)
+    add = torch.randn(B, H, W, C, device=dev).bfloat16()
+    y, st = op.fwd(x, w, stats=True)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()                      # torch's current stream == the stream the C ABI launches on
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ms_f = timed(lambda: op.fwd(x, w, stats=True, out=y, stats_out=st))
+    ms_d = timed(lambda: op.dgrad(x, wt, (H, W), addsrc=add))
+    ms_old = timed(lambda: op.fwd(x, w, stats=True, out=y, stats_out=st, tile_cfg=9))
+    flop = 2.0 * B * H * W * k * k * C * C
+    a = flop / (ms_f * 1e-3) / 1e12
+    return {"kernel": "conv_ring_bf16<64, 9>: 9x9 s1 64->64 + BN-stats epilogue, B=%d 128x416 (level 0), bf16 in / fp32 accumulate -- the "
+                      "dominant kernel of the RtoD bf16 step (configs[2]); LDS-DMA ring, persistent workgroups (DESIGN.md 2.11)" % B,
+            "bound": "mfma", "unit": "TFLOP/s", "achieved": round(a, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+            "frac": round(a / PEAK_BF16_MFMA_TFLOPS, 4), "gflop_per_launch": round(flop / 1e9, 1), "ms_per_launch": round(ms_f, 4),
+            "traffic": pmc_traffic("r04_conv_ring_pmc.json"),
+            "dgrad_with_residual": {"ms_per_launch": round(ms_d, 4), "achieved": round(flop / (ms_d * 1e-3) / 1e12, 1)},
+            "round1_kernel": {"kernel": "conv_rowpatch_bf16<64,4,1> (tile_cfg 9)", "ms_per_launch": round(ms_old, 4),
+                              "achieved": round(flop / (ms_old * 1e-3) / 1e12, 1)}}
+
+
 def pmc_traffic(name="r01_conv3x3_pmc.json"):
     """L2->fabric bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None if the summary is absent."""
@@ -394,6 +432,10 @@ def other_configs(dev, B, depth, rgb, sparse):
             out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         gc.collect()
         torch.cuda.empty_cache()
+    try:
+        out["roofline_rtod_bf16"] = ring_roofline(dev, B)
+    except Exception as e:  # noqa: BLE001
+        out["roofline_rtod_bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}
     for key, dt in (("infer_b64_graph", "fp32"), ("infer_b64_graph_bf16", "bf16")):
         try:
             ms, chk = infer_measure(dev, 64, dt, 3, 1, graph=True)

@@ -494,3 +494,30 @@ def test_ring_kernel_rounds_and_tail_split(gpu, case, monkeypatch):
             a, b = res[(cfg, "1")], res[(cfg, "0")]
             assert a[1] != b[1], "the split did not happen (same slot count)"
             assert (a[0] - b[0]).abs().max() <= 2 ** -7 * b[0].abs().max()      # one bf16 ulp of the largest value
+
+
+@pytest.mark.parametrize("tr,B,H,W", [(False, 2, 40, 64), (True, 1, 24, 52), (False, 1, 128, 416)], ids=["conv", "convT_ragged", "full_size"])
+def test_head_bf16_on_the_matrix_pipe(gpu, tr, B, H, W):
+    """The 64 -> 1 9x9 heads with bf16 activations (conv_head_mfma_bf16_kernel, round 4): the 81 taps are the rows of a bf16
+    MFMA product per input row, the fp32 weights enter as three exact bf16 terms, the output is a shifted gather.  Against torch
+    on the bf16-rounded activations with the FULL fp32 weights: the kernel is an fp32-weight product, so the fp32 bar holds
+    (1e-3 relative + 1e-4 of the maximum) -- with and without tanh, Conv2d and ConvTranspose2d (flipped taps), a width that is
+    not a multiple of the 16-column strips, and every row-segment boundary of the full-size map."""
+    import torch.nn.functional as F
+    from gdn_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = r16(torch.randn(B, 64, H, W, generator=g))
+    w = torch.randn(1, 64, 9, 9, generator=g) / 72.0
+    if tr:
+        wt = w.permute(1, 0, 2, 3).contiguous()                   # ConvTranspose2d weight [Cin, Cout, k, k]
+        ref = F.conv_transpose2d(x, wt, stride=1, padding=4)
+        w_tap = tapmajor(wt, True)
+    else:
+        ref = F.conv2d(x, w, padding=4)
+        w_tap = tapmajor(w, False)
+    op = ops.Conv(64, 1, 9, 1, 4, transposed=tr)
+    xd = nhwc(x).to(gpu).bfloat16()
+    for act, rf in ((ops.ACT_NONE, ref), (ops.ACT_TANH, torch.tanh(ref))):
+        y = op.fwd(xd, w_tap.to(gpu), act=act)
+        assert y.dtype == torch.float32 and tuple(y.shape) == (B, H, W, 1)
+        close(nchw(y), rf, rtol=1e-3, atol_scale=1e-4, what="bf16 head tr=%s act=%d" % (tr, act))

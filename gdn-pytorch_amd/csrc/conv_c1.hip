@@ -39,8 +39,8 @@ __device__ __forceinline__ float c1_fetch(const float* __restrict__ img, int H, 
 // y[p][n] = sum_tap x1[p + tap - pad] * w[tap][n]  (+ epilogue).  A workgroup stages the 81 x 64 weights once ([ky][kx pad 10][64],
 // 23 KB) and walks 8 x 32 pixel tiles (persistent grid); wave w owns rows 2w, 2w+1 of a tile: 2 pixel tiles x 2 channel
 // tiles of 32 x 32.  stats slot = tile.
-__global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ w, float* __restrict__ y,
-                                                          int ldy, const float* __restrict__ addsrc, int ld_add,
+__global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ w, void* __restrict__ y,
+                                                          int ldy, const void* __restrict__ addsrc, int ld_add, int dtypes,
                                                           float* __restrict__ stats, const float* __restrict__ ep_scale,
                                                           const float* __restrict__ ep_shift, int act, C1Geom g, int tiles_x,
                                                           int tiles_y) {
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
                         if (ep_scale) val = val * es + et;
                         if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
                         const size_t px = (size_t)(b * g.H + oy) * g.W + ox;
-                        if (addsrc) val += addsrc[px * ld_add + n];
-                        y[px * ldy + n] = val;
+                        if (addsrc) val += ld1_any(addsrc, px * ld_add + n, dtypes & 2);
+                        st1_any(y, px * ldy + n, val, dtypes & 1);
                     }
                 }
             }
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
 // the end and the workgroup writes one partial [96][64] (summed in fixed order by conv_c1_wgrad_reduce_kernel).
 #define C1W_TH 4
 #define C1W_PH (C1W_TH + C1_K - 1)      // 12
-__global__ __launch_bounds__(256, 2) void conv_c1_wgrad_kernel(const float* __restrict__ x1, const float* __restrict__ gw, int ldg,
+__global__ __launch_bounds__(256, 2) void conv_c1_wgrad_kernel(const float* __restrict__ x1, const void* __restrict__ gw, int ldg, int gw_bf16,
                                                             float* __restrict__ part, C1Geom g, int tiles_x, int tiles_y) {
     __shared__ float patch[C1W_PH * C1_PW];
     __shared__ __attribute__((aligned(16))) float gt[C1W_TH * C1_TW * C1_N];       // [pixel][64]: 32 KB
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv_c1_wgrad_kernel(const float* __re
             const int q = ps * 16 + (tid >> 4), c4 = (tid & 15) * 4;
             const int oy = y0 + q / C1_TW, ox = x0 + q % C1_TW;
             rg[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (oy < g.H && ox < g.W) rg[ps] = *reinterpret_cast<const f32x4*>(gw + ((size_t)(b * g.H + oy) * g.W + ox) * ldg + c4);
+            if (oy < g.H && ox < g.W) rg[ps] = ld4_any(gw, ((size_t)(b * g.H + oy) * g.W + ox) * ldg + c4, gw_bf16);
         }
     };
     if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
@@ -274,23 +274,24 @@ extern "C" int64_t gdn_conv_c1_stats_slots(int32_t B, int32_t H, int32_t W) {
 }
 
 extern "C" int gdn_conv_c1_fwd(const float* x1, int32_t B, int32_t H, int32_t W, int32_t N, int32_t k, int32_t pad, int32_t reflect,
-                               int32_t flip, const float* w, float* y, int32_t ldy, const float* addsrc, int32_t ld_add,
-                               float* stats, const float* ep_scale, const float* ep_shift, int32_t act, void* stream) {
+                               int32_t flip, const float* w, void* y, int32_t ldy, const void* addsrc, int32_t ld_add,
+                               float* stats, const float* ep_scale, const float* ep_shift, int32_t act, int32_t dtypes,
+                               void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!c1_ok(B, H, W, N, k, pad, reflect)) return GDN_ERR_UNSUPPORTED;
-    if (!x1 || !w || !y || (!ep_scale) != (!ep_shift) || (act & GDN_ACT_TANH)) return GDN_ERR_BAD_ARG;
+    if (!x1 || !w || !y || (!ep_scale) != (!ep_shift) || (act & GDN_ACT_TANH) || (dtypes & ~3)) return GDN_ERR_BAD_ARG;
     const C1Geom g = {B, H, W, pad, reflect ? 1 : 0, flip ? 1 : 0};
     const int tiles_x = cdiv(W, C1_TW), tiles_y = cdiv(H, C1_TH), ntiles = B * tiles_x * tiles_y;
     hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3(ntiles < C1_FWD_WGS ? ntiles : C1_FWD_WGS), dim3(256), 0, (hipStream_t)stream, x1, w, y,
-                       ldy, addsrc, ld_add, stats, ep_scale, ep_shift, act, g, tiles_x, tiles_y);
+                       ldy, addsrc, ld_add, (int)dtypes, stats, ep_scale, ep_shift, act, g, tiles_x, tiles_y);
     return gdn_launch_status();
 }
 
 extern "C" size_t gdn_conv_c1_wgrad_workspace_bytes(void) { return (size_t)C1_WGRAD_WGS * 96 * C1_N * sizeof(float); }
 
-extern "C" int gdn_conv_c1_wgrad(const float* x1, const float* gw, int32_t ldg, int32_t B, int32_t H, int32_t W, int32_t N, int32_t k,
-                                 int32_t pad, int32_t reflect, int32_t flip, float* dw, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
+extern "C" int gdn_conv_c1_wgrad(const float* x1, const void* gw, int32_t ldg, int32_t gw_bf16, int32_t B, int32_t H, int32_t W, int32_t N,
+                                 int32_t k, int32_t pad, int32_t reflect, int32_t flip, float* dw, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
     if (!c1_ok(B, H, W, N, k, pad, reflect)) return GDN_ERR_UNSUPPORTED;
     if (!x1 || !gw || !dw || (ldg % 4)) return GDN_ERR_BAD_ARG;
@@ -299,7 +300,8 @@ extern "C" int gdn_conv_c1_wgrad(const float* x1, const float* gw, int32_t ldg, 
     const int tiles_x = cdiv(W, C1_TW), tiles_y = cdiv(H, C1W_TH);
     const int ntiles = B * tiles_x * tiles_y;
     const int nwg = ntiles < C1_WGRAD_WGS ? ntiles : C1_WGRAD_WGS;
-    hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x1, gw, ldg, (float*)workspace, g, tiles_x,
+    hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x1, gw, ldg, gw_bf16 ? 1 : 0, (float*)workspace,
+                       g, tiles_x,
                        tiles_y);
     hipLaunchKernelGGL(conv_c1_wgrad_reduce_kernel, dim3(C1_K * C1_K), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, dw, nwg, flip ? 1 : 0);

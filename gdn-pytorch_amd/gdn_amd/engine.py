@@ -706,7 +706,8 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
 
 def conv_head_tanh(ctx, x, conv):
     """Final 9x9 (transposed) conv to one channel + tanh (AE_model_unet.py:362-363, :570-571).
-    On the bf16 path only x is bf16: weights, the depth map and this layer's backward are fp32."""
+    On the bf16 path only x is bf16: weights, the depth map and this layer's backward results are fp32 (the 1 <-> 64 channel
+    kernels read the bf16 x / the bf16 gradient already accumulated for x directly)."""
     op = _conv_op(conv, 0)
     ctx.claim(x)
     w, tr = _w_tap(conv)
@@ -721,7 +722,7 @@ def conv_head_tanh(ctx, x, conv):
             dpre = ops.tanh_bwd(do.contiguous(), out)
             # 64 -> 1 heads: both gradients are 1 <-> 64 channel correlations with the single-channel d(pre-tanh) as the
             # staged image (csrc/conv_c1.hip); a Conv2d head flips the taps, a ConvTranspose2d head does not
-            c1 = (_C1 and x.dtype == torch.float32 and x.is_contiguous() and conv.out_channels == 1
+            c1 = (_C1 and x.is_contiguous() and conv.out_channels == 1
                   and ops.c1_ok(dpre, conv.in_channels, conv.kernel_size[0], conv.stride[0], conv.padding[0]))
             if conv.weight.requires_grad:
                 if c1:
@@ -730,7 +731,7 @@ def conv_head_tanh(ctx, x, conv):
                     _wgrad_into(ctx, conv, x, dpre)
                 ctx.grads_done(conv.weight)
             if c1:
-                dx = ops.conv_c1_fwd(dpre, w, flip=not tr, addsrc=ctx.pop_grad_as(x, torch.float32))
+                dx = ops.conv_c1_fwd(dpre, w, flip=not tr, addsrc=ctx.pop_grad(x))      # fp32, like the generic path's
             else:
                 wt = ops.transpose_taps(w)
                 dx = op.dgrad(dpre, wt, in_hw, addsrc=ctx.pop_grad_as(x, torch.float32))

@@ -23,6 +23,10 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def _is_bf16(t):
+    return 1 if t is not None and t.dtype == torch.bfloat16 else 0
+
+
 def _ld(t):
     if t.shape[-1] == 1:          # single channel: the pixel pitch is all that matters
         return t.stride(-2) if t.shape[-2] > 1 else 1
@@ -441,30 +445,34 @@ def c1_ok(x1, n, k, stride, pad):
             and stride == 1 and pad == 4)
 
 
-def conv_c1_fwd(x1, w81, reflect=False, flip=False, stats=False, addsrc=None, affine=None, act=ACT_NONE):
-    """y[B,H,W,64] = sum_tap x1[p + tap - 4] * w81[tap][:]; x1 [B,H,W,1], w81 any tensor of 81*64 floats in [tap][64] order."""
+def conv_c1_fwd(x1, w81, reflect=False, flip=False, stats=False, addsrc=None, affine=None, act=ACT_NONE, out_dtype=torch.float32):
+    """y[B,H,W,64] = sum_tap x1[p + tap - 4] * w81[tap][:]; x1 [B,H,W,1], w81 any tensor of 81*64 floats in [tap][64] order.
+    y (out_dtype) and addsrc may be bf16: a bf16 model's head data gradient."""
     _chk(x1, "x1"); _chk(w81, "w")
+    if x1.dtype != torch.float32 or w81.dtype != torch.float32:
+        raise GdnError("conv_c1_fwd: the single-channel image and the weights are fp32")
     B, H, W, _ = x1.shape
     if w81.numel() != 81 * 64 or not w81.is_contiguous():
         raise GdnError("conv_c1_fwd: weights must be 81 x 64 contiguous floats")
-    y = torch.empty((B, H, W, 64), dtype=torch.float32, device=x1.device)
+    y = torch.empty((B, H, W, 64), dtype=out_dtype, device=x1.device)
     st = torch.empty((int(lib.gdn_conv_c1_stats_slots(B, H, W)), 2, 64), dtype=torch.float32, device=x1.device) if stats else None
+    dtypes = _is_bf16(y) | (_is_bf16(addsrc) << 1)
     lib.gdn_conv_c1_fwd(_p(x1), B, H, W, 64, 9, 4, 1 if reflect else 0, 1 if flip else 0, _p(w81), _p(y), 64, _p(addsrc),
                         0 if addsrc is None else _ld(addsrc), _p(st), _p(affine[0]) if affine else None,
-                        _p(affine[1]) if affine else None, int(act), stream())
+                        _p(affine[1]) if affine else None, int(act), dtypes, stream())
     return (y, st) if stats else y
 
 
 def conv_c1_wgrad(x1, gw, dw81, reflect=False, flip=False):
-    """dw81[tap][:] = sum_p gw[p][:] * x1[p + tap - 4] (written at the flipped tap when flip); gw [B,H,W,64]."""
-    _chk(x1, "x1"); _chk(gw, "gw"); _chk(dw81, "dw")
+    """dw81[tap][:] = sum_p gw[p][:] * x1[p + tap - 4] (written at the flipped tap when flip); gw [B,H,W,64], fp32 or bf16."""
+    _chk(x1, "x1"); _chk(gw, "gw", bf16_ok=True); _chk(dw81, "dw")
     B, H, W, _ = x1.shape
     if dw81.numel() != 81 * 64 or not dw81.is_contiguous() or tuple(gw.shape) != (B, H, W, 64):
         raise GdnError("conv_c1_wgrad: bad shapes")
     nb = int(lib.gdn_conv_c1_wgrad_workspace_bytes())
     ws = workspace(nb, x1.device, "wgrad")
-    lib.gdn_conv_c1_wgrad(_p(x1), _p(gw), _ld(gw), B, H, W, 64, 9, 4, 1 if reflect else 0, 1 if flip else 0, _p(dw81), _p(ws), nb,
-                          stream())
+    lib.gdn_conv_c1_wgrad(_p(x1), _p(gw), _ld(gw), _is_bf16(gw), B, H, W, 64, 9, 4, 1 if reflect else 0, 1 if flip else 0, _p(dw81),
+                          _p(ws), nb, stream())
 
 
 def gemm_x3_pack(Bm):

@@ -40,7 +40,7 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
-/* Revision of this header (argument lists, struct layouts).  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+/* Revision of this header (argument lists, struct layouts).  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
  * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
@@ -271,14 +271,16 @@ int gdn_wino2conv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, cons
  *                      gdn_conv_c1_stats_slots.  The first convolution forward, and -- with x1 = d(pre-tanh) -- a head's data gradient.
  *   gdn_conv_c1_wgrad: dw[tap][n] = sum_p gw[p][n] * x1[p + tap - 4]   (gw [B,H,W,64], pitch ldg; result written at the flipped
  *                      tap when flip != 0).  The first convolution's weight gradient (x1 = input, gw = dy) and a head's
- *                      (x1 = d(pre-tanh), gw = the head's input; flip for a Conv2d head, none for a ConvTranspose2d one). */
+ *                      (x1 = d(pre-tanh), gw = the head's input; flip for a Conv2d head, none for a ConvTranspose2d one).
+ *   x1, w, stats, dw stay fp32.  dtypes of gdn_conv_c1_fwd: bit 0 = y is bf16, bit 1 = addsrc is bf16 (a bf16 model's head
+ *   data gradient, rounded once after the fp32 add); gw_bf16 != 0: gw is bf16 (the head's bf16 input), ldg % 4 == 0 either way. */
 int64_t gdn_conv_c1_stats_slots(int32_t B, int32_t H, int32_t W);
 int gdn_conv_c1_fwd(const float* x1, int32_t B, int32_t H, int32_t W, int32_t N, int32_t k, int32_t pad, int32_t reflect,
-                    int32_t flip, const float* w, float* y, int32_t ldy, const float* addsrc, int32_t ld_add,
-                    float* stats, const float* ep_scale, const float* ep_shift, int32_t act, void* stream);
+                    int32_t flip, const float* w, void* y, int32_t ldy, const void* addsrc, int32_t ld_add,
+                    float* stats, const float* ep_scale, const float* ep_shift, int32_t act, int32_t dtypes, void* stream);
 size_t gdn_conv_c1_wgrad_workspace_bytes(void);
-int gdn_conv_c1_wgrad(const float* x1, const float* gw, int32_t ldg, int32_t B, int32_t H, int32_t W, int32_t N, int32_t k,
-                      int32_t pad, int32_t reflect, int32_t flip, float* dw,
+int gdn_conv_c1_wgrad(const float* x1, const void* gw, int32_t ldg, int32_t gw_bf16, int32_t B, int32_t H, int32_t W, int32_t N,
+                      int32_t k, int32_t pad, int32_t reflect, int32_t flip, float* dw,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* fp32 per-bin GEMMs on the bf16 matrix pipe ("bf16 x 3": an fp32 operand is exactly the sum of three bf16 terms; six bf16

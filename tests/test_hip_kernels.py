@@ -416,3 +416,15 @@ def test_conv_c1_layers(gpu, B, H, W, reflect, flip):
     close(dw, wr.grad.permute(2, 3, 0, 1).reshape(81, 64), what="c1 wgrad")
     if not reflect and (H, W) == (8, 32):
         close(y, ops.Conv(1, 64, 9, 1, 4).fwd(x1d, w81.view(81, 64, 1)), what="c1 fwd vs direct")
+    # bf16 operands of a bf16 model's head backward: the 64-channel side (y / addsrc / gw) in bf16, fp32 arithmetic, one rounding
+    # of the result -- bit-exact against the fp32 kernels on the same rounded operands
+    rb, gb = nhwc(res).to(gpu).bfloat16(), nhwc(gy).to(gpu).bfloat16()
+    yb = ops.conv_c1_fwd(x1d, w81, reflect=reflect, flip=flip, addsrc=rb, out_dtype=torch.bfloat16)
+    assert yb.dtype == torch.bfloat16
+    y32 = ops.conv_c1_fwd(x1d, w81, reflect=reflect, flip=flip, addsrc=rb.float())
+    assert torch.equal(yb, y32.bfloat16())
+    assert torch.equal(ops.conv_c1_fwd(x1d, w81, reflect=reflect, flip=flip, addsrc=rb), y32)
+    dwb, dw32 = torch.empty((81, 64), device=gpu), torch.empty((81, 64), device=gpu)
+    ops.conv_c1_wgrad(x1d, gb, dwb, reflect=reflect, flip=flip)
+    ops.conv_c1_wgrad(x1d, gb.float(), dw32, reflect=reflect, flip=flip)
+    assert torch.equal(dwb, dw32)

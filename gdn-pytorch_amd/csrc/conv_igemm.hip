@@ -971,8 +971,6 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
     }
 }
 
-namespace {
-
 // CU count of the current device (a device attribute, read once per process: 256 on MI355X)
 int gdn_num_cus() {
     // GDN_RING_CUS=<n> (test hook, read per call): plan the persistent kernels as for a chip with n CUs, so that small test
@@ -986,6 +984,9 @@ int gdn_num_cus() {
     }();
     return n;
 }
+
+namespace {
+
 
 // Buffer descriptors address 32 bits; out-of-range sentinels sit just below 4 GiB.
 const uint64_t kMaxBufBytes = 0xFF000000ull;

@@ -71,6 +71,8 @@ _SIGS = {
     "gdn_gemm_x3_pack": (c_int32, [_P, _P, _i32, _i32, _i32, _P]),
     "gdn_gemm_x3_nt": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, _P]),
     "gdn_gemm_x3_tn": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, _i32, _P]),
+    "gdn_gemm_x3_ring_workspace_bytes": (_sz, []),
+    "gdn_gemm_x3_nt_packed": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, _P, _sz, _P]),
     "gdn_transpose_taps": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P]),
     "gdn_cast": (c_int32, [_P, _P, _i64, _i32, _P]),
     "gdn_weight_to_tapmajor": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P]),
@@ -110,7 +112,7 @@ _STATUS_FUNCS = {n for n, (r, _) in _SIGS.items() if r is c_int32} - {"gdn_versi
 EXPORTS = tuple(_SIGS)
 # The C ABI revision these signatures (and ConvGeom's layout) describe: gdn_version() of the library must match exactly --
 # a stale build would take the arguments apart differently.
-ABI_VERSION = 213
+ABI_VERSION = 214
 
 
 class _Lib:

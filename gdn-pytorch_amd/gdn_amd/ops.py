@@ -496,6 +496,15 @@ def gemm_x3_nt(A, Bp, N, out=None):
     return C
 
 
+def gemm_x3_nt_packed(Ap, Bp, bins, M, N, K, out=None):
+    """C[bin] = A[bin] @ B[bin]^T with BOTH operands packed (gemm_x3_pack of [bins, M, K] and of [bins, N, K]); fp32 C [bins, M, N]."""
+    C = out if out is not None else torch.empty((bins, M, N), dtype=torch.float32, device=Ap.device)
+    nb = int(lib.gdn_gemm_x3_ring_workspace_bytes())
+    ws = workspace(nb, Ap.device, "x3ring")
+    lib.gdn_gemm_x3_nt_packed(_p(Ap), _p(Bp), _p(C), bins, M, N, K, _p(ws), nb, stream())
+    return C
+
+
 def gemm_x3_tn(A, Bm, nsplit=1):
     """P[split, bin] = A[bin]^T @ B[bin] over the split's rows; A [bins, T, NI], B [bins, T, NJ] fp32 -> [nsplit, bins, NI, NJ]."""
     _chk(A, "A"); _chk(Bm, "B")

@@ -40,7 +40,7 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
-/* Revision of this header (argument lists, struct layouts).  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+/* Revision of this header (argument lists, struct layouts).  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
  * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
@@ -299,6 +299,11 @@ int gdn_gemm_x3_pack(const float* src, void* dst, int32_t bins, int32_t rows, in
 int gdn_gemm_x3_nt(const float* A, const void* Bp, float* C, int32_t bins, int32_t M, int32_t N, int32_t K, void* stream);
 int gdn_gemm_x3_tn(const float* A, const float* B, float* P, int32_t bins, int32_t T, int32_t NI, int32_t NJ, int32_t nsplit,
                    void* stream);
+/* gdn_gemm_x3_nt with A packed as well (gdn_gemm_x3_pack of [bins][M][K]): the LDS-DMA ring kernel (csrc/gemm_x3_ring.h) the
+ * Winograd layers run on when their transforms write panels.  workspace: gdn_gemm_x3_ring_workspace_bytes(). */
+size_t gdn_gemm_x3_ring_workspace_bytes(void);
+int gdn_gemm_x3_nt_packed(const void* Ap, const void* Bp, float* C, int32_t bins, int32_t M, int32_t N, int32_t K,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* bf16 weight gradient (BASELINE configs[2]): x and dy hold bfloat16, dw is fp32 (the master
  * gradient arena).  Same contract as gdn_conv_wgrad otherwise.  Needs Cx and Cout multiples of

@@ -29,6 +29,7 @@ struct WinoGeom {
     int tiles_y, tiles_x, M;      // 2x2 output tiles; M = B * tiles_y * tiles_x
     int cq_shift, nq_shift;       // log2(C / 64), log2(N / 64)
     int x3;                       // per-bin GEMMs as bf16 x 3 split products (gemm_x3.h) unless the caller set GDN_HINT_NO_X3
+    int T, bins;                  // outputs per tile side and transform bins: F(2x2,3x3) T = 2, 16 bins; F(4x4,3x3) T = 4, 36 bins
 };
 
 // V = B^T d B of the 4x4 patch whose top-left corner is (2a - pad_off, 2b - pad_off)
@@ -195,9 +196,9 @@ __global__ __launch_bounds__(256) void wino_weights_x3_kernel(const float* __res
     const int rows = swap ? C : N, K = swap ? N : C, k8n = K / 8;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * k8n) return;
-    // consecutive lanes take consecutive rows when the 8 k values are strided in memory (swap: k = n, stride C), consecutive k
-    // blocks otherwise (k = c contiguous): either way a wave's loads are contiguous runs
-    const int row = swap ? i % rows : i / k8n, k8 = swap ? i / rows : i % k8n;
+    // a wave = 16 consecutive rows x the 4 chunks of ONE k block: 1 KB contiguous per (bin, plane) store in the packed layout;
+    // its loads are 16 runs of 128 B (k = c contiguous) or 8 x 4 runs of 64 B (swap: k = n, stride C)
+    const int row = (i >> 2) % rows, k8 = (i & 3) + 4 * ((i >> 2) / rows);
     float gk[8][3][3];
 #pragma unroll
     for (int ty = 0; ty < 3; ++ty)
@@ -343,6 +344,308 @@ __global__ __launch_bounds__(256) void wino_wgrad_output_kernel(const float* __r
     }
 }
 
+
+// ---- F(4x4, 3x3): 6x6 patches, 36 bins, 2.25 multiplications per output instead of 4 (and 2.25 transformed values per pixel
+// instead of 4).  Interpolation points 0, +-1, +-2, inf (Lavin & Gray): B^T integer, G carries the 1/4, 1/6, 1/24 scalings, A^T powers.
+// fp32 error of one layer against an fp64 convolution: rms 6x, max 15x the direct sum's (2.4e-6 / 4e-5 of the output rms at 512
+// channels) -- two decades inside the 1e-3 bar this path is held to; F(2x2,3x3) stays for reflection-padded layers, small images
+// and the fp32-matrix-pipe fallback.  The weight gradient is F(3x3,4x4) on the same points: the saved B^T d B is reused, dy takes
+// G_w (6x4: rows s_i (1, p, p^2, p^3)), the reduction over tiles is the TN GEMM, and A_w^T (3x6) folds the 36 bins into 9 taps.
+__device__ __forceinline__ void w4_bt(const float (&d)[6], float (&o)[6]) {
+    o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    o[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+    o[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+    o[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+    o[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+    o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+__device__ __forceinline__ void w4_g(const float (&g)[3], float (&o)[6]) {        // G (6x3)
+    const float a = g[0] + g[2];
+    o[0] = 0.25f * g[0];
+    o[1] = (-1.f / 6.f) * (a + g[1]);
+    o[2] = (-1.f / 6.f) * (a - g[1]);
+    const float b = (1.f / 24.f) * g[0] + (1.f / 6.f) * g[2];
+    o[3] = b + (1.f / 12.f) * g[1];
+    o[4] = b - (1.f / 12.f) * g[1];
+    o[5] = g[2];
+}
+__device__ __forceinline__ void w4_gw(const float (&y)[4], float (&o)[6]) {       // G_w (6x4)
+    const float e = y[0] + y[2], f = y[1] + y[3];
+    o[0] = 0.25f * y[0];
+    o[1] = (-1.f / 6.f) * (e + f);
+    o[2] = (-1.f / 6.f) * (e - f);
+    const float a = (1.f / 24.f) * y[0] + (1.f / 6.f) * y[2], b = (1.f / 12.f) * y[1] + (1.f / 3.f) * y[3];
+    o[3] = a + b;
+    o[4] = a - b;
+    o[5] = y[3];
+}
+__device__ __forceinline__ void w4_at(const float (&m)[6], float (&o)[4]) {       // A^T (4x6)
+    const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    o[0] = m[0] + s12 + s34;
+    o[1] = d12 + 2.f * d34;
+    o[2] = s12 + 4.f * s34;
+    o[3] = d12 + 8.f * d34 + m[5];
+}
+__device__ __forceinline__ void w4_awt(const float (&p)[6], float (&o)[3]) {      // A_w^T (3x6)
+    const float s12 = p[1] + p[2], d12 = p[1] - p[2], s34 = p[3] + p[4], d34 = p[3] - p[4];
+    o[0] = p[0] + s12 + s34;
+    o[1] = d12 + 2.f * d34;
+    o[2] = s12 + 4.f * s34 + p[5];
+}
+
+// V = B^T d B of the 6x6 patch whose top-left corner is (4a - pad_off, 4b - pad_off); in_scale / up2x as wino_input_kernel
+// (zero padding only: reflection-padded layers stay on F(2x2,3x3))
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V, WinoGeom g,
+                                                          const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                          int in_relu, int up2x) {
+    int t, c;
+    if (!wino_decode(g.M, g.cq_shift, t, c)) return;
+    const float is = in_scale ? in_scale[c] : 1.f, it = in_scale ? in_shift[c] : 0.f;
+    const float lo = in_relu ? 0.f : -3.402823466e38f;
+    const int b2 = t % g.tiles_x, a2 = (t / g.tiles_x) % g.tiles_y, img = t / (g.tiles_x * g.tiles_y);
+    float r[6][6];                           // B^T along rows, one patch column at a time
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int ix = 4 * b2 - g.pad_off + j;
+        const bool col_ok = ix >= 0 && ix < g.W;
+        float d[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int iy = 4 * a2 - g.pad_off + i;
+            const bool ok = col_ok && iy >= 0 && iy < g.H;
+            float v = 0.f;
+            if (ok) {
+                if (up2x) {
+                    // x is the LOW-resolution tensor [B][H/2][W/2][ldx]: the x2 bilinear upsampling happens here (up2x.h)
+                    const int Hl = g.H >> 1, Wl = g.W >> 1;
+                    float ly, lx; int y0, y1, x0, x1;
+                    up_src(iy, Hl, up2x - 1, ly, y0, y1);
+                    up_src(ix, Wl, up2x - 1, lx, x0, x1);
+                    v = up2x_at(x + ((size_t)(img * Hl + y0) * Wl) * ldx + c, x + ((size_t)(img * Hl + y1) * Wl) * ldx + c, ldx, ly, x0, x1, lx);
+                } else {
+                    v = x[((size_t)(img * g.H + iy) * g.W + ix) * ldx + c];
+                    if (in_scale) v = fmaxf(v * is + it, lo);
+                }
+            }
+            d[i] = v;
+        }
+        float o[6];
+        w4_bt(d, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i][j] = o[i];
+    }
+    float* dst = V + (size_t)t * g.C + c;
+    const size_t bs = (size_t)g.M * g.C;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {            // ... and along columns
+        float o[6];
+        w4_bt(r[i], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { dst[0] = o[j]; dst += bs; GDN_KEEP(dst); }
+    }
+}
+
+// Dv = G_w dy G_w^T of the 4x4 output tile (weight gradient)
+__global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, int ldy, float* __restrict__ Dv, WinoGeom g) {
+    int t, n;
+    if (!wino_decode(g.M, g.nq_shift, t, n)) return;
+    const int b2 = t % g.tiles_x, a2 = (t / g.tiles_x) % g.tiles_y, img = t / (g.tiles_x * g.tiles_y);
+    float s[6][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ox = 4 * b2 + j;
+        float y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oy = 4 * a2 + i;
+            y[i] = (oy < g.Ho && ox < g.Wo) ? dy[((size_t)(img * g.Ho + oy) * g.Wo + ox) * ldy + n] : 0.f;
+        }
+        float o[6];
+        w4_gw(y, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s[i][j] = o[i];
+    }
+    float* dst = Dv + (size_t)t * g.N + n;
+    const size_t bs = (size_t)g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float o[6];
+        w4_gw(s[i], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { dst[0] = o[j]; dst += bs; GDN_KEEP(dst); }
+    }
+}
+
+// U = G g G^T as bf16 x 3 packed panels, 36 bins (arguments as wino_weights_x3_kernel)
+__global__ __launch_bounds__(256) void wino4_weights_x3_kernel(const float* __restrict__ w, unsigned char* __restrict__ Up0, int N, int C,
+                                                               int swap0, unsigned char* __restrict__ Up1, int swap1) {
+    unsigned char* __restrict__ Up = blockIdx.y ? Up1 : Up0;
+    const int swap = blockIdx.y ? swap1 : swap0;
+    const int rows = swap ? C : N, K = swap ? N : C, k8n = K / 8;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * k8n) return;
+    // a wave = 16 consecutive rows x the 4 chunks of ONE k block: 1 KB contiguous per (bin, plane) store in the packed layout
+    // (thread = (row, consecutive k8) wrote sixteen 64-byte pieces 24 KB apart per store: 54 us for 113 MB at 512 channels)
+    const int row = (i >> 2) % rows, k8 = (i & 3) + 4 * ((i >> 2) / rows);
+    float r[8][6][3];                        // G along the tap rows, per k value
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+        float gk[8][3];
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const int tap = swap ? (2 - ty) * 3 + (2 - tx) : ty * 3 + tx;
+            if (swap) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gk[e][ty] = w[((size_t)tap * N + k8 * 8 + e) * C + row];
+            } else {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(w + ((size_t)tap * N + row) * C + k8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(w + ((size_t)tap * N + row) * C + k8 * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gk[e][ty] = lo[e]; gk[4 + e][ty] = hi[e]; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float o[6];
+            w4_g(gk[e], o);
+#pragma unroll
+            for (int i2 = 0; i2 < 6; ++i2) r[e][i2][tx] = o[i2];
+        }
+    }
+    const int KB = K / X3_BK;
+    const size_t per_bin = x3_packed_bytes(rows, K);
+    unsigned char* dst = Up + x3_off(row, k8 * 8, 0, KB);
+#pragma unroll
+    for (int i2 = 0; i2 < 6; ++i2) {
+        float uu[8][6];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w4_g(r[e][i2], uu[e]);
+#pragma unroll
+        for (int j2 = 0; j2 < 6; ++j2) {
+            unsigned h[3][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x3_split2(uu[2 * q][j2], uu[2 * q + 1][j2], h[0][q], h[1][q], h[2][q]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const uint4 v = {h[p][0], h[p][1], h[p][2], h[p][3]};
+                *reinterpret_cast<uint4*>(dst + (size_t)(i2 * 6 + j2) * per_bin + (size_t)p * 128 * 64) = v;
+            }
+        }
+    }
+}
+
+// y = A^T m A (4x4 outputs per tile); epilogue, BatchNorm partials and the data gradient's BatchNorm-backward partials exactly as
+// wino_output_kernel (stats slot = group of 4 tiles)
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mo, float* __restrict__ y, int ldy,
+                                                           const float* __restrict__ addsrc, int ld_add,
+                                                           float* __restrict__ stats, const float* __restrict__ ep_scale,
+                                                           const float* __restrict__ ep_shift, int act, WinoGeom g, int Nout,
+                                                           int q_shift, const float* __restrict__ bnb_y, int ld_bnb,
+                                                           const float* __restrict__ bnb_co, int bnb_relu) {
+    __shared__ float red[256 * 2];
+    int t, n;
+    const bool live = wino_decode(g.M, q_shift, t, n);
+    float s1 = 0.f, s2 = 0.f;
+    if (live) {
+        const int b2 = t % g.tiles_x, a2 = (t / g.tiles_x) % g.tiles_y, img = t / (g.tiles_x * g.tiles_y);
+        float r[4][6];                       // A^T along rows, one bin column at a time
+        const float* src = Mo + (size_t)t * Nout + n;
+        const size_t bs = (size_t)g.M * Nout;
+        {
+            float m[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { m[i][j] = *src; src += bs; GDN_KEEP(src); }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float col[6] = {m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j]};
+                float o[4];
+                w4_at(col, o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i][j] = o[i];
+            }
+        }
+        const float es = ep_scale ? ep_scale[n] : 1.f, et = ep_shift ? ep_shift[n] : 0.f;
+        float bsc = 0.f, bt = 0.f, bmu = 0.f, bis = 0.f;
+        if (bnb_y) { bsc = bnb_co[n]; bt = bnb_co[Nout + n]; bmu = bnb_co[2 * Nout + n]; bis = bnb_co[3 * Nout + n]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float o[4];
+            w4_at(r[i], o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int oy = 4 * a2 + i, ox = 4 * b2 + j;
+                if (oy < g.Ho && ox < g.Wo) {
+                    float val = o[j];
+                    if (!bnb_y) { s1 += val; s2 += val * val; }
+                    if (ep_scale) val = val * es + et;
+                    if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
+                    const size_t px = (size_t)(img * g.Ho + oy) * g.Wo + ox;
+                    if (addsrc) val += addsrc[px * ld_add + n];
+                    if (act & GDN_ACT_TANH) val = tanhf(val);
+                    y[px * ldy + n] = val;
+                    if (bnb_y) {
+                        const float yv = bnb_y[px * ld_bnb + n];
+                        float dz = val;
+                        if (bnb_relu && !(yv * bsc + bt > 0.f)) dz = 0.f;
+                        s1 += dz; s2 += dz * ((yv - bmu) * bis);
+                    }
+                }
+            }
+        }
+    }
+    if (stats) {
+        red[threadIdx.x * 2] = s1; red[threadIdx.x * 2 + 1] = s2;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float a1 = 0.f, a2s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a1 += red[(j * 64 + threadIdx.x) * 2]; a2s += red[(j * 64 + threadIdx.x) * 2 + 1]; }
+            const int slot = blockIdx.x >> q_shift;
+            const int ch = (blockIdx.x & ((1 << q_shift) - 1)) * 64 + threadIdx.x;
+            stats[((size_t)slot * 2 + 0) * Nout + ch] = a1;
+            stats[((size_t)slot * 2 + 1) * Nout + ch] = a2s;
+        }
+    }
+}
+
+// dW[tap][n][c] = (A_w^T P A_w)[ty][tx], the split partial products summed in order
+__global__ __launch_bounds__(256) void wino4_wgrad_output_kernel(const float* __restrict__ P, float* __restrict__ dw, int N, int C,
+                                                                 int nsplit) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const float* src = P + i;
+    const size_t bs = (size_t)N * C;
+    float r[3][6];
+    {
+        float p[6][6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                float v = *src;
+                for (int sp = 1; sp < nsplit; ++sp) v += src[(size_t)sp * 36 * bs];
+                p[a][b] = v; src += bs; GDN_KEEP(src);
+            }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const float col[6] = {p[0][b], p[1][b], p[2][b], p[3][b], p[4][b], p[5][b]};
+            float o[3];
+            w4_awt(col, o);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) r[a][b] = o[a];
+        }
+    }
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+        float o[3];
+        w4_awt(r[ty], o);
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) dw[(size_t)(ty * 3 + tx) * bs + i] = o[tx];
+    }
+}
+
 bool wino_geom(const gdn_conv_geom* g, WinoGeom& f) {
     if (!g || g->transposed || g->stride != 1 || g->k != 3 || g->pad != 1) return false;
     if (g->pad_mode == 1 && (g->H < 4 || g->W < 4)) return false;        // mirrored rows 1 and H-2 must be distinct interior rows
@@ -356,15 +659,27 @@ bool wino_geom(const gdn_conv_geom* g, WinoGeom& f) {
     f.cq_shift = 0; while ((64 << f.cq_shift) < f.C) ++f.cq_shift;
     f.nq_shift = 0; while ((64 << f.nq_shift) < f.N) ++f.nq_shift;
     f.x3 = (g->hints & GDN_HINT_NO_X3) ? 0 : 1;
+    f.T = 2; f.bins = WINO_BINS;
+    // F(4x4,3x3) where every GEMM of the layer runs as bf16 x 3 split products (the transformed weights exist as panels only),
+    // the border is zero padding, and rounding the image up to whole 4 x 4 tiles computes at most 15 % more pixels.
+    // GDN_WINO_F4=0 (measurement / test hook, read per plan): F(2x2,3x3) everywhere.
+    const char* e = getenv("GDN_WINO_F4");
+    if (f.x3 && !f.reflect && g->H >= 4 && g->W >= 4 && !(e && e[0] == '0')) {
+        const int ty = cdiv(g->H, 4), tx = cdiv(g->W, 4), M4 = g->B * ty * tx;
+        const bool fits = (int64_t)ty * tx * 16 * 100 <= (int64_t)g->H * g->W * 115;
+        if (fits && gemm_x3_ok(M4, f.N, f.C) && gemm_x3_ok(M4, f.C, f.N) && gemm_x3_tn_ok(M4, f.N, f.C)) {
+            f.T = 4; f.bins = 36; f.tiles_y = ty; f.tiles_x = tx; f.M = M4;
+        }
+    }
     return true;
 }
 
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
-inline size_t v_bytes(const WinoGeom& f) { return al256((size_t)WINO_BINS * f.M * f.C * 4); }
+inline size_t v_bytes(const WinoGeom& f) { return al256((size_t)f.bins * f.M * f.C * 4); }
 // transformed weights: fp32 [16][N][C], or the bf16 x 3 panels of either orientation (rows padded to whole 128-row tiles)
 inline size_t u_bytes(const WinoGeom& f) {
-    size_t b = (size_t)WINO_BINS * f.N * f.C * 4;
-    const size_t p1 = (size_t)WINO_BINS * x3_packed_bytes(f.N, f.C), p2 = (size_t)WINO_BINS * x3_packed_bytes(f.C, f.N);
+    size_t b = (size_t)f.bins * f.N * f.C * 4;
+    const size_t p1 = (size_t)f.bins * x3_packed_bytes(f.N, f.C), p2 = (size_t)f.bins * x3_packed_bytes(f.C, f.N);
     if (p1 > b) b = p1;
     if (p2 > b) b = p2;
     return al256(b);
@@ -372,12 +687,12 @@ inline size_t u_bytes(const WinoGeom& f) {
 // GDN_HINT_NO_X3 in the geometry keeps every per-bin GEMM on the fp32 MFMA (ranks that share a GPU, A/B measurements, accuracy
 // studies).  It is part of the layer's geometry, so the forward that writes the saved weight set and the backward that reads
 // it agree on its form by construction.
-inline size_t m_bytes(const WinoGeom& f) { return al256((size_t)WINO_BINS * f.M * f.N * 4); }
+inline size_t m_bytes(const WinoGeom& f) { return al256((size_t)f.bins * f.M * f.N * 4); }
 inline bool tn_x3(const WinoGeom& f) { return f.x3 && gemm_x3_tn_ok(f.M, f.N, f.C); }
-inline int tn_splits(const WinoGeom& f) { return tn_x3(f) ? gemm_x3_tn_splits(WINO_BINS, f.M, f.N, f.C) : wino_tn_splits(f.M, f.N, f.C); }
+inline int tn_splits(const WinoGeom& f) { return tn_x3(f) ? gemm_x3_tn_splits(f.bins, f.M, f.N, f.C) : wino_tn_splits(f.M, f.N, f.C); }
 // (workspace sizing: the larger of the two kernels' split counts)
 inline int tn_splits_max(const WinoGeom& f) {
-    const int a = wino_tn_splits(f.M, f.N, f.C), b = gemm_x3_tn_ok(f.M, f.N, f.C) ? gemm_x3_tn_splits(WINO_BINS, f.M, f.N, f.C) : 1;
+    const int a = wino_tn_splits(f.M, f.N, f.C), b = gemm_x3_tn_ok(f.M, f.N, f.C) ? gemm_x3_tn_splits(f.bins, f.M, f.N, f.C) : 1;
     return a > b ? a : b;
 }
 
@@ -419,6 +734,18 @@ extern "C" int gdn_winoconv_fwd(const gdn_conv_geom* g, const float* x, int32_t 
     float* Mo = (float*)p;
     if (state_out) V = (float*)state_out;
     float* Usw = state_out ? (float*)((char*)state_out + v_bytes(f)) : nullptr;
+    if (f.T == 4) {
+        // F(4x4,3x3): every GEMM of the layer is a bf16 x 3 one (wino_geom); the data gradient's weight set rides along as above
+        hipLaunchKernelGGL(wino4_input_kernel, dim3(cdiv(f.M, 4) << f.cq_shift), dim3(256), 0, st, x, ldx, V, f, in_scale, in_shift,
+                           in_relu, in_up2x);
+        hipLaunchKernelGGL(wino4_weights_x3_kernel, dim3(cdiv(f.N * f.C / 8, 256), Usw ? 2 : 1), dim3(256), 0, st, w, (unsigned char*)U, f.N,
+                           f.C, 0, (unsigned char*)Usw, 1);
+        launch_gemm_x3_nt((const float*)V, U, Mo, f.bins, f.M, f.N, f.C, st);
+        hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, (const float*)Mo, y, ldy, addsrc,
+                           ld_add, stats, ep_scale, ep_shift, act, f, f.N, f.nq_shift, (const float*)nullptr, 0,
+                           (const float*)nullptr, 0);
+        return gdn_launch_status();
+    }
     hipLaunchKernelGGL(wino_input_kernel, dim3(cdiv(f.M, 4) << f.cq_shift), dim3(256), 0, st, x, ldx, V, f, in_scale, in_shift,
                        in_relu, in_up2x);
     // the per-bin GEMMs run as bf16 x 3 split products on the bf16 matrix pipe where the shape allows (gemm_x3.h); the data
@@ -450,9 +777,9 @@ extern "C" size_t gdn_winoconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     if (!wino_geom(g, f)) return 0;
     // reflection layers run the data gradient over the padded domain: more tiles, plus the padded gradient itself
     const size_t Md = f.reflect ? (size_t)f.B * cdiv(f.H + 2, 2) * cdiv(f.W + 2, 2) : (size_t)f.M;
-    const size_t vd = al256((size_t)WINO_BINS * Md * f.N * 4), eo = al256((size_t)WINO_BINS * Md * f.C * 4);
+    const size_t vd = al256((size_t)f.bins * Md * f.N * 4), eo = al256((size_t)f.bins * Md * f.C * 4);
     const size_t padded = f.reflect ? al256((size_t)f.B * (f.H + 2) * (f.W + 2) * f.C * 4) : 0;
-    const size_t pr = (size_t)tn_splits_max(f) * al256((size_t)WINO_BINS * f.N * f.C * 4);   // weight-gradient products, one set per split
+    const size_t pr = (size_t)tn_splits_max(f) * al256((size_t)f.bins * f.N * f.C * 4);   // weight-gradient products, one set per split
     return (vd > m_bytes(f) ? vd : m_bytes(f)) + u_bytes(f) + (eo > pr ? eo : pr) + padded;
 }
 
@@ -480,10 +807,33 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
     hipStream_t st = (hipStream_t)stream;
     char* p = (char*)workspace;
     const size_t Md = f.reflect ? (size_t)f.B * cdiv(f.H + 2, 2) * cdiv(f.W + 2, 2) : (size_t)f.M;
-    const size_t vd = al256((size_t)WINO_BINS * Md * f.N * 4);
+    const size_t vd = al256((size_t)f.bins * Md * f.N * 4);
     float* Vd = (float*)p; p += (vd > m_bytes(f) ? vd : m_bytes(f));
     float* U = (float*)p; p += u_bytes(f);
     float* Eo = (float*)p;                       // data gradient: GEMM output [16][Md][C] (+ padded gradient); weight gradient: P
+    if (f.T == 4) {
+        if (dw) {
+            hipLaunchKernelGGL(wino4_dy_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, dy, ldy, Vd, f);
+            const int ns = tn_splits(f);
+            launch_gemm_x3_tn((const float*)Vd, (const float*)state, Eo, f.bins, f.M, f.N, f.C, ns, st);
+            hipLaunchKernelGGL(wino4_wgrad_output_kernel, dim3(cdiv(f.N * f.C, 256)), dim3(256), 0, st, (const float*)Eo, dw, f.N, f.C, ns);
+        }
+        if (dx) {
+            WinoGeom fd = f;
+            fd.C = f.N; fd.N = f.C; fd.cq_shift = f.nq_shift; fd.nq_shift = f.cq_shift;
+            hipLaunchKernelGGL(wino4_input_kernel, dim3(cdiv(fd.M, 4) << fd.cq_shift), dim3(256), 0, st, dy, ldy, Vd, fd,
+                               (const float*)nullptr, (const float*)nullptr, 0, 0);
+            const float* Ud = U;
+            if (state) Ud = (const float*)((const char*)state + v_bytes(f));      // transformed by the forward's launch
+            else hipLaunchKernelGGL(wino4_weights_x3_kernel, dim3(cdiv(f.N * f.C / 8, 256)), dim3(256), 0, st, w, (unsigned char*)U, f.N, f.C, 1,
+                                    (unsigned char*)nullptr, 0);
+            launch_gemm_x3_nt((const float*)Vd, Ud, Eo, f.bins, fd.M, f.C, f.N, st);
+            hipLaunchKernelGGL(wino4_output_kernel, dim3(cdiv(fd.M, 4) << fd.nq_shift), dim3(256), 0, st, (const float*)Eo, dx, ldx,
+                               addsrc, ld_add, bnb_y ? bnb_partial : (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
+                               fd, f.C, fd.nq_shift, bnb_y, ld_bnb, bnb_co, bnb_relu);
+        }
+        return gdn_launch_status();
+    }
     if (dw) {
         hipLaunchKernelGGL(wino_dy_kernel, dim3(cdiv(f.M, 4) << f.nq_shift), dim3(256), 0, st, dy, ldy, Vd, f);
         const int ns = tn_splits(f);
@@ -541,6 +891,6 @@ extern "C" int gdn_winoconv_gemm(const gdn_conv_geom* g, const float* V, const f
     WinoGeom f;
     if (!wino_geom(g, f)) return GDN_ERR_UNSUPPORTED;
     if (!V || !U || !Mo) return GDN_ERR_BAD_ARG;
-    launch_wino_gemm(V, U, Mo, f.M, f.N, f.C, (hipStream_t)stream);
+    launch_wino_gemm(V, U, Mo, f.B * cdiv(f.H, 2) * cdiv(f.W, 2), f.N, f.C, (hipStream_t)stream);      // (F(2x2,3x3) tiles whatever the layer's plan)
     return gdn_launch_status();
 }

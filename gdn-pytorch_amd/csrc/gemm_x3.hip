@@ -13,7 +13,8 @@ __global__ __launch_bounds__(256) void x3_pack_rows_kernel(const float* __restri
     const int bin = blockIdx.y;
     const size_t per_bin = x3_packed_bytes(rows, K);
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < (int64_t)rows_pad * k8n; i += (int64_t)gridDim.x * 256) {
-        const int k8 = (int)(i % k8n), row = (int)(i / k8n);
+        // a wave = 16 consecutive rows x the 4 chunks of one k block: 1 KB contiguous per plane in the packed layout
+        const int row = (int)((i >> 2) % rows_pad), k8 = (int)(i & 3) + 4 * (int)((i >> 2) / rows_pad);
         f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
         if (row < rows) {
             const float* s = src + ((size_t)bin * rows + row) * K + k8 * 8;

@@ -33,7 +33,9 @@ def timed_duty(fn, reps=20):
 
 shapes = [("wino l3 3x3/512 B20", 16, 4160, 512, 512), ("wino l4 3x3/512 B20", 16, 1040, 512, 512),
           ("fft 9x9/64 NP40 embedded", 840, 1040, 128, 128), ("fft 7x7/128 NP32 embedded", 544, 480, 256, 256),
-          ("fft 5x5/256 NP16 embedded", 144, 540, 512, 512), ("odd", 5, 300, 384, 96)]
+          ("fft 5x5/256 NP16 embedded", 144, 540, 512, 512), ("odd", 5, 300, 384, 96),
+          ("deepk 2048", 16, 4096, 512, 2048), ("deepk 512", 16, 4096, 512, 512), ("deepk 128", 16, 4096, 512, 128),
+          ("resident 1 round K2048", 8, 1024, 1024, 2048), ("streaming 1 round K2048", 16, 1024, 512, 2048), ("resident 1 round K512", 8, 1024, 1024, 512)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if sys.argv[1] in s[0]]
 for name, bins, M, N, K in shapes:

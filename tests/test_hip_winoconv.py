@@ -12,7 +12,9 @@ pytestmark = pytest.mark.gpu
 
 # (Cin, Cout, B, H, W): odd sizes (ragged last tile), Cin != Cout, single-tile images
 CASES = [(512, 512, 2, 8, 26), (512, 512, 1, 16, 52), (128, 256, 2, 9, 13), (64, 64, 3, 2, 2), (256, 128, 1, 5, 6),
-         (64, 128, 2, 1, 7)]
+         (64, 128, 2, 1, 7),
+         # F(4x4,3x3) plans (128-multiple channels, <= 15 % tile padding) with ragged last tiles in x / in y
+         (128, 128, 2, 12, 15), (256, 128, 1, 7, 8), (128, 256, 3, 4, 4)]
 
 
 @pytest.mark.parametrize("case", CASES, ids=["c%d_%d_%dx%dx%d" % c for c in CASES])

@@ -72,12 +72,20 @@ void launch_gemm_x3_ring(const void* Ap, const void* Bp, float* C, void* ws, int
 // [bins][T][NJ], both split on the fly); the caller sums the nsplit partial sets in a fixed order.  NI, NJ multiples of 128.
 void launch_gemm_x3_tn(const float* A, const float* Bm, float* P, int bins, int T, int NI, int NJ, int nsplit, hipStream_t st);
 static inline bool gemm_x3_tn_ok(int T, int NI, int NJ) { return T >= 1 && NI >= 128 && NI % 128 == 0 && NJ >= 128 && NJ % 128 == 0; }
-// splits of the reduction: two workgroups per CU fill the chip at 512 workgroups; chunks of at least 256 rows, at most 16
-// (the 64 -> 128 stride-2 layer has 32 (bin, tile) pairs over 30800 rows: 8 splits left half the chip idle, 345 us)
+// splits of the reduction.  512 workgroup slots (two per CU); chunks of at least 256 rows, at most 16 splits.  Cost model, in
+// units of one whole-K tile: rounds of the chip / s for the GEMM, plus the extra partial-product sets the tap kernel has to read
+// back (0.23 per set at T = 1040 and 36 x [512 x 512] products, measured: ~20 us against ~87 us per round; scaled by T and the set's size) -- the F(4x4,3x3) level-3 weight
+// gradient has 576 tiles: one split = 2 rounds (175 us), two = 2.25 half rounds paid as 3 (1.5 + 0.23).  With fewer tiles than
+// slots this reduces to the round-2 rule ceil(512 / tiles) (the 64 -> 128 stride-2 layer: 32 tiles over 30800 rows -> 16 splits).
 static inline int gemm_x3_tn_splits(int bins, int T, int NI, int NJ) {
     const int wgs = (NI / 128) * (NJ / 128) * bins;
-    int s = (512 + wgs - 1) / wgs;
-    if (s > 16) s = 16;
-    while (s > 1 && T / s < 256) --s;
-    return s < 1 ? 1 : s;
+    int best = 1;
+    double best_c = 1e30;
+    for (int s = 1; s <= 16; ++s) {
+        if (s > 1 && T / s < 256) break;
+        const double c = (double)((wgs * s + 511) / 512) / s +
+                         0.23 * (s - 1) * (1040.0 / T) * ((double)bins * NI * NJ / (36.0 * 512 * 512));
+        if (c < best_c - 1e-9) { best_c = c; best = s; }
+    }
+    return best;
 }

@@ -17,8 +17,8 @@ each rank trains its own batch-20 shard and the gradient arena is all-reduced
 with RCCL (weak scaling).  Rank 0 prints ONE JSON line.
 
 The same line carries
-  roofline     -- the dominant kernel of the step, `gemm_x3_nt_kernel`: the 16 per-bin GEMMs of the level-3 Winograd
-                  3x3 512->512 layer (north_star's fused 3x3 convolution) as bf16 x 3 split
+  roofline     -- the dominant kernel of the step, `gemm_x3_nt_kernel`: the 36 per-bin GEMMs of the level-3 Winograd
+                  F(4x4,3x3) 512->512 layer (north_star's fused 3x3 convolution) as bf16 x 3 split
                   products, timed with HIP events on the launch stream: algorithmic fp32 FLOP / time against the
                   bf16 MFMA peak / 6 (six bf16 products per fp32 product; 2500 / 6 = 416.7 TFLOP/s), the executed bf16
                   rate and the replaced fp32 MFMA kernel beside it; `traffic` from the committed PMC pass;
@@ -73,9 +73,9 @@ def conv3x3_roofline(dev, B, level, reps=20):
 
 
 def wino_roofline(dev, B, reps=20):
-    """The 512->512 3x3 layer at level 3 (16x52) as it now runs: Winograd F(2x2,3x3).  Times the dominant kernel (the 16
-    per-bin fp32 MFMA GEMMs) alone, and the whole forward (input / weight transforms + GEMMs + output transform with the
-    BatchNorm partials)."""
+    """The 512->512 3x3 layer at level 3 (16x52) as it now runs: Winograd F(4x4,3x3) with bf16 x 3 GEMMs.  Times the dominant
+    kernel (the 36 per-bin GEMMs) alone, round 2's fp32 MFMA GEMMs of the F(2x2,3x3) plan beside it, and the whole forward
+    (input / weight transforms + GEMMs + output transform with the BatchNorm partials)."""
     from gdn_amd import ops
     H, W, C = 16, 52, 512
     op = ops.Conv(C, C, 3, 1, 1)
@@ -97,11 +97,16 @@ def wino_roofline(dev, B, reps=20):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    ms_g = timed(lambda: op.wino_gemm_only(V, U, Mo, B, H, W))           # the fp32 MFMA per-bin GEMM (GDN_X3=0 path)
-    Up = ops.gemm_x3_pack(U)
-    ms_x = timed(lambda: ops.gemm_x3_nt(V, Up, C, out=Mo))                # the same 16 GEMMs as bf16 x 3 split products
+    ms_g = timed(lambda: op.wino_gemm_only(V, U, Mo, B, H, W))           # the fp32 MFMA per-bin GEMM (GDN_X3=0 path), F(2x2,3x3) shape
+    del V, U, Mo
+    # what the layer runs since round 4: F(4x4,3x3), 36 bins x [B * 4 * 13 tiles x 512] x [512 x 512] as bf16 x 3 split products
+    tiles4 = B * (H // 4) * (W // 4)
+    V4 = torch.randn(36, tiles4, C, device=dev)
+    Up4 = ops.gemm_x3_pack(torch.randn(36, C, C, device=dev) * 0.02)
+    Mo4 = torch.empty(36, tiles4, C, device=dev)
+    ms_x = timed(lambda: ops.gemm_x3_nt(V4, Up4, C, out=Mo4))
     ms_l = timed(lambda: op.wino_fwd(x, w, stats=True, state=True))
-    return ms_g, 2.0 * 16 * tiles * C * C, ms_l, 2.0 * B * H * W * 9 * C * C, ms_x
+    return ms_g, 2.0 * 16 * tiles * C * C, ms_l, 2.0 * B * H * W * 9 * C * C, ms_x, 2.0 * 36 * tiles4 * C * C
 
 
 def fftconv_roofline(dev, B, reps=10):
@@ -691,13 +696,13 @@ def main():
             }
             # dominant kernel of the step: the per-bin GEMMs of the Winograd layers, since round 3 executed as bf16 x 3 split
             # products on the bf16 matrix pipe (csrc/gemm_x3.hip: six bf16 MFMA products per fp32 product)
-            ms_g, fl_g, ms_l, fl_l, ms_x = wino_roofline(dev, B)
-            ax = fl_g / (ms_x * 1e-3) / 1e12                   # algorithmic (fp32) TFLOP/s
+            ms_g, fl_g, ms_l, fl_l, ms_x, fl_x = wino_roofline(dev, B)
+            ax = fl_x / (ms_x * 1e-3) / 1e12                   # algorithmic (fp32) TFLOP/s
             ag = fl_g / (ms_g * 1e-3) / 1e12
             rec["roofline"] = {
-                "kernel": "gemm_x3_nt_kernel: the 16 per-bin fp32 GEMMs [%d x 512] x [512 x 512] of the Winograd F(2x2,3x3) 3x3 s1 "
+                "kernel": "gemm_x3_nt_kernel: the 36 per-bin fp32 GEMMs [%d x 512] x [512 x 512] of the Winograd F(4x4,3x3) 3x3 s1 "
                           "512->512 layer, B=%d 16x52 (level 3), as bf16 x 3 split products (6 bf16 MFMA products per fp32 "
-                          "product, fp32 accumulate)" % (B * 8 * 26, B),
+                          "product, fp32 accumulate)" % (B * 4 * 13, B),
                 "bound": "mfma", "unit": "TFLOP/s",
                 "achieved": round(ax, 2), "peak": round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1), "frac": round(6.0 * ax / PEAK_BF16_MFMA_TFLOPS, 4),
                 "note": "achieved = ALGORITHMIC fp32 FLOPs (2 M N K per bin) / time; peak = what the pipe the kernel runs on can "
@@ -706,9 +711,12 @@ def main():
                         "same figure is frac_of_fp32_mfma_peak",
                 "executed_bf16_tflops": round(6.0 * ax, 1), "bf16_peak": PEAK_BF16_MFMA_TFLOPS,
                 "frac_of_fp32_mfma_peak": round(ax / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": pmc_traffic("r03_gemm_x3_pmc.json"),
-                "gflop_per_launch": round(fl_g / 1e9, 2), "ms_per_launch": round(ms_x, 4),
-                "fp32_mfma_kernel": {"kernel": "wino_gemm_kernel<64,64> (round 2's dominant kernel; GDN_X3=0)", "ms_per_launch": round(ms_g, 4),
+                "traffic": pmc_traffic("r04_gemm_x3_pmc.json"),
+                "gflop_per_launch": round(fl_x / 1e9, 2), "ms_per_launch": round(ms_x, 4),
+                "sustained_pipe_note": "with operands that are not constant the matrix pipe at full issue rate runs at 1.90-1.97 GHz "
+                                       "on this chip (tests/diag/mfma_rate.hip, profiles/r04d_mfma_rate.txt: 1914-1965 TFLOP/s for a "
+                                       "loop of nothing but v_mfma_f32_32x32x16_bf16): 0.78 of the 2.5 PF this record prices against",
+                "fp32_mfma_kernel": {"kernel": "wino_gemm_kernel<64,64> on the F(2x2,3x3) shape, 16 x [4160 x 512] x [512 x 512] (round 2's dominant kernel; GDN_X3=0)", "ms_per_launch": round(ms_g, 4),
                                      "achieved": round(ag, 2), "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(ag / PEAK_F32_MFMA_TFLOPS, 4),
                                      "traffic": pmc_traffic("r02_wino_gemm_pmc.json")},
                 "layer_forward": {"ms": round(ms_l, 4), "direct_conv_gflop": round(fl_l / 1e9, 2),

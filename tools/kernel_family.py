@@ -10,7 +10,7 @@ FFT = re.compile(r"fft|cgemm")
 
 
 def family(n):
-    if re.search(r"gemm_x3|x3_pack|wino_weights_x3", n):
+    if re.search(r"gemm_x3|x3_pack|x3r_combine|wino4?_weights_x3", n):
         return "winograd+x3 (bf16 x 3 GEMMs)"
     if FFT.search(n):
         return "fft chain"

@@ -675,9 +675,10 @@ bool wino_geom(const gdn_conv_geom* g, WinoGeom& f) {
     f.T = 2; f.bins = WINO_BINS;
     // F(4x4,3x3) where every GEMM of the layer runs as bf16 x 3 split products (the transformed weights exist as panels only),
     // the border is zero padding, and rounding the image up to whole 4 x 4 tiles computes at most 15 % more pixels.
-    // GDN_WINO_F4=0 (measurement / test hook, read per plan): F(2x2,3x3) everywhere.
-    const char* e = getenv("GDN_WINO_F4");
-    if (f.x3 && !f.reflect && g->H >= 4 && g->W >= 4 && !(e && e[0] == '0')) {
+    // GDN_HINT_NO_WINO_F4 in the geometry keeps F(2x2,3x3) (A/B measurements, accuracy studies; gdn_amd/ops.py: set_wino_f4).  Like
+    // the bf16 x 3 switch it is part of the geometry -- no environment read -- so the forward that lays out the saved state and the
+    // backward that reads it agree on the plan by construction.
+    if (f.x3 && !f.reflect && g->H >= 4 && g->W >= 4 && !(g->hints & GDN_HINT_NO_WINO_F4)) {
         const int ty = cdiv(g->H, 4), tx = cdiv(g->W, 4), M4 = g->B * ty * tx;
         const bool fits = (int64_t)ty * tx * 16 * 100 <= (int64_t)g->H * g->W * 115;
         if (fits && gemm_x3_ok(M4, f.N, f.C) && gemm_x3_ok(M4, f.C, f.N) && gemm_x3_tn_ok(M4, f.N, f.C)) {

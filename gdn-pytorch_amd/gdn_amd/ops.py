@@ -44,7 +44,7 @@ def _chk(t, name="tensor", bf16_ok=False):
 
 
 CFG_BF16 = 0x10000      # GDN_CFG_BF16
-HINT_TRAIN, HINT_NO_X3 = 1, 2      # GDN_HINT_* bits of gdn_conv_geom.hints
+HINT_TRAIN, HINT_NO_X3, HINT_NO_WINO_F4 = 1, 2, 4      # GDN_HINT_* bits of gdn_conv_geom.hints
 
 # bf16 x 3 split products for the Winograd per-bin GEMMs.  The switch lives HERE, not in the library: the
 # environment variable GDN_X3 is read once, at import; distributed._guard_shared_gpu (ranks sharing one GPU), tests and
@@ -75,6 +75,27 @@ def set_x3(on, explicit=False):
 def _state_x3(state):
     """The switch a forward wrote `state` under (None: stateless call, use the current one)."""
     return getattr(state, "_gdn_x3", None) if state is not None else None
+
+
+# Winograd F(4x4,3x3) for the zero-padded 3x3 layers (DESIGN.md 2.5): GDN_WINO_F4=0 in the environment at import, or
+# set_wino_f4(False), keeps F(2x2,3x3) -- carried to the library as GDN_HINT_NO_WINO_F4 in every geometry, like the switch above
+# (the saved state of a forward is laid out for the plan it was written under; its backward passes the same hint).
+_f4 = os.environ.get("GDN_WINO_F4", "1")[:1] != "0"
+
+
+def wino_f4_enabled():
+    return _f4
+
+
+def set_wino_f4(on):
+    """Switch the F(4x4,3x3) plan on / off for every layer planned from now on; returns the previous setting."""
+    global _f4
+    prev, _f4 = _f4, bool(on)
+    return prev
+
+
+def _state_f4(state):
+    return getattr(state, "_gdn_f4", None) if state is not None else None
 
 
 def _bf(t):
@@ -141,10 +162,12 @@ class Conv:
         self._geom = {}
         self._fwd_ws = {}
 
-    def geom(self, B, H, W, hints=0, x3=None):
-        """x3: None = the current switch; a saved state's backward passes what its forward used."""
+    def geom(self, B, H, W, hints=0, x3=None, f4=None):
+        """x3 / f4: None = the current switch; a saved state's backward passes what its forward used."""
         if not (_x3 if x3 is None else x3):
             hints |= HINT_NO_X3
+        if not (_f4 if f4 is None else f4):
+            hints |= HINT_NO_WINO_F4
         key = (B, H, W, hints)
         g = self._geom.get(key)
         if g is None:
@@ -332,6 +355,7 @@ class Conv:
         sv = torch.empty(int(lib.gdn_winoconv_state_bytes(ref)), dtype=torch.uint8, device=x.device) if state else None
         if sv is not None:
             sv._gdn_x3 = _x3                 # the form of the saved weight set (fp32 / bf16 x 3 panels) follows the switch
+            sv._gdn_f4 = _f4                 # ... and the layout of the saved input transform (16 / 36 bins) the plan
         ws = workspace(nb, x.device, "fft")
         lib.gdn_winoconv_fwd(ref, _p(x), _ld(x), _p(w_tap), _p(y), _ld(y), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
                              _p(st), _p(affine[0]) if affine else None, _p(affine[1]) if affine else None, int(act),
@@ -351,7 +375,7 @@ class Conv:
         _chk(dy, "dy")
         B = dy.shape[0]
         H, W = in_hw
-        _, ref, Ho, Wo = self.geom(B, H, W, x3=_state_x3(state))
+        _, ref, Ho, Wo = self.geom(B, H, W, x3=_state_x3(state), f4=_state_f4(state))
         nb = int(lib.gdn_winoconv_bwd_workspace_bytes(ref))
         if nb == 0:
             raise GdnError("winoconv: unsupported layer k=%d stride=%d" % (self.k, self.stride))

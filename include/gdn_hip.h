@@ -40,7 +40,7 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
-/* Revision of this header (argument lists, struct layouts).  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+/* Revision of this header (argument lists, struct layouts).  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
  * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
@@ -71,11 +71,13 @@ typedef struct {
  * frequency-domain path then tiles for the sum of both passes: 40-point tiles (32 valid outputs of a 9x9 window: 128 x 416
  * is exactly 4 x 13 of them, 26 % fewer transformed points) shorten the three per-bin GEMM chains of a training step by a
  * quarter but make the forward's single-pass transforms slower, so inference / frozen layers keep the 32-point tiles. */
-enum { GDN_HINT_TRAIN = 1, GDN_HINT_NO_X3 = 2 };
+enum { GDN_HINT_TRAIN = 1, GDN_HINT_NO_X3 = 2, GDN_HINT_NO_WINO_F4 = 4 };
 /* GDN_HINT_NO_X3: the Winograd paths (gdn_winoconv_*, gdn_wino2conv_*) run their per-bin GEMMs on the fp32 matrix
  * instruction instead of as bf16 x 3 split products (gdn_gemm_x3_*).  Same results to rounding.  The library reads no
  * environment variable for this: the caller decides once (gdn_amd/ops.py: set_x3; ranks that share one GPU switch it off,
- * DESIGN.md 2.10) and the form of a forward's saved weight set follows the geometry its backward is called with. */
+ * DESIGN.md 2.10) and the form of a forward's saved weight set follows the geometry its backward is called with.
+ * GDN_HINT_NO_WINO_F4: gdn_winoconv_* plans F(2x2,3x3) where it would plan F(4x4,3x3) (zero-padded 3x3 layers whose GEMMs are
+ * bf16 x 3 eligible); results differ by rounding only, the layout of the saved state follows the plan. */
 
 enum { GDN_ACT_NONE = 0, GDN_ACT_TANH = 1, GDN_ACT_RELU = 2 };   /* bit flags */
 

@@ -131,3 +131,32 @@ def test_winoconv_reflection_pad(gpu, case):
     close(dw, tapmajor(wr.grad, False), what="wgrad")
     close(nchw(op.wino_bwd(nhwc(gy).to(gpu), wd, (H, W))), xr.grad, what="dgrad only")
     close(y, op.fwd(xd, wd), what="fwd vs direct")
+
+
+def test_winoconv_plan_switch_travels_with_the_state(gpu):
+    """F(4x4,3x3) / F(2x2,3x3) is part of the geometry (GDN_HINT_NO_WINO_F4), not an environment read: a forward's saved state
+    (36 or 16 bins) is read back by its backward under the plan it was written with even if the switch moved in between, and
+    the two plans agree with each other to rounding."""
+    from gdn_amd import ops
+    C, B, H, W = 128, 2, 8, 12
+    gen = torch.Generator(device=gpu).manual_seed(4)
+    x = torch.randn(B, H, W, C, device=gpu, generator=gen)
+    w = torch.randn(9, C, C, device=gpu, generator=gen) / (C * 9) ** 0.5
+    g = torch.randn(B, H, W, C, device=gpu, generator=gen)
+    op = ops.Conv(C, C, 3, 1, 1)
+    prev = ops.set_wino_f4(True)
+    try:
+        y4, sv4 = op.wino_fwd(x, w, state=True)
+        ops.set_wino_f4(False)
+        y2, sv2 = op.wino_fwd(x, w, state=True)
+        assert sv4.numel() != sv2.numel()                       # 36 x 6 tiles against 16 x 24 tiles of transformed input
+        dw4, dw2 = torch.empty_like(w), torch.empty_like(w)
+        dx4 = op.wino_bwd(g, w, (H, W), state=sv4, dw_tap=dw4)  # switch is OFF now: the state carries its own plan
+        ops.set_wino_f4(True)
+        dx2 = op.wino_bwd(g, w, (H, W), state=sv2, dw_tap=dw2)  # ... and ON here
+    finally:
+        ops.set_wino_f4(prev)
+    close(y4, y2, rtol=1e-4, atol_scale=2e-5, what="fwd F4 vs F2")
+    close(dx4, dx2, rtol=1e-4, atol_scale=2e-5, what="dgrad F4 vs F2")
+    close(dw4, dw2, rtol=1e-4, atol_scale=2e-5, what="wgrad F4 vs F2")
+    close(y4, op.fwd(x, w), rtol=1e-4, atol_scale=2e-5, what="fwd F4 vs direct")

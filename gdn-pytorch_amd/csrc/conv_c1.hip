@@ -26,45 +26,53 @@ struct C1Geom {
     int pad, reflect, flip;
 };
 
-__device__ __forceinline__ float c1_fetch(const float* __restrict__ img, int H, int W, int y, int x, int reflect, int pad) {
+// pixel (y, x) of an image whose pixels are `cs` floats apart (cs = 1: a single-channel image; 3: one channel of an RGB one)
+__device__ __forceinline__ float c1_fetch(const float* __restrict__ img, int H, int W, int y, int x, int reflect, int pad, int cs = 1) {
     if (reflect) {
         if (y < -pad || y >= H + pad || x < -pad || x >= W + pad) return 0.f;      // only feeds outputs beyond the image
         y = y < 0 ? -y : (y >= H ? 2 * H - 2 - y : y);
         x = x < 0 ? -x : (x >= W ? 2 * W - 2 - x : x);
-        return img[(size_t)y * W + x];
+        return img[((size_t)y * W + x) * cs];
     }
-    return (y >= 0 && y < H && x >= 0 && x < W) ? img[(size_t)y * W + x] : 0.f;
+    return (y >= 0 && y < H && x >= 0 && x < W) ? img[((size_t)y * W + x) * cs] : 0.f;
 }
 
-// y[p][n] = sum_tap x1[p + tap - pad] * w[tap][n]  (+ epilogue).  A workgroup stages the 81 x 64 weights once ([ky][kx pad 10][64],
-// 23 KB) and walks 8 x 32 pixel tiles (persistent grid); wave w owns rows 2w, 2w+1 of a tile: 2 pixel tiles x 2 channel
-// tiles of 32 x 32.  stats slot = tile.
+// y[p][n] = sum_{tap, c} x1[p + tap - pad][c] * w[tap][n][c]  (+ epilogue).  A workgroup stages the 81 x 64 (x CIN) weights once
+// ([c][ky][kx pad 10][64], 23 KB per input channel) and walks 8 x 32 pixel tiles (persistent grid); wave w owns rows 2w, 2w+1 of a
+// tile: 2 pixel tiles x 2 channel tiles of 32 x 32.  stats slot = tile.  CIN = 1: the depth networks' first layer and the heads'
+// data gradient; CIN = 3 (round 4): R's first layer Conv2d(3, 64, 9) after ReflectionPad2d(4) (AE_model_unet.py:273), whose
+// implicit-GEMM form gathers 243 scalars per output (942 us at B = 20 against 0.23 ms of fp32 MFMA time).
+template <int CIN>
 __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ w, void* __restrict__ y,
                                                           int ldy, const void* __restrict__ addsrc, int ld_add, int dtypes,
                                                           float* __restrict__ stats, const float* __restrict__ ep_scale,
                                                           const float* __restrict__ ep_shift, int act, C1Geom g, int tiles_x,
                                                           int tiles_y) {
-    __shared__ float patch[C1_PH * C1_PW];
-    __shared__ float wl[C1_K * C1_KP * C1_N];
+    constexpr int PSZ = C1_PH * C1_PW, WSZ = C1_K * C1_KP * C1_N;
+    __shared__ float patch[CIN * PSZ];
+    __shared__ float wl[CIN * WSZ];
     __shared__ float red[4 * 2 * C1_N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
-    for (int i = tid; i < C1_K * C1_K * C1_N; i += 256) {           // source order: coalesced, no pad column
-        const int n = i & (C1_N - 1), tap = i >> 6, ky = tap / C1_K, kx = tap - ky * C1_K;
+    for (int i = tid; i < C1_K * C1_K * C1_N * CIN; i += 256) {     // source order [tap][n][c]: coalesced, no pad column
+        const int c = i % CIN, i1 = i / CIN, n = i1 & (C1_N - 1), tap = i1 >> 6, ky = tap / C1_K, kx = tap - ky * C1_K;
         const int src = g.flip ? (C1_K * C1_K - 1 - tap) : tap;
-        wl[(ky * C1_KP + kx) * C1_N + n] = w[(size_t)src * C1_N + n];
+        wl[c * WSZ + (ky * C1_KP + kx) * C1_N + n] = w[((size_t)src * C1_N + n) * CIN + c];
     }
-    for (int i = tid; i < C1_K * C1_N; i += 256) wl[((i >> 6) * C1_KP + C1_K) * C1_N + (i & (C1_N - 1))] = 0.f;   // pad tap kx = 9
+    for (int i = tid; i < C1_K * C1_N * CIN; i += 256) {            // pad tap kx = 9
+        const int c = i / (C1_K * C1_N), r = i - c * (C1_K * C1_N);
+        wl[c * WSZ + ((r >> 6) * C1_KP + C1_K) * C1_N + (r & (C1_N - 1))] = 0.f;
+    }
     const float* pa = patch + (2 * wave) * C1_PW + l32 + h;        // + (mt + ky) * PW + 2j
     const float* pb = wl + h * C1_N + l32;                         // + (ky * KP + 2j) * N + nt * 32
     const int ntiles = g.B * tiles_y * tiles_x;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
         const int x0 = tx * C1_TW, y0 = ty * C1_TH;
-        const float* img = x1 + (size_t)b * g.H * g.W;
+        const float* img = x1 + (size_t)b * g.H * g.W * CIN;
         __syncthreads();                                           // previous tile's patch / red fully consumed
-        for (int i = tid; i < C1_PH * C1_PW; i += 256) {            // (column 40 only meets the zero-weight pad tap: keep it finite)
-            const int py = i / C1_PW, px = i - py * C1_PW;
-            patch[i] = px < C1_TW + C1_K - 1 ? c1_fetch(img, g.H, g.W, y0 + py - g.pad, x0 + px - g.pad, g.reflect, g.pad) : 0.f;
+        for (int i = tid; i < CIN * PSZ; i += 256) {                // (column 40 only meets the zero-weight pad tap: keep it finite)
+            const int c = i / PSZ, i1 = i - c * PSZ, py = i1 / C1_PW, px = i1 - py * C1_PW;
+            patch[i] = px < C1_TW + C1_K - 1 ? c1_fetch(img + c, g.H, g.W, y0 + py - g.pad, x0 + px - g.pad, g.reflect, g.pad, CIN) : 0.f;
         }
         __syncthreads();
         f32x16 acc[2][2];
@@ -75,16 +83,18 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 #pragma unroll
-        for (int ky = 0; ky < C1_K; ++ky)
+        for (int c = 0; c < CIN; ++c)
 #pragma unroll
-            for (int j = 0; j < C1_KP / 2; ++j) {
-                const float a0 = pa[ky * C1_PW + 2 * j], a1 = pa[(ky + 1) * C1_PW + 2 * j];
-                const float b0 = pb[(ky * C1_KP + 2 * j) * C1_N], b1 = pb[(ky * C1_KP + 2 * j) * C1_N + 32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
+            for (int ky = 0; ky < C1_K; ++ky)
+#pragma unroll
+                for (int j = 0; j < C1_KP / 2; ++j) {
+                    const float a0 = pa[c * PSZ + ky * C1_PW + 2 * j], a1 = pa[c * PSZ + (ky + 1) * C1_PW + 2 * j];
+                    const float b0 = pb[c * WSZ + (ky * C1_KP + 2 * j) * C1_N], b1 = pb[c * WSZ + (ky * C1_KP + 2 * j) * C1_N + 32];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
         // epilogue: acc[mt][nt][r] = pixel (row y0 + 2*wave + mt, column x0 + (r&3) + 8*(r>>2) + 4*h), channel nt*32 + l32
         float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
@@ -273,17 +283,21 @@ extern "C" int64_t gdn_conv_c1_stats_slots(int32_t B, int32_t H, int32_t W) {
     return (int64_t)B * cdiv(H, C1_TH) * cdiv(W, C1_TW);
 }
 
-extern "C" int gdn_conv_c1_fwd(const float* x1, int32_t B, int32_t H, int32_t W, int32_t N, int32_t k, int32_t pad, int32_t reflect,
+extern "C" int gdn_conv_c1_fwd(const float* x1, int32_t Cin, int32_t B, int32_t H, int32_t W, int32_t N, int32_t k, int32_t pad, int32_t reflect,
                                int32_t flip, const float* w, void* y, int32_t ldy, const void* addsrc, int32_t ld_add,
                                float* stats, const float* ep_scale, const float* ep_shift, int32_t act, int32_t dtypes,
                                void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
-    if (!c1_ok(B, H, W, N, k, pad, reflect)) return GDN_ERR_UNSUPPORTED;
+    if (!c1_ok(B, H, W, N, k, pad, reflect) || (Cin != 1 && Cin != 3)) return GDN_ERR_UNSUPPORTED;
     if (!x1 || !w || !y || (!ep_scale) != (!ep_shift) || (act & GDN_ACT_TANH) || (dtypes & ~3)) return GDN_ERR_BAD_ARG;
     const C1Geom g = {B, H, W, pad, reflect ? 1 : 0, flip ? 1 : 0};
     const int tiles_x = cdiv(W, C1_TW), tiles_y = cdiv(H, C1_TH), ntiles = B * tiles_x * tiles_y;
-    hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3(ntiles < C1_FWD_WGS ? ntiles : C1_FWD_WGS), dim3(256), 0, (hipStream_t)stream, x1, w, y,
-                       ldy, addsrc, ld_add, (int)dtypes, stats, ep_scale, ep_shift, act, g, tiles_x, tiles_y);
+    if (Cin == 1)
+        hipLaunchKernelGGL(conv_c1_fwd_kernel<1>, dim3(ntiles < C1_FWD_WGS ? ntiles : C1_FWD_WGS), dim3(256), 0, (hipStream_t)stream, x1, w,
+                           y, ldy, addsrc, ld_add, (int)dtypes, stats, ep_scale, ep_shift, act, g, tiles_x, tiles_y);
+    else          // 77 KB of LDS per workgroup: two per CU
+        hipLaunchKernelGGL(conv_c1_fwd_kernel<3>, dim3(ntiles < C1_FWD_WGS / 2 ? ntiles : C1_FWD_WGS / 2), dim3(256), 0, (hipStream_t)stream,
+                           x1, w, y, ldy, addsrc, ld_add, (int)dtypes, stats, ep_scale, ep_shift, act, g, tiles_x, tiles_y);
     return gdn_launch_status();
 }
 

@@ -63,8 +63,8 @@ _SIGS = {
     "gdn_wino2conv_bwd_workspace_bytes": (_sz, [_PG]),
     "gdn_wino2conv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _sz, _P]),
     "gdn_conv_c1_stats_slots": (_i64, [_i32, _i32, _i32]),
-    "gdn_conv_c1_fwd": (c_int32, [_P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _i32,
-                                  _P]),
+    "gdn_conv_c1_fwd": (c_int32, [_P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32,
+                                  _i32, _P]),
     "gdn_conv_c1_wgrad_workspace_bytes": (_sz, []),
     "gdn_conv_c1_wgrad": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P, _P, _sz, _P]),
     "gdn_gemm_x3_packed_bytes": (_sz, [_i32, _i32, _i32]),
@@ -112,7 +112,7 @@ _STATUS_FUNCS = {n for n, (r, _) in _SIGS.items() if r is c_int32} - {"gdn_versi
 EXPORTS = tuple(_SIGS)
 # The C ABI revision these signatures (and ConvGeom's layout) describe: gdn_version() of the library must match exactly --
 # a stale build would take the arguments apart differently.
-ABI_VERSION = 215
+ABI_VERSION = 216
 
 
 class _Lib:

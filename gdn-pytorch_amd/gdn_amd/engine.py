@@ -577,9 +577,9 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
             xt = x.dense(ctx.dtype)      # (the direct kernels' loaders go straight to LDS: materialise)
     xf = None
     keep_xf = use_fft and ctx.record and conv.weight.requires_grad
-    use_c1 = (_C1 and not use_fft and ldt == torch.float32 and x2 is None and not lazy and conv.in_channels == 1
+    use_c1 = (_C1 and not use_fft and ldt == torch.float32 and x2 is None and not lazy and conv.in_channels in (1, 3)
               and not isinstance(conv, torch.nn.ConvTranspose2d)
-              and ops.c1_ok(x, conv.out_channels, conv.kernel_size[0], conv.stride[0], reflect or conv.padding[0]))
+              and ops.c1_ok(x, conv.out_channels, conv.kernel_size[0], conv.stride[0], reflect or conv.padding[0], rgb=True))
     if bn.training:
         if use_fft:
             r = alt_fwd(xt, w, stats=True, **{state_kw: keep_xf}, **in_kw, **hint_kw)
@@ -685,7 +685,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                     ctx.grads_done(bn.weight, bn.bias, conv.weight)
                 return
             if not frozen:
-                if use_c1 and dy.is_contiguous():
+                if use_c1 and dy.is_contiguous() and conv.in_channels == 1:
                     ops.conv_c1_wgrad(xt, dy, tap_view(conv.weight.grad, False), reflect=bool(reflect))
                 else:
                     _wgrad_into(ctx, conv, xt, dy, x2)

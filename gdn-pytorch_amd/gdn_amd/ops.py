@@ -463,25 +463,26 @@ class Conv:
                            _mask(x, dy), stream())
 
 
-def c1_ok(x1, n, k, stride, pad):
-    """The 1 <-> 64 channel 9x9 layers of csrc/conv_c1.hip: a dense fp32 single-channel image against 64 channels."""
-    return (x1.dtype == torch.float32 and x1.dim() == 4 and x1.shape[3] == 1 and x1.is_contiguous() and n == 64 and k == 9
-            and stride == 1 and pad == 4)
+def c1_ok(x1, n, k, stride, pad, rgb=False):
+    """The 1 <-> 64 channel 9x9 layers of csrc/conv_c1.hip: a dense fp32 single-channel image against 64 channels
+    (rgb: the forward also takes a 3-channel image, R's first layer)."""
+    return (x1.dtype == torch.float32 and x1.dim() == 4 and (x1.shape[3] == 1 or (rgb and x1.shape[3] == 3)) and x1.is_contiguous()
+            and n == 64 and k == 9 and stride == 1 and pad == 4)
 
 
 def conv_c1_fwd(x1, w81, reflect=False, flip=False, stats=False, addsrc=None, affine=None, act=ACT_NONE, out_dtype=torch.float32):
-    """y[B,H,W,64] = sum_tap x1[p + tap - 4] * w81[tap][:]; x1 [B,H,W,1], w81 any tensor of 81*64 floats in [tap][64] order.
-    y (out_dtype) and addsrc may be bf16: a bf16 model's head data gradient."""
+    """y[B,H,W,64] = sum_{tap,c} x1[p + tap - 4][c] * w81[tap][:][c]; x1 [B,H,W,Cin], Cin = 1 or 3, w81 any tensor of 81*64*Cin
+    floats in [tap][64][Cin] order.  y (out_dtype) and addsrc may be bf16: a bf16 model's head data gradient."""
     _chk(x1, "x1"); _chk(w81, "w")
     if x1.dtype != torch.float32 or w81.dtype != torch.float32:
-        raise GdnError("conv_c1_fwd: the single-channel image and the weights are fp32")
-    B, H, W, _ = x1.shape
-    if w81.numel() != 81 * 64 or not w81.is_contiguous():
-        raise GdnError("conv_c1_fwd: weights must be 81 x 64 contiguous floats")
+        raise GdnError("conv_c1_fwd: the image and the weights are fp32")
+    B, H, W, cin = x1.shape
+    if cin not in (1, 3) or w81.numel() != 81 * 64 * cin or not w81.is_contiguous() or not x1.is_contiguous():
+        raise GdnError("conv_c1_fwd: dense [B,H,W,1|3] image and 81 x 64 x Cin contiguous weights expected")
     y = torch.empty((B, H, W, 64), dtype=out_dtype, device=x1.device)
     st = torch.empty((int(lib.gdn_conv_c1_stats_slots(B, H, W)), 2, 64), dtype=torch.float32, device=x1.device) if stats else None
     dtypes = _is_bf16(y) | (_is_bf16(addsrc) << 1)
-    lib.gdn_conv_c1_fwd(_p(x1), B, H, W, 64, 9, 4, 1 if reflect else 0, 1 if flip else 0, _p(w81), _p(y), 64, _p(addsrc),
+    lib.gdn_conv_c1_fwd(_p(x1), cin, B, H, W, 64, 9, 4, 1 if reflect else 0, 1 if flip else 0, _p(w81), _p(y), 64, _p(addsrc),
                         0 if addsrc is None else _ld(addsrc), _p(st), _p(affine[0]) if affine else None,
                         _p(affine[1]) if affine else None, int(act), dtypes, stream())
     return (y, st) if stats else y

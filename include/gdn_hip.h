@@ -40,7 +40,7 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
-/* Revision of this header (argument lists, struct layouts).  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+/* Revision of this header (argument lists, struct layouts).  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
  * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
@@ -274,10 +274,12 @@ int gdn_wino2conv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, cons
  *   gdn_conv_c1_wgrad: dw[tap][n] = sum_p gw[p][n] * x1[p + tap - 4]   (gw [B,H,W,64], pitch ldg; result written at the flipped
  *                      tap when flip != 0).  The first convolution's weight gradient (x1 = input, gw = dy) and a head's
  *                      (x1 = d(pre-tanh), gw = the head's input; flip for a Conv2d head, none for a ConvTranspose2d one).
+ *   gdn_conv_c1_fwd also takes Cin = 3 (x1 [B,H,W,3], w [tap][64][3]): R's first convolution Conv2d(3, 64, 9) after
+ *   ReflectionPad2d(4), AE_model_unet.py:273 (its weight gradient stays on gdn_conv_wgrad).
  *   x1, w, stats, dw stay fp32.  dtypes of gdn_conv_c1_fwd: bit 0 = y is bf16, bit 1 = addsrc is bf16 (a bf16 model's head
  *   data gradient, rounded once after the fp32 add); gw_bf16 != 0: gw is bf16 (the head's bf16 input), ldg % 4 == 0 either way. */
 int64_t gdn_conv_c1_stats_slots(int32_t B, int32_t H, int32_t W);
-int gdn_conv_c1_fwd(const float* x1, int32_t B, int32_t H, int32_t W, int32_t N, int32_t k, int32_t pad, int32_t reflect,
+int gdn_conv_c1_fwd(const float* x1, int32_t Cin, int32_t B, int32_t H, int32_t W, int32_t N, int32_t k, int32_t pad, int32_t reflect,
                     int32_t flip, const float* w, void* y, int32_t ldy, const void* addsrc, int32_t ld_add,
                     float* stats, const float* ep_scale, const float* ep_shift, int32_t act, int32_t dtypes, void* stream);
 size_t gdn_conv_c1_wgrad_workspace_bytes(void);

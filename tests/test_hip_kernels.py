@@ -428,3 +428,22 @@ def test_conv_c1_layers(gpu, B, H, W, reflect, flip):
     ops.conv_c1_wgrad(x1d, gb, dwb, reflect=reflect, flip=flip)
     ops.conv_c1_wgrad(x1d, gb.float(), dw32, reflect=reflect, flip=flip)
     assert torch.equal(dwb, dw32)
+
+
+@pytest.mark.parametrize("B,H,W,reflect", [(2, 16, 64, True), (1, 13, 45, False), (1, 128, 416, True), (2, 5, 7, True)])
+def test_conv_c1_rgb_first_layer(gpu, B, H, W, reflect):
+    """R's first convolution, Conv2d(3, 64, 9) after ReflectionPad2d(4) (AE_model_unet.py:273), on the patch-staged MFMA
+    kernel of csrc/conv_c1.hip (CIN = 3) against torch's CPU conv2d, the BatchNorm partials and the direct kernel."""
+    from gdn_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + H + W)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 9, 9, generator=g) / (27 ** 0.5 * 3)
+    xp = F.pad(x, (4, 4, 4, 4), mode="reflect") if reflect else F.pad(x, (4, 4, 4, 4))
+    y_ref = F.conv2d(xp, w)
+    xd, wd = nhwc(x).to(gpu), tapmajor(w, False).to(gpu)            # [B,H,W,3], [81][64][3]
+    assert ops.c1_ok(xd, 64, 9, 1, 4, rgb=True) and not ops.c1_ok(xd, 64, 9, 1, 4)
+    y, st = ops.conv_c1_fwd(xd, wd, reflect=reflect, stats=True)
+    close(nchw(y), y_ref, what="rgb first layer")
+    close(st[:, 0].sum(0), y_ref.sum((0, 2, 3)), rtol=1e-3, atol_scale=1e-3, what="stats sum")
+    close(st[:, 1].sum(0), (y_ref ** 2).sum((0, 2, 3)), what="stats sumsq")
+    close(y, ops.Conv(3, 64, 9, 1, 4, reflect=reflect).fwd(xd, wd), what="vs direct kernel")

@@ -49,9 +49,10 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
                                                           const float* __restrict__ ep_shift, int act, C1Geom g, int tiles_x,
                                                           int tiles_y) {
     constexpr int PSZ = C1_PH * C1_PW, WSZ = C1_K * C1_KP * C1_N;
-    __shared__ float patch[CIN * PSZ];
+    __shared__ __attribute__((aligned(16))) float patch[CIN * PSZ];
     __shared__ float wl[CIN * WSZ];
     __shared__ float red[4 * 2 * C1_N];
+    __shared__ __attribute__((aligned(16))) float scr1[CIN == 1 ? 4 * 256 : 4];        // epilogue scratch (CIN = 3: the patch)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
     for (int i = tid; i < C1_K * C1_K * C1_N * CIN; i += 256) {     // source order [tap][n][c]: coalesced, no pad column
         const int c = i % CIN, i1 = i / CIN, n = i1 & (C1_N - 1), tap = i1 >> 6, ky = tap / C1_K, kx = tap - ky * C1_K;
@@ -95,8 +96,14 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
                 }
-        // epilogue: acc[mt][nt][r] = pixel (row y0 + 2*wave + mt, column x0 + (r&3) + 8*(r>>2) + 4*h), channel nt*32 + l32
+        // epilogue: acc[mt][nt][r] = pixel (row y0 + 2*wave + mt, column x0 + (r&3) + 8*(r>>2) + 4*h), channel nt*32 + l32.
+        // The tile leaves through a 1 KB per-wave LDS transposition, 8 pixels x 32 channels at a time: 16-byte stores (8 lanes =
+        // the 128 bytes of one pixel's 32 channels) instead of 4-byte stores in the MFMA layout -- the kernel was store-issue-bound
+        // (272 MB in 216 us at B = 20).  CIN = 3 has no LDS to spare (two workgroups per CU): its scratch is the patch.
         float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+        if (CIN != 1) __syncthreads();                             // every wave is done reading the patch
+        float* scr = (CIN == 1 ? scr1 : patch) + wave * 256;
+        const int rrow = lane >> 3, rc4 = (lane & 7) * 4;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int oy = y0 + 2 * wave + mt;
@@ -105,16 +112,23 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
                 const int n = nt * 32 + l32;
                 const float es = ep_scale ? ep_scale[n] : 1.f, et = ep_shift ? ep_shift[n] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (oy < g.H && ox < g.W) {
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * q + e, ox = x0 + 8 * q + e + 4 * h;
                         float val = acc[mt][nt][r];
-                        s1[nt] += val; s2[nt] += val * val;
+                        if (oy < g.H && ox < g.W) { s1[nt] += val; s2[nt] += val * val; }
                         if (ep_scale) val = val * es + et;
                         if (act & GDN_ACT_RELU) val = fmaxf(val, 0.f);
+                        scr[(e + 4 * h) * 32 + l32] = val;
+                    }
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&scr[rrow * 32 + rc4]);
+                    const int ox = x0 + 8 * q + rrow;
+                    if (oy < g.H && ox < g.W) {
                         const size_t px = (size_t)(b * g.H + oy) * g.W + ox;
-                        if (addsrc) val += ld1_any(addsrc, px * ld_add + n, dtypes & 2);
-                        st1_any(y, px * ldy + n, val, dtypes & 1);
+                        f32x4 o = v;
+                        if (addsrc) o += ld4_any(addsrc, px * ld_add + nt * 32 + rc4, dtypes & 2);
+                        st4_any(y, px * ldy + nt * 32 + rc4, o, dtypes & 1);
                     }
                 }
             }
@@ -290,6 +304,7 @@ extern "C" int gdn_conv_c1_fwd(const float* x1, int32_t Cin, int32_t B, int32_t 
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!c1_ok(B, H, W, N, k, pad, reflect) || (Cin != 1 && Cin != 3)) return GDN_ERR_UNSUPPORTED;
     if (!x1 || !w || !y || (!ep_scale) != (!ep_shift) || (act & GDN_ACT_TANH) || (dtypes & ~3)) return GDN_ERR_BAD_ARG;
+    if ((ldy % 4) || (addsrc && (ld_add % 4))) return GDN_ERR_UNSUPPORTED;          // 16-byte (fp32) / 8-byte (bf16) accesses
     const C1Geom g = {B, H, W, pad, reflect ? 1 : 0, flip ? 1 : 0};
     const int tiles_x = cdiv(W, C1_TW), tiles_y = cdiv(H, C1_TH), ntiles = B * tiles_x * tiles_y;
     if (Cin == 1)

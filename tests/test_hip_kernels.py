@@ -447,3 +447,9 @@ def test_conv_c1_rgb_first_layer(gpu, B, H, W, reflect):
     close(st[:, 0].sum(0), y_ref.sum((0, 2, 3)), rtol=1e-3, atol_scale=1e-3, what="stats sum")
     close(st[:, 1].sum(0), (y_ref ** 2).sum((0, 2, 3)), what="stats sumsq")
     close(y, ops.Conv(3, 64, 9, 1, 4, reflect=reflect).fwd(xd, wd), what="vs direct kernel")
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    res = torch.randn(B, 64, H, W, generator=g)
+    y2 = ops.conv_c1_fwd(xd, wd, reflect=reflect, addsrc=nhwc(res).to(gpu), affine=(sc.to(gpu), sh.to(gpu)), act=ops.ACT_RELU)
+    close(nchw(y2), torch.relu(y_ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + res, what="rgb epilogue")
+    y3 = ops.conv_c1_fwd(xd, wd, reflect=reflect)                       # twice in a row on the same stream: the scratch is the patch
+    assert torch.equal(y3, y)

@@ -220,7 +220,11 @@ def test_input_gradient_vs_oracle(gpu, name):
     out = model(xg, istrain=False)
     close_abs(out, out_ref, 1e-3, what=name + " eval forward")
     out.backward(gy.to(gpu))
-    close(xg.grad, xr.grad, rtol=5e-3, atol_scale=5e-3, what=name + " d out / d input")
+    # outliers: a first-layer pre-activation within rounding of zero takes the other side of its ReLU under a different (equally
+    # valid) summation order -- one such flip moves the 9 x 9 x C input gradients under that output by ~1 % of the largest one
+    # (seen with the patch-staged 3-channel first-layer kernel: 62 of 6144 elements in one 9 x 9 block, outputs equal to 1.3e-7)
+    close(xg.grad, xr.grad, rtol=5e-3, atol_scale=5e-3, what=name + " d out / d input", outliers=2e-2)
+    close(xg.grad, xr.grad, rtol=5e-2, atol_scale=5e-2, what=name + " d out / d input, every element")
 
 
 def test_cli_augment_latent_grad_bf16_smoke(gpu, tmp_path, monkeypatch):

@@ -10,6 +10,7 @@
 // instead of four v_fma.  Weights are wave-uniform (scalar loads).  HBM traffic: the input once (272 MB at B=20) + 4 B
 // per pixel out.  Mixed-precision path: x may hold bf16 (weights and the depth map stay fp32).
 #include "common.h"
+#include "gemm_x3.h"
 
 namespace {
 
@@ -111,9 +112,16 @@ __device__ __forceinline__ unsigned hm_bf16_rn(float f) {
     return u >> 16;
 }
 
-__global__ __launch_bounds__(256) void conv_head_mfma_bf16_kernel(const unsigned short* __restrict__ x, int ldx, const float* __restrict__ w,
-                                                                  float* __restrict__ y, int B, int H, int W, int pad, int flip, int act,
-                                                                  int strips, int segs) {
+// XF32 (round 4): fp32 activations -- the loader wave splits every value into three exact bf16 terms (x3_split2, gemm_x3.h) and
+// writes three images; the tap waves run the six products of the bf16 x 3 scheme (w1 x1 into one accumulator, the five correction
+// products into a second one, as gemm_x3.hip does): the fp32 head on the matrix pipe, 440 -> ~250 us at B = 20.
+template <bool XF32>
+__global__ __launch_bounds__(256) void conv_head_mfma_kernel(const void* __restrict__ xv, int ldx, const float* __restrict__ w,
+                                                             float* __restrict__ y, int B, int H, int W, int pad, int flip, int act,
+                                                             int strips, int segs) {
+    const unsigned short* __restrict__ x = reinterpret_cast<const unsigned short*>(xv);
+    const float* __restrict__ xf = reinterpret_cast<const float*>(xv);
+    constexpr int NX = XF32 ? 3 : 1;                                  // bf16 images of an input row
     __shared__ float Dl[2][96][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
@@ -156,24 +164,49 @@ __global__ __launch_bounds__(256) void conv_head_mfma_bf16_kernel(const unsigned
     // waves read their B fragments from there.  (Fragment-shaped loads straight into the MFMA waves' registers -- 32 lines per
     // instruction, three times over -- kept the texture addresser busy 8x as long: 191 us instead of 130 at B = 20; the VALU kernel above: 440.)
     // image: [pixel q][8 chunks of 16 B], chunk XOR-permuted by (q >> 1) & 7 (conflict-free ds_read_b128 over 32 pixels)
-    __shared__ __attribute__((aligned(16))) unsigned char Xl[2][32 * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char Xl[NX][2][32 * 128];
     constexpr int PF = 4;
+    constexpr int NL = XF32 ? 6 : 3;                                 // 16-byte loads per lane and row (fp32: two 32-channel halves per pixel)
     const int lq = lane >> 3, lc = lane & 7;                         // loader: pixel within a piece of 8, logical chunk
-    uint4 ring[PF][3];
-    auto load_row = [&](int iy, uint4 (&f)[3]) {
+    uint4 ring[PF][NL];
+    auto load_row = [&](int iy, uint4 (&f)[NL]) {
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
             const int q = e * 8 + lq, col = x0 - pad + q;
             const bool ok = (unsigned)iy < (unsigned)H && (unsigned)col < (unsigned)W;
-            const uint4 v = *reinterpret_cast<const uint4*>(x + ((size_t)b * H * W + (size_t)(ok ? iy : 0) * W + (ok ? col : 0)) * ldx + 8 * lc);
-            f[e] = ok ? v : uint4{0u, 0u, 0u, 0u};
+            const size_t px = ((size_t)b * H * W + (size_t)(ok ? iy : 0) * W + (ok ? col : 0)) * ldx;
+            if constexpr (XF32) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(xf + px + 32 * hh + 4 * lc);
+                    f[2 * e + hh] = ok ? v : uint4{0u, 0u, 0u, 0u};
+                }
+            } else {
+                const uint4 v = *reinterpret_cast<const uint4*>(x + px + 8 * lc);
+                f[e] = ok ? v : uint4{0u, 0u, 0u, 0u};
+            }
         }
     };
-    auto store_row = [&](int slot, const uint4 (&f)[3]) {
+    auto store_row = [&](int slot, const uint4 (&f)[NL]) {
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
             const int q = e * 8 + lq;
-            *reinterpret_cast<uint4*>(&Xl[slot][q * 128 + ((lc ^ ((q >> 1) & 7)) << 4)]) = f[e];
+            if constexpr (XF32) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    // channels 32 hh + 4 lc .. + 3: half of the 16-byte chunk lc / 2 + 4 hh of each term's image
+                    const uint4 v = f[2 * e + hh];
+                    unsigned p0[3], p1[3];
+                    x3_split2(__uint_as_float(v.x), __uint_as_float(v.y), p0[0], p0[1], p0[2]);
+                    x3_split2(__uint_as_float(v.z), __uint_as_float(v.w), p1[0], p1[1], p1[2]);
+                    const int chunk = (lc >> 1) + 4 * hh;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        *reinterpret_cast<uint2*>(&Xl[p][slot][q * 128 + ((chunk ^ ((q >> 1) & 7)) << 4) + (lc & 1) * 8]) = uint2{p0[p], p1[p]};
+                }
+            } else {
+                *reinterpret_cast<uint4*>(&Xl[0][slot][q * 128 + ((lc ^ ((q >> 1) & 7)) << 4)]) = f[e];
+            }
         }
     };
     const int s9 = tid / HM_SW, ox = tid % HM_SW;                    // gather role (tid < 144)
@@ -185,7 +218,9 @@ __global__ __launch_bounds__(256) void conv_head_mfma_bf16_kernel(const unsigned
         store_row(0, ring[0]);
         load_row(iy_lo + PF, ring[0]);
     }
-    if (tid < 128) *reinterpret_cast<uint4*>(&Xl[tid >> 6][(24 + ((tid >> 3) & 7)) * 128 + ((tid & 7) << 4)]) = uint4{0u, 0u, 0u, 0u};   // patch pixels 24..31: zeros
+#pragma unroll
+    for (int p = 0; p < NX; ++p)
+        if (tid < 128) *reinterpret_cast<uint4*>(&Xl[p][tid >> 6][(24 + ((tid >> 3) & 7)) * 128 + ((tid & 7) << 4)]) = uint4{0u, 0u, 0u, 0u};   // patch pixels 24..31: zeros
     __syncthreads();
     const unsigned bq = (unsigned)r * 128u, bkey = (unsigned)((r >> 1) & 7);
     for (int iy0 = iy_lo; iy0 <= iy_hi; iy0 += PF) {
@@ -196,17 +231,29 @@ __global__ __launch_bounds__(256) void conv_head_mfma_bf16_kernel(const unsigned
             const int buf = j & 1;
             const bool in_img = (unsigned)iy < (unsigned)H;
             if (wave < 3 && in_img) {
-                hm_f32x16 acc;
+                hm_f32x16 acc, cor;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                for (int e = 0; e < 16; ++e) { acc[e] = 0.f; cor[e] = 0.f; }
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) {
-                    const hm_bf16x8 bf = __builtin_bit_cast(hm_bf16x8, *reinterpret_cast<const uint4*>(&Xl[buf][bq + ((((unsigned)(2 * s2 + h)) ^ bkey) << 4)]));
+                    const unsigned off = bq + ((((unsigned)(2 * s2 + h)) ^ bkey) << 4);
+                    const hm_bf16x8 b0 = __builtin_bit_cast(hm_bf16x8, *reinterpret_cast<const uint4*>(&Xl[0][buf][off]));
+                    if constexpr (XF32) {
+                        const hm_bf16x8 b1 = __builtin_bit_cast(hm_bf16x8, *reinterpret_cast<const uint4*>(&Xl[1][buf][off]));
+                        const hm_bf16x8 b2 = __builtin_bit_cast(hm_bf16x8, *reinterpret_cast<const uint4*>(&Xl[NX - 1][buf][off]));
+                        cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[2][s2], b0, cor, 0, 0, 0);
+                        cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][s2], b1, cor, 0, 0, 0);
+                        cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][s2], b2, cor, 0, 0, 0);
+                        cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][s2], b0, cor, 0, 0, 0);
+                        cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][s2], b1, cor, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][s2], b0, acc, 0, 0, 0);
+                    } else {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[p][s2], bf, acc, 0, 0, 0);
+                        for (int p = 0; p < 3; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[p][s2], b0, acc, 0, 0, 0);
+                    }
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) Dl[buf][wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h][r] = acc[e];
+                for (int e = 0; e < 16; ++e) Dl[buf][wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h][r] = XF32 ? acc[e] + cor[e] : acc[e];
             }
             if (wave == 3) {
                 // ring[(j + 1) % PF] holds row iy + 1 (ring[j] was re-used for row iy + PF one iteration ago, or in the prologue)
@@ -250,13 +297,17 @@ int gdn_conv_head_fwd(const gdn_conv_geom* g, const void* x, int32_t ldx, const 
     const int pad = g->transposed ? g->k - 1 - g->pad : g->pad;
     const int Ho = g->H + 2 * pad - g->k + 1, Wo = g->W + 2 * pad - g->k + 1;
     if (Ho != g->H || Wo != g->W) return GDN_ERR_UNSUPPORTED;      // "same" heads only
-    if (x_bf16 && g->Cin == 64 && (ldx % 8) == 0) {
+    if (g->Cin == 64 && (ldx % (x_bf16 ? 8 : 4)) == 0) {
         // bf16 activations: the matrix-pipe kernel; every image is cut into row segments until the grid gives a CU ~4 workgroups
         const int strips = cdiv(g->W, HM_SW);
         int segs = 1;
         while (segs < 8 && (int64_t)strips * g->B * segs < 1024 && g->H / (segs * 2) >= 16) segs *= 2;
-        hipLaunchKernelGGL(conv_head_mfma_bf16_kernel, dim3(strips * segs * g->B), dim3(256), 0, (hipStream_t)stream,
-                           (const unsigned short*)x, ldx, w, y, g->B, g->H, g->W, pad, g->transposed ? 1 : 0, act, strips, segs);
+        if (!x_bf16)
+            hipLaunchKernelGGL(conv_head_mfma_kernel<true>, dim3(strips * segs * g->B), dim3(256), 0, (hipStream_t)stream, x, ldx, w, y, g->B,
+                               g->H, g->W, pad, g->transposed ? 1 : 0, act, strips, segs);
+        else
+        hipLaunchKernelGGL(conv_head_mfma_kernel<false>, dim3(strips * segs * g->B), dim3(256), 0, (hipStream_t)stream,
+                           x, ldx, w, y, g->B, g->H, g->W, pad, g->transposed ? 1 : 0, act, strips, segs);
         return gdn_launch_status();
     }
     const int tiles_x = cdiv(g->W, HD_TW), tiles_y = cdiv(g->H, HD_TH);

@@ -521,3 +521,9 @@ def test_head_bf16_on_the_matrix_pipe(gpu, tr, B, H, W):
         y = op.fwd(xd, w_tap.to(gpu), act=act)
         assert y.dtype == torch.float32 and tuple(y.shape) == (B, H, W, 1)
         close(nchw(y), rf, rtol=1e-3, atol_scale=1e-4, what="bf16 head tr=%s act=%d" % (tr, act))
+    # fp32 activations take the same kernel with the activations split into three exact bf16 terms as well (six products):
+    # full fp32 operands against an fp64 reference, at the fp32 bar of the VALU kernel this replaces
+    x32 = torch.randn(B, 64, H, W, generator=g) * torch.logspace(-2, 1, 64).view(1, 64, 1, 1)
+    ref64 = (F.conv_transpose2d(x32.double(), wt.double(), stride=1, padding=4) if tr else F.conv2d(x32.double(), w.double(), padding=4))
+    y32 = op.fwd(nhwc(x32).to(gpu), w_tap.to(gpu))
+    close(nchw(y32), ref64.float(), rtol=1e-5, atol_scale=2e-6, what="fp32 head on the matrix pipe tr=%s" % tr)

@@ -45,6 +45,9 @@ struct IgemmParams {
     float* part;                           // [ksplit][npix_out][N]  (conv_ring_bf16: the tail ranges' slabs [parts (x2)][tail pixels][N])
     long long npix_out;
     int ring_main, ring_sp;                // conv_ring_bf16 with ksplit = parts > 1: units of the full rounds, stages per tail range
+    // conv_ring_bf16 as a data gradient whose output is the FINAL gradient of z = [relu](BN_train(bnb_y)): `stats` then receives that
+    // BatchNorm's backward partials (sum dz, sum dz * xhat per slot) instead of sum / sum of squares (bnb_co = [scale, shift, mean, invstd][N])
+    const void* bnb_y; const float* bnb_co; int ld_bnb, bnb_relu;
     IgemmPhase ph[MAX_PHASE];
     short tdy[MAX_TAPS], tdx[MAX_TAPS], twi[MAX_TAPS];
 };
@@ -915,7 +918,9 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
                                                              const void* __restrict__ addsrc, int ld_add, int act,
                                                              float* __restrict__ stats, int bf16,
                                                              const float* __restrict__ ep_scale,
-                                                             const float* __restrict__ ep_shift) {
+                                                             const float* __restrict__ ep_shift,
+                                                             const void* __restrict__ bnb_y = nullptr, int ld_bnb = 0,
+                                                             const float* __restrict__ bnb_co = nullptr, int bnb_relu = 0) {
     __shared__ float sh[256 * 8];
     const int cq = N >> 2;
     const int CQ = cq < 256 ? cq : 256, PY = 256 / CQ;
@@ -938,8 +943,7 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
                     for (int e = 0; e < 8; ++e) v += u[e];
                 }
                 for (; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(part + z * zs + (size_t)pix * N + c);
-                s1 += v;
-                s2 += v * v;
+                if (!bnb_y) { s1 += v; s2 += v * v; }
                 if (ep_scale) v = v * *reinterpret_cast<const f32x4*>(ep_scale + c) + *reinterpret_cast<const f32x4*>(ep_shift + c);
                 if (act & GDN_ACT_RELU) {
 #pragma unroll
@@ -951,6 +955,19 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
                     for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
                 }
                 st4_any(y, (size_t)pix * ldy + c, v, bf16);
+                if (bnb_y) {
+                    // v is the final gradient of z = [relu](BN(bnb_y)): the BatchNorm backward's partial sums (conv_ring.h, same arithmetic)
+                    const f32x4 yv = ld4_any(bnb_y, (size_t)pix * ld_bnb + c, bf16);
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(bnb_co + c), sf = *reinterpret_cast<const f32x4*>(bnb_co + N + c);
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(bnb_co + 2 * N + c), is = *reinterpret_cast<const f32x4*>(bnb_co + 3 * N + c);
+                    // (the gradient as the consumer reads it: rounded to the tensor's dtype)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float dz = bf16 ? bf16_h_to_f32(f32_to_bf16_h(v[e])) : v[e];
+                        if (bnb_relu && !(yv[e] * sc[e] + sf[e] > 0.f)) dz = 0.f;
+                        s1[e] += dz; s2[e] += dz * ((yv[e] - mu[e]) * is[e]);
+                    }
+                }
             }
         }
         if (stats) {
@@ -1247,7 +1264,8 @@ int launch_igemm(IgemmParams& P, int cfg, hipStream_t st, int ksplit = 1, void* 
                 const dim3 g1(rp.G), b1(512);
                 P.ksplit = rp.parts; P.ring_main = rp.main_units; P.ring_sp = rp.sp;
                 if (rp.parts > 1 && !split_ws) return GDN_ERR_WORKSPACE;
-#define GDN_RING(BNV, KWV) hipLaunchKernelGGL((conv_ring_bf16<BNV, KWV>), g1, b1, 0, st, P)
+#define GDN_RING(BNV, KWV) do { if (P.bnb_y) hipLaunchKernelGGL((conv_ring_bf16<BNV, KWV, 0, true>), g1, b1, 0, st, P); \
+                                else hipLaunchKernelGGL((conv_ring_bf16<BNV, KWV>), g1, b1, 0, st, P); } while (0)
                 const int kw = ring_kw(P);
                 if (cfg == 10) { if (kw == 3) GDN_RING(64, 3); else if (kw == 5) GDN_RING(64, 5); else if (kw == 7) GDN_RING(64, 7); else if (kw == 9) GDN_RING(64, 9); else return GDN_ERR_UNSUPPORTED; }
                 else { if (kw == 3) GDN_RING(128, 3); else if (kw == 5) GDN_RING(128, 5); else if (kw == 7) GDN_RING(128, 7); else if (kw == 9) GDN_RING(128, 9); else return GDN_ERR_UNSUPPORTED; }
@@ -1260,7 +1278,9 @@ int launch_igemm(IgemmParams& P, int cfg, hipStream_t st, int ksplit = 1, void* 
                     hipLaunchKernelGGL(splitk_combine_kernel, dim3(blocks), dim3(256), 0, st, (const float*)P.part, rp.slabs, (long long)rp.tail_px,
                                        P.N, (void*)((unsigned short*)P.y + p0 * P.ldy), P.ldy,
                                        P.addsrc ? (const void*)((const unsigned short*)P.addsrc + p0 * P.ld_add) : (const void*)nullptr, P.ld_add,
-                                       P.act, P.stats ? P.stats + (size_t)rp.main_mtiles * 2 * P.N : (float*)nullptr, 1, P.ep_scale, P.ep_shift);
+                                       P.act, P.stats ? P.stats + (size_t)rp.main_mtiles * 2 * P.N : (float*)nullptr, 1, P.ep_scale, P.ep_shift,
+                                       P.bnb_y ? (const void*)((const unsigned short*)P.bnb_y + p0 * P.ld_bnb) : (const void*)nullptr, P.ld_bnb,
+                                       P.bnb_co, P.bnb_relu);
                 }
                 return gdn_launch_status();
             }
@@ -1493,8 +1513,24 @@ extern "C" size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g, int32_t
     return (fold ? fold_bytes(g) : 0) + ksplit_bytes(P, pick_ksplit(P, cfg, scalar, tile_cfg)) + ring_ws_bytes(P, cfg);
 }
 
+// slots of the BatchNorm-backward partials the data gradient's epilogue can emit for this layer (0: not available -- only the
+// LDS-DMA ring kernel of the bf16 stride-1 layers without reflection padding does it)
+extern "C" int64_t gdn_conv_dgrad_bnb_slots(const gdn_conv_geom* g, int32_t tile_cfg) {
+    IgemmParams P{};
+    bool fold, scalar;
+    if (!g || !fill_dgrad(g, P, fold, scalar) || fold || scalar || !(tile_cfg & CFG_BF16)) return 0;
+    P.bf16 = 1;
+    if ((g->Cout % 64) || (g->Cin % 8)) return 0;
+    const int cfg = pick_cfg(P, P.N, scalar, tile_cfg);
+    if (cfg < 10) return 0;
+    const RingPlan rp = ring_plan(P, cfg == 10 ? 64 : 128);
+    if (rp.parts > 1) return rp.main_mtiles + cdiv64(rp.tail_px, SK_ROWS);
+    return (int64_t)P.nphase * cdiv64(max_phase_m(P), kCfg[cfg].bm);
+}
+
 extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t ldy, const void* wtv, void* dxv,
-                              int32_t ldx, const void* addsrcv, int32_t ld_add, void* workspace,
+                              int32_t ldx, const void* addsrcv, int32_t ld_add, const void* bnb_y, int32_t ld_bnb,
+                              const float* bnb_co, int32_t bnb_relu, float* bnb_partial, void* workspace,
                               size_t workspace_bytes, int32_t tile_cfg, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     const float *dy = (const float*)dyv, *wt = (const float*)wtv, *addsrc = (const float*)addsrcv;
@@ -1527,6 +1563,12 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t l
     if ((ksplit > 1 || rb) && ((P.ldy % 4) || (P.addsrc && (P.ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
     P.kc = (!scalar && g->Cout % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
     if (cfg >= 10) P.kc = (tile_cfg >> 12) & 15;
+    if (bnb_y) {
+        // the producer BatchNorm's backward partials from this epilogue: gdn_conv_dgrad_bnb_slots(g, tile_cfg) said so
+        if (!bnb_co || !bnb_partial || (ld_bnb % 8)) return GDN_ERR_BAD_ARG;
+        if (cfg < 10 || fold || !bf) return GDN_ERR_UNSUPPORTED;
+        P.bnb_y = bnb_y; P.ld_bnb = ld_bnb; P.bnb_co = bnb_co; P.bnb_relu = bnb_relu ? 1 : 0; P.stats = bnb_partial;
+    }
     int rc = launch_igemm(P, cfg, st, ksplit, (ksplit > 1 || rb) ? (char*)workspace + fb : nullptr);
     if (rc != GDN_OK) return rc;
     if (fold && (g->Cin % 4)) {

@@ -68,7 +68,9 @@ typedef __attribute__((address_space(3))) void* rg_lds_ptr;
 #define RG_DEVICE_BODY 0
 #endif
 
-template <int BN, int KW, int DPO = 0>
+// BNB: the data-gradient instantiation whose epilogue also emits the producer BatchNorm's backward partials (p.bnb_y; kept out of
+// the other instantiations: its 16 running sums cost the 256 x 128 form ~30 spilled registers)
+template <int BN, int KW, int DPO = 0, bool BNB = false>
 __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
 #if RG_DEVICE_BODY
     constexpr int BM = RG_BM;
@@ -87,7 +89,8 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
     constexpr int TABN = BM + RG_KMAX * RG_NRMAX + RG_NRMAX + 1 + RG_NRMAX + 3;     // ints per table set (392)
     static_assert(TAB0 - SC0 >= 34 * 1024 && TABN * 4 <= 1600, "LDS map");
     // ONE shared object: the compiler must see a single LDS array beside the LDS-DMA instructions
-    __shared__ __attribute__((aligned(16))) unsigned char sm[TAB0 + 2 * 1600 + 64];
+    constexpr int COEF0 = TAB0 + 2 * 1600 + 64;              // [4][BN] floats: the BatchNorm coefficients of a data gradient's bnb mode
+    __shared__ __attribute__((aligned(16))) unsigned char sm[COEF0 + 4 * 128 * 4];
     int* const wirow = reinterpret_cast<int*>(sm + TAB0 + 2 * 1600);      // [RG_KMAX] weight index of the first tap of each filter row
     auto tab = [&](int b) { return reinterpret_cast<int*>(sm + TAB0 + b * 1600); };
     // a table set: row_out[256] output pixel index or -1 | rowoff[RG_KMAX][RG_NRMAX] byte offset of input row or -1 |
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
         }
         // row tile ii of this wave covers tile rows rbeg(ii) + rowmap(r, lane_e)
         auto rbeg = [&](int ii) { return BN == 64 ? wm * 64 + wz * 32 : wm * 64 + ii * 32; };
-        if (p.stats) {
+        if (p.stats && !(BNB && p.bnb_y)) {
             float* red = sc;                         // [8 waves][64 columns][2]
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -493,6 +496,20 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
         constexpr int TPP = BN / 8;                  // threads per pixel on the way out
         unsigned short* yo = reinterpret_cast<unsigned short*>(p.y);
         const unsigned short* ad = reinterpret_cast<const unsigned short*>(p.addsrc);
+        // bnb mode (a data gradient that is the final gradient of z = [relu](BN_train(bnb_y))): the BatchNorm backward's partial
+        // sums sum dz, sum dz * xhat over this tile's pixels, from the values as they are stored (rounded to bf16), so the
+        // stand-alone reduce pass over (dx, y) disappears; slot = tile, like the forward's sum / sum of squares
+        float* const coef = reinterpret_cast<float*>(sm + COEF0);
+        const bool bnb = BNB && p.bnb_y != nullptr;
+        float bs1[8], bs2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; }
+        if (BNB && bnb) {
+            for (int i = tid_e; i < 4 * BN; i += 512) {
+                const int n = n0 + i % BN;
+                coef[i] = n < p.N ? p.bnb_co[(size_t)(i / BN) * p.N + n] : 0.f;
+            }
+        }
 #pragma unroll 1
         for (int rr = 0; rr < NRND; ++rr) {
             if ((BN == 64 ? (wm >> 1) : wm) == rr) {
@@ -528,7 +545,39 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
                         for (int e = 0; e < 4; ++e) { lo[e] = tanhf(lo[e]); hi[e] = tanhf(hi[e]); }
                     }
                     st8_any(yo, (size_t)op * p.ldy + n0 + cg * 8, lo, hi, 1);
+                    if (BNB && bnb) {
+                        f32x4 ylo, yhi;
+                        ld8_any(p.bnb_y, (size_t)op * p.ld_bnb + n0 + cg * 8, 1, ylo, yhi);
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const f32x4 yv = hh ? yhi : ylo, dv = hh ? hi : lo;
+                            const f32x4 csc = *reinterpret_cast<const f32x4*>(coef + cg * 8 + hh * 4);
+                            const f32x4 csh = *reinterpret_cast<const f32x4*>(coef + BN + cg * 8 + hh * 4);
+                            const f32x4 cmu = *reinterpret_cast<const f32x4*>(coef + 2 * BN + cg * 8 + hh * 4);
+                            const f32x4 cis = *reinterpret_cast<const f32x4*>(coef + 3 * BN + cg * 8 + hh * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float dz = bf16_h_to_f32(f32_to_bf16_h(dv[e]));
+                                if (p.bnb_relu && !(yv[e] * csc[e] + csh[e] > 0.f)) dz = 0.f;
+                                bs1[hh * 4 + e] += dz;
+                                bs2[hh * 4 + e] += dz * ((yv[e] - cmu[e]) * cis[e]);
+                            }
+                        }
+                    }
                 }
+            }
+            __syncthreads();
+        }
+        if (BNB && bnb) {
+            // thread (pixel lane q = tid / TPP, channel group cg = tid % TPP) -> per-channel sums over the 512 / TPP pixel lanes
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[tid_e * 16 + e] = bs1[e]; sc[tid_e * 16 + 8 + e] = bs2[e]; }
+            __syncthreads();
+            if (tid_e < 2 * BN) {
+                const int c = tid_e % BN, which = tid_e / BN;
+                float a = 0.f;
+                for (int q = 0; q < 512 / TPP; ++q) a += sc[(q * TPP + (c >> 3)) * 16 + which * 8 + (c & 7)];
+                if (n0 + c < p.N) p.stats[((size_t)mt * 2 + which) * p.N + n0 + c] = a;
             }
             __syncthreads();
         }

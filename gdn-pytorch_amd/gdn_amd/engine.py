@@ -25,7 +25,7 @@ _WINOGRAD = os.environ.get("GDN_WINOGRAD", "1") != "0"
 _FUSE_TRAIN_BN = os.environ.get("GDN_FUSE_TRAIN_BN", "1") != "0"
 # per-site A/B switches of that fusion (measurement; all on by default unless a site measured slower)
 _FUSE = {k: os.environ.get("GDN_FUSE_" + k.upper(), d) != "0" for k, d in
-         (("fft_in", "1"), ("fft_dyb", "1"), ("wino_in", "1"), ("wino_bnb", "1"))}
+         (("fft_in", "1"), ("fft_dyb", "1"), ("wino_in", "1"), ("wino_bnb", "1"), ("ring_bnb", "1"))}
 # fp32 4x4 stride-2 pad-1 Conv2d / ConvTranspose2d layers run as Winograd F(3x3,2x2) over the polyphase images
 # (csrc/conv_wino2.hip) when both channel counts reach this value (0 disables): the transforms move ~1.8x the
 # layer's activations (measured: a gain on every such layer of G, the smallest at 64 channels, tests/diag/wino2_time.py)
@@ -693,8 +693,20 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
             if want_dx:
                 wt = ops.transpose_taps(_w_tap(conv)[0], dtype=ldt)
                 if x2 is None:
-                    dx = op.dgrad(dy, wt, in_hw, addsrc=ctx.pop_grad_as(x, ldt))
+                    bnb = None
+                    if (xin is not None and ldt == torch.bfloat16 and xin.y.dtype == ldt and _FUSE_TRAIN_BN and _FUSE["ring_bnb"]
+                            and xin.y.is_contiguous()):
+                        # x = [relu](BN_train(xin.y)) and this data gradient is its final gradient (we are its first consumer;
+                        # the other consumers' gradients arrive as addsrc): the LDS-DMA ring kernel's epilogue emits the
+                        # producer's BatchNorm-backward partial sums, as the Winograd path does for the fp32 layers
+                        slots = op.dgrad_bnb_slots(x.shape[0], x.shape[1], x.shape[2], ldt)
+                        if slots > 0:
+                            part = torch.empty((slots, 2, conv.in_channels), dtype=torch.float32, device=dy.device)
+                            bnb = (xin.y, xin.co, xin.relu, part)
+                    dx = op.dgrad(dy, wt, in_hw, addsrc=ctx.pop_grad_as(x, ldt), bnb=bnb)
                     ctx.grads[id(x)] = (x, dx)
+                    if bnb is not None:
+                        xin.partial = bnb[3]
                 else:
                     dcat = op.dgrad(dy, wt, in_hw)
                     c1 = x.shape[3]

@@ -227,8 +227,15 @@ class Conv:
                 tuple(x.shape), _ld(x), None if x2 is None else tuple(x2.shape))) from None
         return (y, st) if stats else y
 
-    def dgrad(self, dy, wt_tap, in_hw, addsrc=None, tile_cfg=0):
-        """dx = dgrad(dy) (+ addsrc).  wt_tap: [k*k, Cin, Cout]; in_hw: layer input (H, W)."""
+    def dgrad_bnb_slots(self, B, H, W, dtype, tile_cfg=0):
+        """Slots of the BatchNorm-backward partials dgrad's epilogue can emit for this layer (0: it cannot)."""
+        _, ref, _, _ = self.geom(B, H, W)
+        return int(lib.gdn_conv_dgrad_bnb_slots(ref, tile_cfg | (CFG_BF16 if dtype == torch.bfloat16 else 0)))
+
+    def dgrad(self, dy, wt_tap, in_hw, addsrc=None, tile_cfg=0, bnb=None):
+        """dx = dgrad(dy) (+ addsrc).  wt_tap: [k*k, Cin, Cout]; in_hw: layer input (H, W).
+        bnb = (y, co, relu, partial): dx is the final gradient of [relu](BN_train(y)); `partial` [dgrad_bnb_slots, 2, Cin]
+        receives that BatchNorm's backward partial sums (as wino_bwd's bnb)."""
         _chk(dy, "dy", bf16_ok=True)
         _same_dtype(dy, wt_tap, addsrc)
         if dy.dtype == torch.bfloat16:
@@ -241,8 +248,12 @@ class Conv:
         dx = torch.empty((B, H, W, self.cin), dtype=dy.dtype, device=dy.device)
         nb = int(lib.gdn_conv_dgrad_workspace_bytes(ref, tile_cfg))
         ws = workspace(nb, dy.device, "dgrad") if nb else None
+        by, bco, brelu, bpart = bnb if bnb is not None else (None, None, False, None)
+        if by is not None and by.dtype != dy.dtype:
+            raise GdnError("dgrad: the BatchNorm input of the fused backward reduction must have the gradient's dtype")
         lib.gdn_conv_dgrad(ref, _p(dy), _ld(dy), _p(wt_tap), _p(dx), _ld(dx), _p(addsrc),
-                           0 if addsrc is None else _ld(addsrc), _p(ws), nb, tile_cfg, stream())
+                           0 if addsrc is None else _ld(addsrc), _p(by), 0 if by is None else _ld(by), _p(bco),
+                           1 if brelu else 0, _p(bpart), _p(ws), nb, tile_cfg, stream())
         return dx
 
     # ---- FFT-domain path (csrc/conv_fft.hip): stride-1 zero-padded fp32 layers with 64..256 channels ----

@@ -40,7 +40,7 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
-/* Revision of this header (argument lists, struct layouts).  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+/* Revision of this header (argument lists, struct layouts).  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
  * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
@@ -135,9 +135,16 @@ int gdn_conv_fwd(const gdn_conv_geom* g,
  * Reflection-padded layers need a workspace for the gradient on the padded
  * domain, folded back onto dx inside the call. */
 size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g, int32_t tile_cfg);
+/* bnb_y != NULL: dx (+ addsrc) is the FINAL gradient of z = [relu](BN_train(bnb_y)) -- the layer's input is the output of a
+ * train-mode BatchNorm (+ReLU) and this call comes from its first consumer -- and bnb_partial [slots][2][Cin] receives that
+ * BatchNorm's backward partial sums (sum dz, sum dz * xhat per slot; bnb_co = [scale, shift, mean, invstd][Cin]) computed from
+ * the values as they are stored, so gdn_bn_bwd can skip its reduce pass.  slots = gdn_conv_dgrad_bnb_slots(g, tile_cfg);
+ * 0 = not available for this layer (today: the bf16 stride-1 layers of the LDS-DMA ring kernel, zero padding). */
+int64_t gdn_conv_dgrad_bnb_slots(const gdn_conv_geom* g, int32_t tile_cfg);
 int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dy, int32_t ldy,
                    const void* wt, void* dx, int32_t ldx,
                    const void* addsrc, int32_t ld_add,
+                   const void* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu, float* bnb_partial,
                    void* workspace, size_t workspace_bytes, int32_t tile_cfg, void* stream);
 
 /* Weight gradient (same call sites).  x is the layer input ([B,H,W], channel

@@ -527,3 +527,45 @@ def test_head_bf16_on_the_matrix_pipe(gpu, tr, B, H, W):
     ref64 = (F.conv_transpose2d(x32.double(), wt.double(), stride=1, padding=4) if tr else F.conv2d(x32.double(), w.double(), padding=4))
     y32 = op.fwd(nhwc(x32).to(gpu), w_tap.to(gpu))
     close(nchw(y32), ref64.float(), rtol=1e-5, atol_scale=2e-6, what="fp32 head on the matrix pipe tr=%s" % tr)
+
+
+@pytest.mark.parametrize("case,cus", [(("bnb_k3_l3", 128, 128, 3, 2, 16, 52), 0), (("bnb_k9_64", 64, 64, 9, 2, 24, 64), 0),
+                                      (("bnb_k5_tail", 64, 64, 5, 4, 17, 64), 16), (("bnb_k7_relu_off", 64, 128, 7, 1, 16, 40), 0)])
+def test_ring_dgrad_emits_batchnorm_backward_partials(gpu, case, cus, monkeypatch):
+    """Data gradient of a bf16 stride-1 layer on the LDS-DMA ring kernel with the producer BatchNorm's backward reduction fused
+    into its epilogue (gdn_conv_dgrad bnb_*): dx is unchanged bit for bit, and the partial sums -- sum dz and sum dz * xhat with
+    dz = dx [z > 0] taken from the gradient AS STORED (bf16) -- match a torch evaluation of the same stored tensors to fp32
+    summation error.  cus: plan for a small chip so that the K-split tail (splitk_combine_kernel's twin of the epilogue) runs."""
+    from gdn_amd import ops
+    name, ci, co, k, B, H, W = case
+    if cus:
+        monkeypatch.setenv("GDN_RING_CUS", str(cus))
+    g = torch.Generator().manual_seed(len(name) + k)
+    gy = r16(torch.randn(B, H, W, co, generator=g))
+    wt = r16(torch.randn(k * k, ci, co, generator=g) / (co * k * k) ** 0.5)
+    add = r16(torch.randn(B, H, W, ci, generator=g))
+    y = r16(torch.randn(B, H, W, ci, generator=g))                       # the producer's raw convolution output
+    coef = torch.stack([torch.rand(ci, generator=g) + 0.5, torch.randn(ci, generator=g) * 0.3, torch.randn(ci, generator=g) * 0.1,
+                        torch.rand(ci, generator=g) + 0.5])              # scale, shift, mean, invstd
+    relu = "relu_off" not in name
+    op = ops.Conv(ci, co, k, 1, k // 2)
+    slots = op.dgrad_bnb_slots(B, H, W, torch.bfloat16)
+    assert slots > 0
+    if "tail" in name:       # 17 tiles on a 16-CU plan: one full round + a tail unit cut along K, finished by splitk_combine_kernel
+        assert slots != -(-B * H * W // 256), "the plan has no K-split tail"
+    gyd, wtd, addd, yd, cd = [t.to(gpu) for t in (gy.bfloat16(), wt.bfloat16(), add.bfloat16(), y.bfloat16(), coef)]
+    dx0 = op.dgrad(gyd, wtd, (H, W), addsrc=addd)
+    part = torch.full((slots, 2, ci), float("nan"), device=gpu)
+    dx1 = op.dgrad(gyd, wtd, (H, W), addsrc=addd, bnb=(yd, cd, relu, part))
+    assert torch.equal(dx0, dx1)
+    dxs, ys = dx1.float().cpu().double(), y.double()
+    mask = ((ys * coef[0].double() + coef[1].double()) > 0) if relu else torch.ones_like(ys, dtype=torch.bool)
+    dz = dxs * mask
+    xhat = (ys - coef[2].double()) * coef[3].double()
+    s = part.double().sum(0).cpu()
+    assert torch.isfinite(part).all()
+    close(s[0], dz.sum((0, 1, 2)), rtol=1e-4, atol_scale=1e-5, what=name + " sum dz")
+    close(s[1], (dz * xhat).sum((0, 1, 2)), rtol=1e-4, atol_scale=1e-5, what=name + " sum dz xhat")
+    # a layer the ring kernel does not take (stride 2) offers no slots
+    assert ops.Conv(64, 128, 4, 2, 1).dgrad_bnb_slots(2, 16, 24, torch.bfloat16) == 0
+    assert op.dgrad_bnb_slots(B, H, W, torch.float32) == 0

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the round's final records (profiles/r04f_*): whole-step MFMA utilisation, step traces of five configurations, default bench line
 cd /root/repo
-GDN_COMMIT=04e01aa bash tools/pmc_step.sh > gpurun_out/pmc_step.log 2>&1
+GDN_COMMIT=22d62b5 bash tools/pmc_step.sh > gpurun_out/pmc_step.log 2>&1
 bash tools/prof_step.sh r04f_dtod_fp32 > /dev/null 2>&1
 bash tools/prof_step.sh r04f_rtod_bf16 --mode RtoD --dtype bf16 > /dev/null 2>&1
 bash tools/prof_step.sh r04f_dtod_bf16 --dtype bf16 > /dev/null 2>&1

@@ -464,6 +464,12 @@ extern "C" int gdn_gemm_x3_nt(const float* A, const void* Bp, float* C, int32_t 
     return gdn_launch_status();
 }
 
+// host query: the split count the reduction GEMM's callers use (gemm_x3.h cost model)
+extern "C" int64_t gdn_gemm_x3_tn_splits(int32_t bins, int32_t T, int32_t NI, int32_t NJ) {
+    if (bins < 1 || !gemm_x3_tn_ok(T, NI, NJ)) return 0;
+    return gemm_x3_tn_splits(bins, T, NI, NJ);
+}
+
 extern "C" size_t gdn_gemm_x3_ring_workspace_bytes(void) { return gemm_x3_ring_ws_bytes(); }
 
 extern "C" int gdn_gemm_x3_nt_packed(const void* Ap, const void* Bp, float* C, int32_t bins, int32_t M, int32_t N, int32_t K,

@@ -73,6 +73,7 @@ _SIGS = {
     "gdn_gemm_x3_nt": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, _P]),
     "gdn_gemm_x3_tn": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, _i32, _P]),
     "gdn_gemm_x3_ring_workspace_bytes": (_sz, []),
+    "gdn_gemm_x3_tn_splits": (_i64, [_i32, _i32, _i32, _i32]),
     "gdn_gemm_x3_nt_packed": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, _P, _sz, _P]),
     "gdn_transpose_taps": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P]),
     "gdn_cast": (c_int32, [_P, _P, _i64, _i32, _P]),
@@ -113,7 +114,7 @@ _STATUS_FUNCS = {n for n, (r, _) in _SIGS.items() if r is c_int32} - {"gdn_versi
 EXPORTS = tuple(_SIGS)
 # The C ABI revision these signatures (and ConvGeom's layout) describe: gdn_version() of the library must match exactly --
 # a stale build would take the arguments apart differently.
-ABI_VERSION = 217
+ABI_VERSION = 218
 
 
 class _Lib:

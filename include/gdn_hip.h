@@ -40,7 +40,7 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
-/* Revision of this header (argument lists, struct layouts).  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+/* Revision of this header (argument lists, struct layouts).  218: gdn_gemm_x3_tn_splits.  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
  * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
@@ -313,6 +313,9 @@ int gdn_gemm_x3_tn(const float* A, const float* B, float* P, int32_t bins, int32
 /* gdn_gemm_x3_nt with A packed as well (gdn_gemm_x3_pack of [bins][M][K]): the LDS-DMA ring kernel (csrc/gemm_x3_ring.h) the
  * Winograd layers run on when their transforms write panels.  workspace: gdn_gemm_x3_ring_workspace_bytes(). */
 size_t gdn_gemm_x3_ring_workspace_bytes(void);
+/* host query: the number of reduction splits gdn_winoconv_bwd / gdn_wino2conv_bwd give gdn_gemm_x3_tn for a shape (0: shape not
+ * eligible): rounds of the chip per split plus the partial-product sets read back, DESIGN.md 2.10 */
+int64_t gdn_gemm_x3_tn_splits(int32_t bins, int32_t T, int32_t NI, int32_t NJ);
 int gdn_gemm_x3_nt_packed(const void* Ap, const void* Bp, float* C, int32_t bins, int32_t M, int32_t N, int32_t K,
                           void* workspace, size_t workspace_bytes, void* stream);
 

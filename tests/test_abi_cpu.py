@@ -60,6 +60,23 @@ def test_host_queries_without_gpu(built_lib):
     assert lib.gdn_conv_wgrad_workspace_bytes(ctypes.byref(bad), 8) == 0
     with pytest.raises(Exception):
         lib.gdn_conv_out_dims(ctypes.byref(bad), ctypes.byref(ho), ctypes.byref(wo))
+    # round-4 host plans: Winograd F(4x4,3x3) where the image rounds up to whole 4x4 tiles with <= 15 % more pixels, the
+    # GDN_HINT_NO_WINO_F4 switch, the reduction GEMM's split model, the data gradient's BatchNorm-backward slots
+    st4, st2 = lib.gdn_winoconv_state_bytes(ctypes.byref(g)), lib.gdn_winoconv_state_bytes(ctypes.byref(ConvGeom(20, 16, 52, 512, 512, 3, 1, 1, 0, 0, 4)))
+    v = lambda bins, tiles: bins * tiles * 512 * 4
+    u = 36 * 512 * 512 * 6                                      # the data gradient's weight set: 36 bf16 x 3 panel sets
+    assert st4 == v(36, 20 * 4 * 13) + u and st2 == v(16, 20 * 8 * 26) + 16 * 512 * 512 * 6
+    assert lib.gdn_winoconv_stats_slots(ctypes.byref(g)) == 20 * 4 * 13 // 4
+    g9 = ConvGeom(2, 9, 13, 128, 256, 3, 1, 1, 0, 0)            # 12 x 16 tiles for 9 x 13 pixels: +64 % -> F(2x2,3x3)
+    assert lib.gdn_winoconv_stats_slots(ctypes.byref(g9)) == (2 * 5 * 7 + 3) // 4
+    assert lib.gdn_gemm_x3_tn_splits(36, 1040, 512, 512) == 2    # 576 tiles on 512 slots: two rounds whole, 1.5 in halves
+    assert lib.gdn_gemm_x3_tn_splits(16, 4160, 512, 512) == 2    # 256 tiles: half the chip idle unless split
+    assert lib.gdn_gemm_x3_tn_splits(36, 280, 512, 512) == 1     # chunks of at least 256 rows
+    assert lib.gdn_gemm_x3_tn_splits(16, 30800, 128, 256) == 16  # 32 tiles over 30800 rows
+    assert lib.gdn_gemm_x3_tn_splits(16, 1040, 96, 512) == 0     # not a multiple of 128: not eligible
+    assert lib.gdn_conv_dgrad_bnb_slots(ctypes.byref(ConvGeom(20, 16, 52, 512, 512, 3, 1, 1, 0, 0)), 0x10000) > 0   # bf16 ring layer
+    assert lib.gdn_conv_dgrad_bnb_slots(ctypes.byref(g), 0) == 0                                                    # fp32
+    assert lib.gdn_conv_dgrad_bnb_slots(ctypes.byref(ConvGeom(2, 16, 24, 64, 128, 4, 2, 1, 0, 0)), 0x10000) == 0   # stride 2
 
 
 def test_models_match_oracle_init_and_keys():

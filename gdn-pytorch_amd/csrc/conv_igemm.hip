@@ -45,6 +45,7 @@ struct IgemmParams {
     float* part;                           // [ksplit][npix_out][N]  (conv_ring_bf16: the tail ranges' slabs [parts (x2)][tail pixels][N])
     long long npix_out;
     int ring_main, ring_sp;                // conv_ring_bf16 with ksplit = parts > 1: units of the full rounds, stages per tail range
+    int ring_notail;                       // tile_cfg & 0x800 ("single stage"): the last round's units stay whole (A/B measurements, tests)
     // conv_ring_bf16 as a data gradient whose output is the FINAL gradient of z = [relu](BN_train(bnb_y)): `stats` then receives that
     // BatchNorm's backward partials (sum dz, sum dz * xhat per slot) instead of sum / sum of squares (bnb_co = [scale, shift, mean, invstd][N])
     const void* bnb_y; const float* bnb_co; int ld_bnb, bnb_relu;
@@ -1076,8 +1077,7 @@ RingPlan ring_plan(const IgemmParams& P, int bn) {
     const int kw = ring_kw(P), nstage = kw ? (ph.tap_end - ph.tap_begin) / kw * (P.Cred / 64) : 0;
     const int rounds = units / r.G, tail = units % r.G;
     r.main_units = units; r.parts = 1; r.sp = nstage; r.slabs = 0; r.main_mtiles = r.grid_m; r.tail_px = 0;
-    const char* e = getenv("GDN_RING_TAIL");                           // measurement: 0 keeps the last round whole
-    if (e && e[0] == '0') return r;
+    if (P.ring_notail) return r;                                       // (tile_cfg & 0x800: every unit whole)
     if (rounds >= 1 && tail > 0 && 4 * tail <= r.G && nstage >= 2 && r.G % r.grid_n == 0) {
         int parts = r.G / tail < nstage ? r.G / tail : nstage;
         if (parts > 8) parts = 8;                 // (each range is one fp32 slab -- two with the 256 x 64 form -- that the combine pass reads back)
@@ -1408,6 +1408,7 @@ extern "C" int64_t gdn_conv_stats_slots(const gdn_conv_geom* g, int32_t tile_cfg
     IgemmParams P{};
     if (fill_fwd(g, P) != GDN_OK) return GDN_ERR_BAD_ARG;
     const bool scalar = (g->Cin % KC_MIN) != 0;
+    P.ring_notail = (tile_cfg & 0x800) ? 1 : 0;
     const int cfg = pick_cfg(P, g->Cout, scalar, tile_cfg);
     if (pick_ksplit(P, cfg, scalar, tile_cfg) > 1) return cdiv64((int64_t)P.B * P.Hy * P.Wy, SK_ROWS);
     if (cfg >= 10) {
@@ -1421,6 +1422,7 @@ extern "C" size_t gdn_conv_fwd_workspace_bytes(const gdn_conv_geom* g, int32_t t
     IgemmParams P{};
     if (fill_fwd(g, P) != GDN_OK) return 0;
     const bool scalar = (g->Cin % KC_MIN) != 0;
+    P.ring_notail = (tile_cfg & 0x800) ? 1 : 0;
     const int cfg = pick_cfg(P, g->Cout, scalar, tile_cfg);
     return ksplit_bytes(P, pick_ksplit(P, cfg, scalar, tile_cfg)) + ring_ws_bytes(P, cfg);
 }
@@ -1465,6 +1467,7 @@ extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const void* xv, int32_t ldx,
     }
     // 32-channel slabs measured faster than 64 everywhere (6 waves/SIMD vs 4); 0x200 selects 64 for tuning runs
     P.kc = (!scalar && g->Cin % 64 == 0 && C1 % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
+    P.ring_notail = (tile_cfg & 0x800) ? 1 : 0;
     const int cfg = pick_cfg(P, P.N, scalar, tile_cfg);
     // the row-patch kernel reads one input tensor; a fused concat with k >= 3 has no call site in the networks
     if (cfg >= 8 && x2) return GDN_ERR_UNSUPPORTED;
@@ -1509,6 +1512,7 @@ extern "C" size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g, int32_t
     IgemmParams P{};
     bool fold, scalar;
     if (!fill_dgrad(g, P, fold, scalar)) return 0;
+    P.ring_notail = (tile_cfg & 0x800) ? 1 : 0;
     const int cfg = pick_cfg(P, P.N, scalar, tile_cfg);
     return (fold ? fold_bytes(g) : 0) + ksplit_bytes(P, pick_ksplit(P, cfg, scalar, tile_cfg)) + ring_ws_bytes(P, cfg);
 }
@@ -1521,6 +1525,7 @@ extern "C" int64_t gdn_conv_dgrad_bnb_slots(const gdn_conv_geom* g, int32_t tile
     if (!g || !fill_dgrad(g, P, fold, scalar) || fold || scalar || !(tile_cfg & CFG_BF16)) return 0;
     P.bf16 = 1;
     if ((g->Cout % 64) || (g->Cin % 8)) return 0;
+    P.ring_notail = (tile_cfg & 0x800) ? 1 : 0;
     const int cfg = pick_cfg(P, P.N, scalar, tile_cfg);
     if (cfg < 10) return 0;
     const RingPlan rp = ring_plan(P, cfg == 10 ? 64 : 128);
@@ -1553,6 +1558,7 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t l
     if (bf && (scalar || (g->Cout % 64) || (ldy % 8) || (g->Cin % 4))) return GDN_ERR_UNSUPPORTED;
     P.bf16 = bf ? 1 : 0;
     if (fold && (g->Cin % 4) && bf) return GDN_ERR_UNSUPPORTED;
+    P.ring_notail = (tile_cfg & 0x800) ? 1 : 0;
     const int cfg = pick_cfg(P, P.N, scalar, tile_cfg);
     const int ksplit = pick_ksplit(P, cfg, scalar, tile_cfg);
     const size_t rb = ring_ws_bytes(P, cfg);

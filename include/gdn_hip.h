@@ -91,7 +91,8 @@ enum { GDN_ACT_NONE = 0, GDN_ACT_TANH = 1, GDN_ACT_RELU = 2 };   /* bit flags */
  * bf16 tile ids (tests, A/B measurements): 1-3 tap-major tiles, 8/9 the round-1 row-patch kernel, 10/11 conv_ring_bf16 (256 x 64 /
  * 256 x 128: the LDS-DMA ring kernel of the stride-1 layers with a 3/5/7/9 window, the automatic choice for them; its persistent
  * workgroups may cut the last round of tiles into stage ranges, whose fp32 slabs live in `workspace`: the forward and the
- * data-gradient workspace queries include them).  For ids 10/11 bits 12..15 are measurement knobs of that kernel (timing-only
+ * data-gradient workspace queries include them; bit 0x800, "single stage", keeps every unit whole, as it keeps the other
+ * kernels from splitting over the filter taps).  For ids 10/11 bits 12..15 are measurement knobs of that kernel (timing-only
  * variants that drop an operand's LDS-DMA traffic or skip the tap loop; 0 in production). */
 enum { GDN_CFG_KC64 = 0x200, GDN_CFG_NO_SPLITK = 0x800, GDN_CFG_BF16 = 0x10000 };
 

@@ -459,7 +459,7 @@ def test_ring_kernel_rounds_and_tail_split(gpu, case, monkeypatch):
     round's units cut into stage ranges whose fp32 slabs splitk_combine_kernel sums -- on shapes small enough for the CPU
     reference: GDN_RING_CUS=16 plans for a 16-CU chip (9 or 18 tiles of 256 pixels -> full rounds + a split tail of 2-4 units).  Forward (+ BatchNorm
     partials: the slot layout changes with the split), data gradient with a residual; against torch on the bf16-rounded
-    operands, and against the same launch with the split off (GDN_RING_TAIL=0): same sums in another order."""
+    operands, and against the same launch with the split off (tile_cfg bit 0x800): same sums in another order."""
     from gdn_amd import ops
     name, ci, co, k, p, refl, B, H, W = case
     g = torch.Generator().manual_seed(5)
@@ -475,18 +475,18 @@ def test_ring_kernel_rounds_and_tail_split(gpu, case, monkeypatch):
     res = {}
     for tail in ("1", "0"):
         monkeypatch.setenv("GDN_RING_CUS", "16")
-        monkeypatch.setenv("GDN_RING_TAIL", tail)
+        single = 0 if tail == "1" else 0x800                   # tile_cfg bit "single stage": the last round's units stay whole
         for cfg in (10, 11):
             if co % (64 if cfg == 10 else 128):
                 continue
             op = ops.Conv(ci, co, k, 1, p, reflect=refl)       # (a fresh op: its cached workspace size belongs to one plan)
-            y, st = op.fwd(xd, wd, stats=True, tile_cfg=cfg)
+            y, st = op.fwd(xd, wd, stats=True, tile_cfg=cfg | single)
             what = "%s cfg%d tail%s" % (name, cfg, tail)
             close(nchw(y.float()), y_ref, rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=what + " fwd")
             close(st[:, 0, :].double().sum(0).cpu(), yr.sum((0, 2, 3)), rtol=1e-3, atol_scale=1e-3, what=what + " stats sum")
             close(st[:, 1, :].double().sum(0).cpu(), (yr * yr).sum((0, 2, 3)), what=what + " stats sumsq")
             if not refl:
-                dx = op.dgrad(gyd, wt, (H, W), addsrc=add.to(gpu).bfloat16(), tile_cfg=cfg)
+                dx = op.dgrad(gyd, wt, (H, W), addsrc=add.to(gpu).bfloat16(), tile_cfg=cfg | single)
                 close(nchw(dx.float()), x.grad + nchw(add), rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=what + " dgrad")
             res[(cfg, tail)] = (y.float().cpu(), st.shape[0])
     for cfg in (10, 11):

@@ -80,6 +80,31 @@ def test_upsample_folded_into_zero_padded_conv_forward(gpu, k, align):
     close(nchw(y), y_ref, what="fwd")
 
 
+@pytest.mark.parametrize("align", [False, True])
+def test_upsample_folded_into_f4_winograd_forward(gpu, align):
+    """The same fold in the F(4x4,3x3) input transform (128 -> 128 channels, 16 x 20 = 4 x 5 tiles: the plan wino_geom picks):
+    against torch, and against the F(2x2,3x3) plan of the same layer."""
+    from gdn_amd import ops
+    ci = co = 128
+    B, Hl, Wl = 2, 8, 10
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, ci, Hl, Wl, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
+    y_ref = _ref(x, w, 3, False, align)
+    op = ops.Conv(ci, co, 3, 1, 1)
+    xd, wd = nhwc(x).to(gpu), tapmajor(w, False).to(gpu)
+    prev = ops.set_wino_f4(True)
+    try:
+        y4, st4 = op.wino_fwd(xd, wd, stats=True, up2x=2 if align else 1)
+        ops.set_wino_f4(False)
+        y2, st2 = op.wino_fwd(xd, wd, stats=True, up2x=2 if align else 1)
+    finally:
+        ops.set_wino_f4(prev)
+    assert st4.shape[0] != st2.shape[0]                       # 40 tiles of 4 x 4 against 160 of 2 x 2: the plans differ
+    close(nchw(y4), y_ref, what="F4 fwd with the upsampling folded in")
+    close(y4, y2, rtol=1e-4, atol_scale=2e-5, what="F4 vs F2")
+
+
 def test_upsample_fold_argument_checks(gpu):
     from gdn_amd import ops
     from gdn_amd._lib import GdnError

@@ -37,7 +37,7 @@ def _worker(rank, world, port, q):
         flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
         for wk in D.allreduce_flat(flat, bucket_elems=300):
             wk.wait()
-        assert torch.equal(flat, torch.arange(1000, dtype=torch.float32) * 3)
+        assert torch.equal(flat, torch.arange(1000, dtype=torch.float32) * (world * (world + 1) // 2))
         assert [b.numel() for b in D.flat_buckets(flat, 300)] == [300, 300, 300, 100]
         # --- one training step per rank on its own shard, CPU oracle arithmetic ---
         torch.manual_seed(0)                       # identical init on every rank
@@ -52,17 +52,23 @@ def _worker(rank, world, port, q):
         sd0 = O.init_state_dict("AutoEncoder_DtoD", seed=0)
         assert all(torch.equal(v, sd0[k]) for k, v in model.state_dict().items())
         shards = [O.synthetic_batch(1, 32, 64, seed=10 + i) for i in range(world)]
-        grads = []
-        for i in range(world):                      # every rank computes all shards to know the expected mean
-            res = O.train_step("DtoD", {k: v.clone() for k, v in sd0.items()}, shards[i], {})
-            grads.append(res["grads"])
+        # every rank needs all shards' gradients to know the expected mean: two ranks compute them all themselves; eight
+        # compute their own and exchange them with all_gather_object (a different collective from the all-reduce under test)
+        if world <= 2:
+            grads = [O.train_step("DtoD", {k: v.clone() for k, v in sd0.items()}, shards[i], {})["grads"] for i in range(world)]
+        else:
+            import torch.distributed as dist
+            mine = O.train_step("DtoD", {k: v.clone() for k, v in sd0.items()}, shards[rank], {})["grads"]
+            grads = [None] * world
+            dist.all_gather_object(grads, {k: v.clone() for k, v in mine.items()})
         arena.bind_grads()
         for k, p in model.named_parameters():
             p.grad.copy_(grads[rank][k])            # what this rank's backward would have written
         D.sync_gradients(model, None)               # SUM all-reduce, then 1/world
         for k, p in model.named_parameters():
             want = sum(g[k] for g in grads) / world
-            torch.testing.assert_close(p.grad, want, rtol=1e-5, atol=1e-7)
+            # (gloo sums the ranks in ring order, this loop in rank order: fp32 summation-order noise grows with the rank count)
+            torch.testing.assert_close(p.grad, want, rtol=5e-6 * world, atol=5e-8 * world + 2.5e-7 * world * float(want.abs().max()))
         # --- overlapped reduction: buckets fire as soon as their last parameter is marked ---
         red = D.GradReducer(arena, bucket_elems=200000)
         assert len(red.buckets) > 4 and sum(b[2] for b in red.buckets) == len(arena.items)
@@ -76,7 +82,7 @@ def _worker(rank, world, port, q):
         assert red.finish() and not red.active
         for k, p in model.named_parameters():
             want = sum(g[k] for g in grads)
-            torch.testing.assert_close(p.grad, want, rtol=1e-5, atol=1e-7)
+            torch.testing.assert_close(p.grad, want, rtol=5e-6 * world, atol=5e-8 * world + 2.5e-7 * world * float(want.abs().max()))
         t = torch.tensor([float(rank)])
         assert D.allreduce_max_scalar(t).item() == world - 1
         q.put((rank, "ok"))
@@ -90,8 +96,12 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_gradient_allreduce_gloo():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_gradient_allreduce_gloo(world):
+    """world = 4: more than two ranks on the gloo backend (eight -- BASELINE configs[3] -- pass too but take 2.5 minutes of start-up on
+    this 8-core box) -- parameter
+    broadcast, the whole-arena and the bucketed / overlapped gradient reduction against the mean of all shards' gradients."""
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -100,7 +110,7 @@ def test_two_rank_gradient_allreduce_gloo():
     res = [q.get(timeout=540) for _ in procs]
     for p in procs:
         p.join(60)
-    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
 
 
 def test_launch_ranks_spawns_one_process_per_device(tmp_path):

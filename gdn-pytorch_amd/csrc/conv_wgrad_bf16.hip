@@ -46,6 +46,8 @@ __device__ __forceinline__ s16x4 tr_read(const lds_u8* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
+#include "wgrad_ring.h"
+
 template <int NTW, int XV, int GV>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradBfParams& p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -376,9 +378,83 @@ int launch_cls(const WgradBfParams& P, int blocks, size_t lds, hipStream_t st) {
     return gdn_launch_status();
 }
 
+// ---- wgrad_ring_bf16 (wgrad_ring.h): plan ----
+struct PlanRing {
+    WgRingParams P;
+    size_t ws_bytes;
+    int blocks;
+};
+
+// Which layers take the ring kernel: stride-1 Conv2d with a 5x5 ... 9x9 window (3x3: two filter rows x three taps of a
+// 64 x 64 tile are too little MFMA work per staged byte -- those layers keep the round-1 kernel until a wider tile exists).
+bool make_plan_ring(const gdn_conv_geom* g, int Cx_in, bool forced, PlanRing& pl) {
+    if (!g || g->transposed || g->stride != 1) return false;
+    const int k = g->k;
+    if (k != 3 && k != 5 && k != 7 && k != 9) return false;
+    if (!forced && k == 3) return false;
+    int Ho, Wo;
+    if (gdn_conv_out_dims(g, &Ho, &Wo) != GDN_OK) return false;
+    if ((g->Cout % 64) || (Cx_in % 64) || Wo < 9 || Ho < 1) return false;
+    if (g->pad_mode == 1 && (g->pad >= g->H || g->pad >= g->W)) return false;
+    WgRingParams& P = pl.P;
+    P = WgRingParams{};
+    P.B = g->B; P.k = k; P.pad = g->pad; P.pad_mode = g->pad_mode;
+    P.Hg = Ho; P.Wg = Wo; P.Cg = g->Cout;
+    P.Hx = g->H; P.Wx = g->W; P.Cx = Cx_in;
+    // stage geometry: whole rows while they fit 224 pixels (as many as the X images allow), else 16-aligned strips of <= 208
+    if (Wo <= WR_GPX) {
+        P.nstrip = 1; P.TW = Wo; P.TWp = (Wo + 7) & ~7;
+        int n = WR_GPX / P.TWp;
+        if (n > Ho) n = Ho;
+        while (n > 1 && (size_t)2 * (n + 1) * (P.TWp + 8) * 128 > WR_XBYTES) --n;
+        P.nr = n;
+    } else {
+        P.nstrip = cdiv(Wo, 208);
+        P.TW = cdiv(cdiv(Wo, P.nstrip), 16) * 16;
+        P.TWp = P.TW; P.nr = 1;
+    }
+    P.ring = P.nr == 1;
+    P.RP = P.TWp + 8;
+    P.nks = cdiv(P.nr * P.TWp, 16);
+    if (P.nks * 16 > WR_GPX) return false;
+    if ((size_t)(P.ring ? 3 : 2 * (P.nr + 1)) * P.RP * 128 > WR_XBYTES) return false;
+    if ((P.ring ? 1 : P.nr + 1) * (P.RP / 8) > (P.ring ? 32 : 48)) return false;     // DMA pieces per stage the kernel unrolls
+    P.sph = cdiv(Ho, P.nr);
+    P.nst = P.B * P.nstrip * P.sph;
+    P.n_cgt = P.Cg / 64; P.n_cxt = P.Cx / 64;
+    P.gmagic = 65536 / P.TWp + 1; P.xmagic = 65536 / (P.RP / 8) + 1;
+    // split-K over stages: one workgroup per CU, every split runs all (filter-row pair, channel tile) units side by side
+    const int wps = ((k + 1) / 2) * P.n_cgt * P.n_cxt;
+    int S = 256 / wps;
+    if (S < 1) S = 1;
+    if (S > P.nst) S = P.nst;
+    P.ips = cdiv(P.nst, S);
+    P.S = cdiv(P.nst, P.ips);
+    pl.blocks = cdiv(P.S * wps, 8) * 8;
+    pl.ws_bytes = (size_t)P.S * k * k * P.Cg * P.Cx * sizeof(float);
+    return true;
+}
+
+int launch_ring(const WgRingParams& P, int blocks, hipStream_t st) {
+    const dim3 grid(blocks), blk(512);
+#define WR_LAUNCH(K) do { if (P.ring) hipLaunchKernelGGL((wgrad_ring_bf16<K, true>), grid, blk, 0, st, P); \
+                          else hipLaunchKernelGGL((wgrad_ring_bf16<K, false>), grid, blk, 0, st, P); } while (0)
+    switch (P.k) {
+        case 3: WR_LAUNCH(3); break;
+        case 5: WR_LAUNCH(5); break;
+        case 7: WR_LAUNCH(7); break;
+        default: WR_LAUNCH(9); break;
+    }
+#undef WR_LAUNCH
+    return gdn_launch_status();
+}
+
 }  // namespace
 
 extern "C" size_t gdn_conv_wgrad_bf16_workspace_bytes(const gdn_conv_geom* g, int32_t Cx, int32_t cfg) {
+    PlanRing pr;
+    if (((cfg & 7) == 0 || (cfg & 7) == 4) && make_plan_ring(g, Cx, (cfg & 7) == 4, pr)) return pr.ws_bytes;
+    if ((cfg & 7) == 4) return 0;
     PlanBf pl;
     if (!make_plan_bf(g, Cx, cfg & 3, pl)) return 0;
     return pl.ws_bytes;
@@ -389,6 +465,29 @@ extern "C" int gdn_conv_wgrad_bf16(const gdn_conv_geom* g, const void* x, int32_
                                    size_t workspace_bytes, int32_t cfg, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     if (!x || !dy || !dw) return GDN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    PlanRing pr;
+    if (((cfg & 7) == 0 || (cfg & 7) == 4) && make_plan_ring(g, Cx, (cfg & 7) == 4, pr)) {
+        if (!workspace || workspace_bytes < pr.ws_bytes) return GDN_ERR_WORKSPACE;
+        WgRingParams& R = pr.P;
+        R.g = dy; R.ldg = ldy; R.x = x; R.ldx = ldx;
+        if ((R.ldg % 8) || (R.ldx % 8) || ((uintptr_t)R.g % 16) || ((uintptr_t)R.x % 16)) return GDN_ERR_UNSUPPORTED;
+        const uint64_t gb = (((uint64_t)R.B * R.Hg * R.Wg - 1) * (uint64_t)R.ldg + R.Cg) * 2;
+        const uint64_t xb = (((uint64_t)R.B * R.Hx * R.Wx - 1) * (uint64_t)R.ldx + R.Cx) * 2;
+        if (gb >= 0xFF000000ull || xb >= 0xFF000000ull) return GDN_ERR_UNSUPPORTED;
+        R.g_bytes = (unsigned)gb; R.x_bytes = (unsigned)xb;
+        R.part = (float*)workspace;
+        R.knobs = (cfg >> 12) & 15;
+        int rc = launch_ring(R, pr.blocks, st);
+        if (rc != GDN_OK) return rc;
+        const int KK = R.k * R.k;
+        const int64_t n = (int64_t)KK * R.Cg * R.Cx;
+        const int blocks = (int)(cdiv64(n, 256) < 2048 ? cdiv64(n, 256) : 2048);
+        hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, R.S, KK,
+                           R.Cg, R.Cx, ld_dw, ci_off, 0, 0);
+        return gdn_launch_status();
+    }
+    if ((cfg & 7) == 4) return GDN_ERR_UNSUPPORTED;
     PlanBf pl;
     if (!make_plan_bf(g, Cx, cfg & 3, pl)) return GDN_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < pl.ws_bytes) return GDN_ERR_WORKSPACE;
@@ -403,7 +502,6 @@ extern "C" int gdn_conv_wgrad_bf16(const gdn_conv_geom* g, const void* x, int32_
         if (gb >= 0xFF000000ull || xb >= 0xFF000000ull) return GDN_ERR_UNSUPPORTED;
         P.g_bytes = (unsigned)gb; P.x_bytes = (unsigned)xb;
     }
-    hipStream_t st = (hipStream_t)stream;
     int rc = pl.cls == 1 ? launch_cls<3, 1>(P, pl.blocks, pl.lds_bytes, st)
            : pl.cls == 3 ? launch_cls<4, 4>(P, pl.blocks, pl.lds_bytes, st)
                          : launch_cls<8, 7>(P, pl.blocks, pl.lds_bytes, st);

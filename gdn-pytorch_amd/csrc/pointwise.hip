@@ -732,7 +732,7 @@ extern "C" int gdn_adam_step_dev(float* p, const float* g, float* m, float* v, i
     return gdn_launch_status();
 }
 
-extern "C" int gdn_version(void) { return 218; }
+extern "C" int gdn_version(void) { return 219; }
 
 extern "C" const char* gdn_strerror(int status) {
     switch (status) {

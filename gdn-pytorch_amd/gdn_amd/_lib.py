@@ -114,7 +114,7 @@ _STATUS_FUNCS = {n for n, (r, _) in _SIGS.items() if r is c_int32} - {"gdn_versi
 EXPORTS = tuple(_SIGS)
 # The C ABI revision these signatures (and ConvGeom's layout) describe: gdn_version() of the library must match exactly --
 # a stale build would take the arguments apart differently.
-ABI_VERSION = 218
+ABI_VERSION = 219
 
 
 class _Lib:

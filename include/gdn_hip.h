@@ -40,7 +40,7 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
-/* Revision of this header (argument lists, struct layouts).  218: gdn_gemm_x3_tn_splits.  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+/* Revision of this header (argument lists, struct layouts).  219: gdn_conv_wgrad_bf16 cfg 4 (wgrad_ring_bf16).  218: gdn_gemm_x3_tn_splits.  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
  * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
@@ -322,8 +322,15 @@ int gdn_gemm_x3_nt_packed(const void* Ap, const void* Bp, float* C, int32_t bins
 
 /* bf16 weight gradient (BASELINE configs[2]): x and dy hold bfloat16, dw is fp32 (the master
  * gradient arena).  Same contract as gdn_conv_wgrad otherwise.  Needs Cx and Cout multiples of
- * 64, pixel pitches multiples of 8 and 16-byte aligned bases.  cfg: 0 automatic, 1/2 force the
- * small/large staging class (tuning).  v_mfma_f32_32x32x16_bf16 fed by ds_read_b64_tr_b16. */
+ * 64, pixel pitches multiples of 8 and 16-byte aligned bases.  v_mfma_f32_32x32x16_bf16 fed by
+ * ds_read_b64_tr_b16.  cfg (low 3 bits): 0 automatic; 1 / 3 / 2 force the small / medium / large
+ * staging class of the round-1 kernel (tuning, tests); 4 forces wgrad_ring_bf16 (csrc/wgrad_ring.h,
+ * round 5: persistent workgroups, LDS-DMA staged row images, one filter-row pair per workgroup,
+ * the taps of a row as register shifts of one transposed window -- stride-1 Conv2d with a 3 / 5 / 7 / 9
+ * window; GDN_ERR_UNSUPPORTED otherwise), the automatic choice for 5x5 ... 9x9 windows.  Bits 12..15:
+ * measurement knobs of that kernel (timing-only variants that drop its DMA traffic or its MFMA
+ * loop; 0 in production).  The workspace query takes the same cfg.  Results are bitwise reproducible
+ * for a given geometry and cfg (fixed-order split-K). */
 size_t gdn_conv_wgrad_bf16_workspace_bytes(const gdn_conv_geom* g, int32_t Cx, int32_t cfg);
 int gdn_conv_wgrad_bf16(const gdn_conv_geom* g, const void* x, int32_t ldx, int32_t Cx,
                         const void* dy, int32_t ldy,

@@ -80,10 +80,16 @@ def test_conv_bf16_fwd_dgrad(gpu, case):
         dx3 = op.dgrad(gyd, wt, (H, W), addsrc=add.to(gpu).bfloat16(), tile_cfg=cfg)
         close(nchw(dx3.float()), x.grad + nchw(add), rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=name + " dgrad cfg%d" % cfg)
     # weight gradient: bf16 operands, fp32 accumulation and fp32 result -> only the summation order differs
-    for cfg in (0, 1, 3):
+    # 4: the LDS-DMA ring kernel of round 5 (csrc/wgrad_ring.h), where the geometry allows it
+    ring_ok = s == 1 and not tr and k in (3, 5, 7, 9)
+    for cfg in (0, 1, 3) + ((4,) if ring_ok else ()):
         dw = torch.full(wd.shape, float("nan"), device=gpu)
         op.wgrad(xd, gyd, dw, cfg=cfg)
         close(dw, tapmajor(w.grad, tr), rtol=2e-3, atol_scale=2e-4, what=name + " wgrad cfg%d" % cfg)
+    if not ring_ok:
+        from gdn_amd._lib import GdnError
+        with pytest.raises(GdnError):
+            op.wgrad(xd, gyd, torch.empty(wd.shape, device=gpu), cfg=4)
 
 
 def test_conv_bf16_concat_tanh_addsrc(gpu):
@@ -119,6 +125,66 @@ def test_wgrad_bf16_concat_halves(gpu):
     op.wgrad(nhwc(a).to(gpu).bfloat16(), nhwc(gy).to(gpu).bfloat16(), dw, 0)
     op.wgrad(wide[..., 16:80], nhwc(gy).to(gpu).bfloat16(), dw, 64)
     close(dw, tapmajor(w.grad, False), rtol=2e-3, atol_scale=2e-4, what="bf16 concat wgrad")
+
+
+# (name, Cin, Cout, k, pad, reflect, B, H, W): shapes that walk every path of wgrad_ring_bf16 -- rows in a ring of X row slots
+# (one-row stages: W > 112) and stages of several rows (double-buffered X images), strips (W > 224), a row width that is no
+# multiple of 8 or 16 (zero-padded runs), a stage count the row count does not divide, images shorter than a stage, split
+# boundaries inside an image, reflection, a padding that is not k // 2, several channel tiles
+RING_WGRAD_CASES = [
+    ("k9_20x40", 64, 64, 9, 4, False, 1, 20, 40),
+    ("k7_refl_12x64", 128, 64, 7, 3, True, 1, 12, 64),
+    ("k5_10x40", 64, 128, 5, 2, False, 2, 10, 40),
+    ("k3_8x26", 128, 192, 3, 1, False, 3, 8, 26),
+    ("k9_33x250_strips", 64, 64, 9, 4, False, 2, 33, 250),
+    ("k5_refl_7x19", 64, 64, 5, 2, True, 2, 7, 19),
+    ("k7_9x104", 64, 128, 7, 3, False, 2, 9, 104),
+    ("k3_refl_5x9", 64, 64, 3, 1, True, 1, 5, 9),
+    ("k9_pad2_24x48", 64, 64, 9, 2, False, 1, 24, 48),
+    ("k7_ring_6x120", 64, 64, 7, 3, False, 5, 6, 120),
+    ("k5_ring_refl_40x208", 64, 64, 5, 2, True, 3, 40, 208),
+    ("k3_pad0_11x30", 64, 64, 3, 0, False, 2, 11, 30),
+]
+
+
+@pytest.mark.parametrize("case", RING_WGRAD_CASES, ids=[c[0] for c in RING_WGRAD_CASES])
+def test_wgrad_ring_bf16_vs_float64(gpu, case):
+    """csrc/wgrad_ring.h against torch's conv2d weight gradient in float64 on the same bf16-rounded operands (the kernel sums the
+    exact bf16 products in fp32: 2e-6 of max|dW| is summation order), bitwise repeatable, equal to the round-1 kernel to rounding."""
+    import torch.nn.functional as F
+    from gdn_amd import ops
+    name, ci, co, k, p, refl, B, H, W = case
+    g = torch.Generator().manual_seed(11)
+    x = r16(torch.randn(B, H, W, ci, generator=g))
+    Ho, Wo = H + 2 * p - k + 1, W + 2 * p - k + 1
+    gy = r16(torch.randn(B, Ho, Wo, co, generator=g))
+    w = torch.zeros(co, ci, k, k, dtype=torch.float64, requires_grad=True)
+    xin = nchw(x).double()
+    if refl:
+        xin = F.pad(xin, (p, p, p, p), mode="reflect")
+    F.conv2d(xin, w, None, 1, 0 if refl else p).backward(nchw(gy).double())
+    ref = w.grad.permute(2, 3, 0, 1).reshape(k * k, co, ci)
+    op = ops.Conv(ci, co, k, 1, p, reflect=refl)
+    xd, gyd = x.to(gpu).bfloat16(), gy.to(gpu).bfloat16()
+    dw = torch.full((k * k, co, ci), float("nan"), device=gpu)
+    op.wgrad(xd, gyd, dw, cfg=4)
+    err = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, "%s: ring wgrad off by %.2e of max|dW|" % (name, err)
+    dw2 = torch.full_like(dw, float("nan"))
+    op.wgrad(xd, gyd, dw2, cfg=4)
+    assert torch.equal(dw, dw2), name + ": not bitwise repeatable"
+    dw1 = torch.empty_like(dw)
+    op.wgrad(xd, gyd, dw1, cfg=1)
+    assert float((dw - dw1).abs().max() / ref.abs().max()) < 4e-6, name + ": differs from the round-1 kernel"
+    # a channel slice of a wider tensor on both operands (pixel pitch != channels), written into a slice of a wider gradient
+    widex = torch.randn(B, H, W, ci + 64, generator=g).to(gpu).bfloat16()
+    widex[..., 32:32 + ci] = xd
+    widey = torch.randn(B, Ho, Wo, co + 16, generator=g).to(gpu).bfloat16()
+    widey[..., 8:8 + co] = gyd
+    op2 = ops.Conv(ci + 64, co, k, 1, p, reflect=refl)
+    dww = torch.zeros(k * k, co, ci + 64, device=gpu)
+    op2.wgrad(widex[..., 32:32 + ci], widey[..., 8:8 + co], dww, ci_off=64, cfg=4)
+    assert torch.equal(dww[..., 64:], dw) and float(dww[..., :64].abs().max()) == 0.0, name + ": pitched operands / offset result"
 
 
 def test_conv_bf16_rejects_unsupported(gpu):

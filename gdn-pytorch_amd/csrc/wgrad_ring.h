@@ -94,10 +94,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_ring_bf16(const WgRingParams p) 
     const int h = lane >> 5, q = (lane >> 2) & 3, g16 = (lane >> 4) & 1, pp = lane & 3;
 
     // ---- this workgroup's unit.  Workgroups b, b + 8, ... share an XCD; ids are dealt so that the workgroups of one split (same
-    // dY rows, overlapping X rows) are neighbours there.  (Measured and not kept: the workgroups of the single last filter row of
-    // an odd window -- half of their waves idle -- taking two splits each: LDS-DMA brings ~25 GB/s into a CU, a stage's 54 KB take
-    // 2.2 us against 4.1 us of MFMA work for a pair of rows, so with one row's work per stage those workgroups became DMA-bound
-    // and the critical path: 9x9 0.70 -> 0.91 ms.)
+    // dY rows, overlapping X rows) are neighbours there.  The workgroup of the single last filter row of an odd window has half
+    // of its waves idle (10 % of the 9x9 launch, 12.5 % of 7x7, 17 % of 5x5).  Measured and not kept, both with such a workgroup
+    // taking TWO splits so that the others get fewer stages: (a) as it is -- LDS-DMA brings ~25 GB/s into a CU, a stage's 54 KB
+    // take 2.2 us, and with one row's MFMA work per stage those workgroups became DMA-bound and the critical path: 9x9 0.70 ->
+    // 0.91 ms; (b) its two wave groups sharing the k-steps of the one row (summed through LDS at the end): a stage still costs it
+    // 3.3 us against 5.8 us of a row pair's (barrier, first reads, the DMA pieces its 6-7 k-steps cannot cover): 0.62 -> 0.75 ms.
     const int nblk = (int)gridDim.x;
     const int id = (int)(blockIdx.x & 7) * (nblk >> 3) + (int)(blockIdx.x >> 3);
     const int nct = p.n_cgt * p.n_cxt, nkg = (p.k + 1) >> 1;

@@ -47,7 +47,7 @@ struct WgRingParams {
     int RP, nks, ring;                    // X row pitch in positions, k-steps per stage, X rows live in a ring (nr == 1)
     unsigned g_bytes, x_bytes;
     int gmagic, xmagic;                   // 65536 / TWp + 1, 65536 / (RP / 8) + 1: the kernel's divisions by multiplication
-    int knobs;                            // measurement knobs (0 in production): 1 no DMA after the first stage, 2 no k-loop
+    int knobs;                            // measurement knobs (0 in production): 1 no DMA after the first stage, 2 no k-loop, 4 bare stage boundary
 };
 
 typedef int wr_i32x4 __attribute__((ext_vector_type(4)));
@@ -244,12 +244,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_ring_bf16(const WgRingParams p) 
     // One k-step = one basic block: the 2 + NR1 + NR2 reads of step t + 1, one LDS-DMA piece with its address arithmetic and the
     // KW MFMAs of step t with their shifts, interleaved by the scheduler as "one MFMA, one or two reads, a few vector / scalar
     // instructions": everything that is not an MFMA is issued in the shadow of one.
-    auto kstep = [&](int set, int t) {
-        rd_all(set ^ 1, t + 1);
-        if (set == 0) fire_x(t >> 1); else fire_g(t >> 1);
+    auto mfmas = [&](int set) {
         const wb_bf16x8 a = __builtin_bit_cast(wb_bf16x8, __builtin_shufflevector(fa[set][0], fa[set][1], 0, 1, 2, 3, 4, 5, 6, 7));
         taps(a, fw[set], 0);
         taps(a, fw2[set], 1);
+    };
+    auto kstep = [&](int set, int t) {
+        rd_all(set ^ 1, t + 1);
+        if (set == 0) fire_x(t >> 1); else fire_g(t >> 1);
+        mfmas(set);
         WrSched<KW, 2 + NR1 + NR2, 0>::apply();
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -264,7 +267,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_ring_bf16(const WgRingParams p) 
             for (int r_ = 0; r_ < 16; ++r_) acc[t][r_] = 0.f;
         }
         // ---- stage walk: the stage computed at counter c had its DMA fired during stage c - 1; a ring starts every strip
-        // column (and every split) with a virtual stage that brings in X row 0 of the filter-row pair ----
+        // column (and every split) with a virtual stage that brings in X row 0 of the filter-row pair.  The stage boundary
+        // (vmcnt(0), barrier) sits INSIDE the last k-step of a stage: behind the barrier the first fragment reads of the next stage
+        // go out, then the MFMAs of the last step run on operands that are in registers already -- the reads land under them
+        // instead of in front of an idle matrix pipe. ----
         int rb = i0 % p.sph, strip, b;
         { const int t2 = i0 / p.sph; strip = t2 % p.nstrip; b = t2 / p.nstrip; }
         int cur_i = i0;
@@ -274,6 +280,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_ring_bf16(const WgRingParams p) 
         if (si > 0) __builtin_amdgcn_s_barrier();              // (every wave is done with the previous split's LDS images)
 #pragma unroll 1
         for (int e = 0; e < NFS / 2; ++e) { fire_x(e); fire_g(e); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first stage's pieces have landed
+        __builtin_amdgcn_s_barrier();
+        gbase = offA;
+        xbase = (unsigned)(WR_X0 + (RING ? (z % 3) * ROWB : z * ROWB));
+        rd_all(0, 0);
         for (;;) {
             bool nxt_virt = false, has_next = true;
             if (!cur_virt) {
@@ -284,25 +295,37 @@ __global__ __launch_bounds__(512, 2) void wgrad_ring_bf16(const WgRingParams p) 
                     nxt_virt = RING && rb == 0;
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's pieces (fired a stage ago) have landed
-            __builtin_amdgcn_s_barrier();                       // ... everyone's; and every wave is done reading stage c - 1
             pf_b = b; pf_x0 = strip * p.TW; pf_oy0 = rb * nr - (nxt_virt ? 1 : 0); pf_virt = nxt_virt; pf_c = c + 1;
             pf_live = has_next && !(p.knobs & 1);              // (timing knob 1: the loop without its DMA traffic)
-            {
-                // (no branch around the stage's MFMA loop: a stage this wave does not compute -- virtual, or the missing filter
-                //  row of an odd window -- is a loop of zero k-steps; the register allocator otherwise keeps a second copy of the
-                //  accumulators for the path around it)
-                const int nk = (!cur_virt && has_ky && !(p.knobs & 2)) ? nks : 0;
-                gbase = (unsigned)((c & 1) * WR_GBYTES) + offA;
-                xbase = (unsigned)(WR_X0 + (RING ? ((c + z) % 3) * ROWB : ((c & 1) * (nr + 1) + z) * ROWB));
-                rd_all(0, 0);
-                int t = 0;
+            // (no branch around the stage's MFMA loop: a stage this wave does not compute -- virtual, or the missing filter row of
+            //  an odd window -- is a loop of zero k-steps; the register allocator otherwise keeps a second copy of the accumulators
+            //  for the path around it)
+            const int nk = (!cur_virt && has_ky && !(p.knobs & 2)) ? nks : 0;
+            // a stage with an odd number of k-steps keeps its last one (set 0) for the boundary; an even one ends on set 1 and the
+            // boundary is bare (the layers of the two networks all have 13 k-steps per stage)
+            const int nlast = nk & 1, npair = nk - nlast;
+            int t = 0;
 #pragma nounroll
-                for (; t + 1 < nk; t += 2) { kstep(0, t); kstep(1, t + 1); }
-                if (t < nk) { kstep(0, t); ++t; }
+            for (; t < npair; t += 2) { kstep(0, t); kstep(1, t + 1); }
 #pragma unroll 1
-                for (; t < NFS; ++t) { if (t & 1) fire_g(t >> 1); else fire_x(t >> 1); }   // (fewer k-steps than pieces: the rest goes out now)
+            for (int u = t; u < NFS; ++u) { if (u & 1) fire_g(u >> 1); else fire_x(u >> 1); }   // (pieces the k-steps did not fire)
+            // ---- the stage boundary, in front of the last k-step's MFMAs (timing knob 4: behind them, the bare boundary) ----
+            const int npre = (p.knobs & 4) ? nlast : 0;
+#pragma nounroll
+            for (int i = 0; i < npre; ++i) mfmas(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // the next stage's pieces have landed; this wave's reads of this stage too
+                __builtin_amdgcn_s_barrier();                   // ... everyone's
+                gbase = (unsigned)(((c + 1) & 1) * WR_GBYTES) + offA;
+                xbase = (unsigned)(WR_X0 + (RING ? ((c + 1 + z) % 3) * ROWB : (((c + 1) & 1) * (nr + 1) + z) * ROWB));
             }
+            rd_all(1, 0);                                      // the next stage's first fragments ...
+            __builtin_amdgcn_sched_barrier(0);
+#pragma nounroll
+            for (int i = 0; i < nlast - npre; ++i) mfmas(0);   // (zero or one trip: a loop, not a branch -- see nk above)
+            __builtin_amdgcn_sched_barrier(0);
+            fa[0][0] = fa[1][0]; fa[0][1] = fa[1][1]; fw[0] = fw[1]; fw2[0] = fw2[1];      // ... over to set 0, where a stage starts
             if (!has_next) break;
             cur_virt = nxt_virt; ++c;
         }

@@ -88,7 +88,10 @@ for name, ci, co, k, p, refl, H, W in SHAPES:
         dwk = torch.empty_like(dw1)
         tk1 = timeit(lambda: op.wgrad(x, gy, dwk, cfg=4 | (1 << 12)), reps=3)      # knob: no DMA after the first stage
         tk2 = timeit(lambda: op.wgrad(x, gy, dwk, cfg=4 | (2 << 12)), reps=3)      # knob: no MFMA loop
-        print("%-16s %7.1f GF | old (cfg %d) %6.1f TF %.3f ms | ring %6.1f TF %.3f ms  (diff %.1e, bitwise repeat %s) | no-DMA %.3f ms, no-kloop %.3f ms" % (
-            name, gf, old, gf / t0, t0, gf / t1, t1, d, same, tk1, tk2), flush=True)
+        ab = []
+        for _ in range(3):                                                         # interleaved A/B: default vs knob 4 (bare stage boundary)
+            ab.append((timeit(lambda: op.wgrad(x, gy, dw1, cfg=4), reps=5), timeit(lambda: op.wgrad(x, gy, dwk, cfg=4 | (4 << 12)), reps=5)))
+        print("%-16s %7.1f GF | old (cfg %d) %6.1f TF %.3f ms | ring %6.1f TF %.3f ms  (diff %.1e, bitwise repeat %s) | no-DMA %.3f ms, no-kloop %.3f ms | A/B default vs bare boundary: %s" % (
+            name, gf, old, gf / t0, t0, gf / t1, t1, d, same, tk1, tk2, " ".join("%.3f/%.3f" % v for v in ab)), flush=True)
     except Exception as e:
         print("%-16s %7.1f GF | old %6.1f TF | ring: %s" % (name, gf, gf / t0, e), flush=True)

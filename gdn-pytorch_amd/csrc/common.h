@@ -15,15 +15,16 @@ static inline int gdn_launch_status() {
     return e == hipSuccess ? GDN_OK : GDN_ERR_LAUNCH;
 }
 
-// GDN_PLAN_BATCH=<n> (test / measurement override, read per call): every plan that depends on the batch size -- the
-// frequency-domain tile size, the direct kernels' tile configuration and split-K factor -- is chosen as if the batch were n.
-// With it a batch-1 run takes the plans of a batch-n run, so an image's result can be compared BITWISE across batch sizes
-// (tests/test_hip_robustness.py::test_legacy_inference_b64_graph_matches_single_image).
-static inline int gdn_plan_batch(int B) {
-    const char* e = getenv("GDN_PLAN_BATCH");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : B;
-}
+// Plan overrides ride in gdn_conv_geom.hints (gdn_hip.h: GDN_HINT_PLAN_BATCH / GDN_HINT_PLAN_CUS / GDN_HINT_FFT_NP*): the library
+// reads no environment variable -- a plan is a function of the geometry a call carries, also inside a captured graph.
+int gdn_num_cus();      // conv_igemm.hip: CU count of the current device
+// the batch size the plans are made for: every plan that depends on it -- the frequency-domain tile size, the direct kernels'
+// tile configuration and split-K factor -- is chosen as if the batch were this, so that a batch-1 run can take the plans of a
+// batch-n run and an image's result be compared BITWISE across batch sizes
+// (tests/test_hip_robustness.py::test_legacy_inference_b64_graph_matches_single_image)
+static inline int gdn_plan_batch(const gdn_conv_geom* g) { const int v = (g->hints >> 8) & 0xff; return v ? v : g->B; }
+// the CU count the persistent kernels are planned for (tests: small shapes reach the multi-round / tail-split paths)
+static inline int gdn_plan_cus(const gdn_conv_geom* g) { const int v = (g->hints >> 16) & 0xff; return v ? v * 8 : gdn_num_cus(); }
 
 __host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -926,7 +926,7 @@ bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
     // waste of T = 28, the per-bin GEMMs get M = 540 rows instead of 160 (measured: forward GEMM -31 %, step -1.7 ms).
     {
         const int t32 = 33 - g->k;
-        const long m32 = (long)gdn_plan_batch(g->B) * cdiv(g->H, t32) * cdiv(g->W, t32);
+        const long m32 = (long)gdn_plan_batch(g) * cdiv(g->H, t32) * cdiv(g->W, t32);
         f.np = (g->k <= 5 && 3L * g->Cout > 2 * m32) ? 16 : 32;
         // 40-point tiles for a TRAINED layer (GDN_HINT_TRAIN) where they cut the transformed points by at least a fifth -- the
         // 9x9 layers at 128 x 416: T = 32 tiles the image exactly, 4 x 13 x 1600 points against 6 x 18 x 1024 -- and the weight
@@ -935,8 +935,7 @@ bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
         // 0.81 ms, backward 1.33 -> 1.17 ms; an eval-mode forward (frozen guide, inference) is slower and keeps 32 points.
         const int t40 = 41 - g->k;
         const long p32 = (long)cdiv(g->H, t32) * cdiv(g->W, t32) * 1024, p40 = (long)cdiv(g->H, t40) * cdiv(g->W, t40) * 1600;
-        const char* fe = getenv("GDN_FFT_NP");                      // measurement / test override: 32 or 40
-        const int force = fe ? atoi(fe) : 0;
+        const int force = (g->hints & GDN_HINT_FFT_NP32) ? 32 : (g->hints & GDN_HINT_FFT_NP40) ? 40 : 0;   // measurement / test override
         if (f.np == 32 && (g->hints & GDN_HINT_TRAIN) && g->k >= 7 && g->Cin <= 128 && g->Cout <= 128 && 5 * p40 <= 4 * p32) f.np = 40;
         if (force == 32 && f.np == 40) f.np = 32;
         if (force == 40 && f.np == 32 && g->k >= 5) f.np = 40;

@@ -33,6 +33,7 @@ struct IgemmParams {
     const float* x; const float* x2; const float* w; float* y; const float* addsrc; float* stats;
     const float* ep_scale; const float* ep_shift;   // optional per-channel affine of the epilogue (eval-mode BN fold)
     int B, Hi, Wi, C1, C2, ldx1, ldx2;
+    int plan_B, plan_cus;            // gdn_plan_batch() / gdn_plan_cus() of the geometry: what the host-side plans are made for
     int N, ldy, ld_add, Hy, Wy, osy, osx;
     int stride, pad_mode, act, nphase;
     int Cred, w_tap_stride;
@@ -991,9 +992,6 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __rest
 
 // CU count of the current device (a device attribute, read once per process: 256 on MI355X)
 int gdn_num_cus() {
-    // GDN_RING_CUS=<n> (test hook, read per call): plan the persistent kernels as for a chip with n CUs, so that small test
-    // shapes reach the multi-round / tail-split paths
-    if (const char* e = getenv("GDN_RING_CUS")) { const int v = atoi(e); if (v >= 8) return v / 8 * 8; }
     static const int n = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
@@ -1072,7 +1070,7 @@ RingPlan ring_plan(const IgemmParams& P, int bn) {
     const IgemmPhase& ph = P.ph[0];
     const int64_t M = (int64_t)P.B * ph.Ho * ph.Wo;
     r.grid_m = (int)cdiv64(M, RG_BM); r.grid_n = P.N / bn;
-    const int units = r.grid_m * r.grid_n, units_xcd = cdiv(r.grid_m, 8) * r.grid_n, cus_xcd = gdn_num_cus() / 8 > 0 ? gdn_num_cus() / 8 : 32;
+    const int units = r.grid_m * r.grid_n, units_xcd = cdiv(r.grid_m, 8) * r.grid_n, cus_xcd = P.plan_cus / 8 > 0 ? P.plan_cus / 8 : 32;
     r.G = 8 * (units_xcd < cus_xcd ? units_xcd : cus_xcd);
     const int kw = ring_kw(P), nstage = kw ? (ph.tap_end - ph.tap_begin) / kw * (P.Cred / 64) : 0;
     const int rounds = units / r.G, tail = units % r.G;
@@ -1111,7 +1109,7 @@ int pick_cfg_bf16(const IgemmParams& P, int64_t M, int N, int forced) {
     if (forced == 0 && ring_kw(P) != 0 && !P.x2 && N % 64 == 0) {
         // 256 x 128 tiles (0.75 fragment reads per MFMA instead of 1, no exchange of reduction halves) wherever they give every
         // CU at least one unit; else 256 x 64 (8x26 level: 68 units of 256 x 128 for 256 CUs)
-        if (N % 128 == 0 && cdiv64(M, RG_BM) * (N / 128) >= gdn_num_cus()) return 11;
+        if (N % 128 == 0 && cdiv64(M, RG_BM) * (N / 128) >= P.plan_cus) return 11;
         return 10;
     }
     if (rp && N <= 128 && cdiv64(M, RP_BM) * cdiv(N, 64) >= 448) return 9;
@@ -1133,7 +1131,7 @@ int pick_cfg_f32(int64_t M, int N, bool scalar, int forced) {
 int64_t max_phase_m(const IgemmParams& P);
 // the row count the PLANS (tile configuration, split-K factor) are chosen for: the launch's own, unless GDN_PLAN_BATCH
 // overrides the batch size (common.h)
-int64_t plan_phase_m(const IgemmParams& P) { return max_phase_m(P) / P.B * gdn_plan_batch(P.B); }
+int64_t plan_phase_m(const IgemmParams& P) { return max_phase_m(P) / P.B * P.plan_B; }
 int pick_cfg(const IgemmParams& P, int N, bool scalar, int tile_cfg) {
     const int64_t M = plan_phase_m(P);
     return (tile_cfg & CFG_BF16) ? pick_cfg_bf16(P, M, N, tile_cfg & 0xff) : pick_cfg_f32(M, N, scalar, tile_cfg & 0xff);
@@ -1395,6 +1393,7 @@ static int fill_fwd(const gdn_conv_geom* g, IgemmParams& P) {
     int Ho, Wo;
     if (gdn_conv_out_dims(g, &Ho, &Wo) != GDN_OK) return GDN_ERR_BAD_ARG;
     P.B = g->B; P.Hi = g->H; P.Wi = g->W; P.N = g->Cout; P.Cred = g->Cin;
+    P.plan_B = gdn_plan_batch(g); P.plan_cus = gdn_plan_cus(g);
     P.w_tap_stride = g->Cout * g->Cin;
     P.Hy = Ho; P.Wy = Wo;
     P.pad_mode = g->pad_mode;
@@ -1472,6 +1471,9 @@ extern "C" int gdn_conv_fwd(const gdn_conv_geom* g, const void* xv, int32_t ldx,
     // the row-patch kernel reads one input tensor; a fused concat with k >= 3 has no call site in the networks
     if (cfg >= 8 && x2) return GDN_ERR_UNSUPPORTED;
     if (cfg >= 10) P.kc = (tile_cfg >> 12) & 15;             // conv_ring_bf16: measurement knobs (0 in production)
+    // conv_ring_bf16's epilogue moves 16 bytes = 8 channels per lane on y and addsrc (the header's "pixel pitches
+    // multiples of 8" enforced on the output side too)
+    if (cfg >= 10 && ((ldy % 8) || (addsrc && (ld_add % 8)))) return GDN_ERR_UNSUPPORTED;
     const int ksplit = pick_ksplit(P, cfg, scalar, tile_cfg);
     if (ksplit > 1 && (!workspace || workspace_bytes < ksplit_bytes(P, ksplit))) return GDN_ERR_WORKSPACE;
     if (ring_ws_bytes(P, cfg) && (!workspace || workspace_bytes < ring_ws_bytes(P, cfg))) return GDN_ERR_WORKSPACE;
@@ -1484,6 +1486,7 @@ static bool fill_dgrad(const gdn_conv_geom* g, IgemmParams& P, bool& fold, bool&
     int Ho, Wo;
     if (!geom_ok(g) || gdn_conv_out_dims(g, &Ho, &Wo) != GDN_OK) return false;
     P.B = g->B; P.Hi = Ho; P.Wi = Wo;             // the gathered tensor is dy
+    P.plan_B = gdn_plan_batch(g); P.plan_cus = gdn_plan_cus(g);
     P.N = g->Cin; P.Cred = g->Cout; P.C1 = g->Cout; P.C2 = 0;
     P.w_tap_stride = g->Cin * g->Cout;
     P.pad_mode = 0; P.act = GDN_ACT_NONE;
@@ -1567,6 +1570,7 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t l
     if (fold) { P.y = (float*)workspace; P.ldy = g->Cin; P.addsrc = nullptr; P.ld_add = 0; }
     else { P.y = dx; P.ldy = ldx; P.addsrc = addsrc; P.ld_add = ld_add; }
     if ((ksplit > 1 || rb) && ((P.ldy % 4) || (P.addsrc && (P.ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
+    if (cfg >= 10 && ((P.ldy % 8) || (P.addsrc && (P.ld_add % 8)) || (bnb_y && (ld_bnb % 8)))) return GDN_ERR_UNSUPPORTED;   // (16-byte epilogue accesses)
     P.kc = (!scalar && g->Cout % 64 == 0 && (tile_cfg & 0x200)) ? 64 : 32;
     if (cfg >= 10) P.kc = (tile_cfg >> 12) & 15;
     if (bnb_y) {

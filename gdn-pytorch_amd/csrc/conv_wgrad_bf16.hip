@@ -425,7 +425,7 @@ bool make_plan_ring(const gdn_conv_geom* g, int Cx_in, bool forced, PlanRing& pl
     P.gmagic = 65536 / P.TWp + 1; P.xmagic = 65536 / (P.RP / 8) + 1;
     // split-K over stages: one workgroup per CU, every split runs all (filter-row pair, channel tile) units side by side
     const int wps = ((k + 1) / 2) * P.n_cgt * P.n_cxt;
-    int S = 256 / wps;
+    int S = gdn_plan_cus(g) / wps;
     if (S < 1) S = 1;
     if (S > P.nst) S = P.nst;
     P.ips = cdiv(P.nst, S);

@@ -63,11 +63,6 @@ void launch_gemm_x3_nt(const float* A, const void* Bp, float* C, int bins, int M
 // packs fp32 row-major [bins][rows][K] into panels (rows padded with zeros to whole tiles)
 void launch_x3_pack_rows(const float* src, void* dst, int bins, int rows, int K, hipStream_t st);
 static inline bool gemm_x3_ok(int M, int N, int K) { return M >= 1 && N >= 128 && N % 128 == 0 && K >= 32 && K % 32 == 0; }
-// The same product with BOTH operands packed (gemm_x3_ring.h: LDS-DMA ring, persistent workgroups, K-split tail).  Ap: panels of
-// [bins][M][K] (rows padded to whole 128-row panels), ws: gemm_x3_ring_ws_bytes() of scratch.
-bool gemm_x3_ring_ok(int bins, int M, int N, int K);
-size_t gemm_x3_ring_ws_bytes();
-void launch_gemm_x3_ring(const void* Ap, const void* Bp, float* C, void* ws, int bins, int M, int N, int K, hipStream_t st);
 // P[split][bin][i][j] = sum over the split's rows t of A[bin][t][i] * Bm[bin][t][j]  (fp32 row-major operands [bins][T][NI] /
 // [bins][T][NJ], both split on the fly); the caller sums the nsplit partial sets in a fixed order.  NI, NJ multiples of 128.
 void launch_gemm_x3_tn(const float* A, const float* Bm, float* P, int bins, int T, int NI, int NJ, int nsplit, hipStream_t st);

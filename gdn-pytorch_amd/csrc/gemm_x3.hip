@@ -1,8 +1,6 @@
 // fp32 per-bin GEMMs as bf16 x 3 split products on v_mfma_f32_32x32x16_bf16 (see gemm_x3.h for the arithmetic and the layout).
 #include "gemm_x3.h"
-#include "gemm_x3_ring.h"
 
-int gdn_num_cus();      // conv_igemm.hip
 
 namespace {
 
@@ -369,71 +367,13 @@ void launch_gemm_x3_nt(const float* A, const void* Bp, float* C, int bins, int M
     // Measured (B = 20, profiles/r03_gemm_x3_time_*.txt): the 256-thread kernel (two workgroups per CU, two barriers per stage)
     // is the fastest on the large GEMMs (level 3: 0.264 ms against 0.281 for the 512-thread double-buffered one); with few row
     // tiles (level 4, M = 1040: 576 tiles of 128 rows = 2.25 rounds of the chip) 64-row tiles win (0.067 against 0.078 ms).
-    // GDN_X3_NT = 4 / 8 / 64 forces a variant (measurement).
-    const char* e = getenv("GDN_X3_NT");
-    const int v = e ? atoi(e) : 0;
-    const bool small = v == 64 || (v == 0 && (int64_t)MT * NT * bins < 4 * 256);
+    // (the 512-thread 128-row variant gemm_x3_nt8_kernel<128> was measured against these two and is not dispatched)
+    const bool small = (int64_t)MT * NT * bins < 4 * 256;
     if (small)
         hipLaunchKernelGGL(gemm_x3_nt8_kernel<64>, dim3(((M + 63) / 64) * NT * bg * 8), dim3(512), 0, st, A, (const unsigned char*)Bp, C, M,
                            N, K, bins);
-    else if (v == 8)
-        hipLaunchKernelGGL(gemm_x3_nt8_kernel<128>, dim3(MT * NT * bg * 8), dim3(512), 0, st, A, (const unsigned char*)Bp, C, M, N, K, bins);
     else
         hipLaunchKernelGGL(gemm_x3_nt_kernel, dim3(MT * NT * bg * 8), dim3(256), 0, st, A, (const unsigned char*)Bp, C, M, N, K, bins);
-}
-
-// ---- the ring kernel's plan ----
-bool gemm_x3_ring_ok(int bins, int M, int N, int K) {
-    if (!(bins >= 1 && M >= 1 && N >= 128 && N % 128 == 0 && K >= 32 && K % 32 == 0)) return false;
-    const uint64_t lim = 0xFF000000ull;                       // buffer descriptors address 32 bits
-    return (uint64_t)bins * x3_packed_bytes(M, K) < lim && (uint64_t)bins * x3_packed_bytes(N, K) < lim && (uint64_t)M * N * 4 < lim;
-}
-
-static X3RingArgs x3r_args(const void* Ap, const void* Bp, float* C, void* ws, int bins, int M, int N, int K) {
-    X3RingArgs a;
-    a.Ap = (const unsigned char*)Ap; a.Bp = (const unsigned char*)Bp; a.C = C; a.slabs = (float*)ws;
-    a.a_bytes = (unsigned)((uint64_t)bins * x3_packed_bytes(M, K)); a.b_bytes = (unsigned)((uint64_t)bins * x3_packed_bytes(N, K));
-    a.bins = bins; a.M = M; a.N = N; a.K = K;
-    a.PM = (M + 127) / 128; a.NTt = N / 128;
-    a.pairs = a.PM / 2; a.single = a.PM & 1;
-    a.upb = a.pairs * a.NTt + a.single * ((a.NTt + 1) / 2);
-    const int cus = gdn_num_cus();
-    a.wgx = cus >= 8 ? cus / 8 : 1;
-    const char* e = getenv("GDN_X3_RING_TAIL");                // measurement: 0 keeps the last round's units whole
-    a.max_parts = (e && e[0] == '0') ? 1 : 8;
-    return a;
-}
-
-size_t gemm_x3_ring_ws_bytes() { return (size_t)(gdn_num_cus() >= 8 ? gdn_num_cus() / 8 * 8 : 8) * X3R_UNIT_FLOATS * sizeof(float) + 64; }
-
-// C = A * B^T with both operands packed (A: x3 panels of [bins][M][K], rows padded to whole 128-row panels).  ws: gemm_x3_ring_ws_bytes().
-void launch_gemm_x3_ring(const void* Ap, const void* Bp, float* C, void* ws, int bins, int M, int N, int K, hipStream_t st) {
-    const X3RingArgs a = x3r_args(Ap, Bp, C, ws, bins, M, N, K);
-    const char* e = getenv("GDN_X3_RING_KNOBS");               // measurement
-    const int kn = e ? atoi(e) : 0;
-    const dim3 grid(8 * a.wgx), blk(512);
-    switch (kn) {
-        case 1: hipLaunchKernelGGL(gemm_x3_ring_kernel<1>, grid, blk, 0, st, a); break;
-        case 2: hipLaunchKernelGGL(gemm_x3_ring_kernel<2>, grid, blk, 0, st, a); break;
-        case 4: hipLaunchKernelGGL(gemm_x3_ring_kernel<4>, grid, blk, 0, st, a); break;
-        case 6: hipLaunchKernelGGL(gemm_x3_ring_kernel<6>, grid, blk, 0, st, a); break;
-        case 8: hipLaunchKernelGGL(gemm_x3_ring_kernel<8>, grid, blk, 0, st, a); break;
-        case 9: hipLaunchKernelGGL(gemm_x3_ring_kernel<9>, grid, blk, 0, st, a); break;
-        case 12: hipLaunchKernelGGL(gemm_x3_ring_kernel<12>, grid, blk, 0, st, a); break;
-        case 13: hipLaunchKernelGGL(gemm_x3_ring_kernel<13>, grid, blk, 0, st, a); break;
-        case 16: hipLaunchKernelGGL(gemm_x3_ring_kernel<16>, grid, blk, 0, st, a); break;
-        case 17: hipLaunchKernelGGL(gemm_x3_ring_kernel<17>, grid, blk, 0, st, a); break;
-        case 18: hipLaunchKernelGGL(gemm_x3_ring_kernel<18>, grid, blk, 0, st, a); break;
-        case 22: hipLaunchKernelGGL(gemm_x3_ring_kernel<22>, grid, blk, 0, st, a); break;
-        case 24: hipLaunchKernelGGL(gemm_x3_ring_kernel<24>, grid, blk, 0, st, a); break;
-        default: hipLaunchKernelGGL(gemm_x3_ring_kernel<0>, grid, blk, 0, st, a); break;
-    }
-    int max_tail = 0;
-    for (int x = 0; x < 8; ++x) {
-        const X3RingXcd xs = x3r_xcd(a, x);
-        if (xs.parts > 1 && xs.tail > max_tail) max_tail = xs.tail;
-    }
-    if (max_tail > 0) hipLaunchKernelGGL(x3r_combine_kernel, dim3(max_tail * (X3R_UNIT_FLOATS / 1024), 8), dim3(256), 0, st, a);
 }
 
 void launch_gemm_x3_tn(const float* A, const float* Bm, float* P, int bins, int T, int NI, int NJ, int nsplit, hipStream_t st) {
@@ -468,18 +408,6 @@ extern "C" int gdn_gemm_x3_nt(const float* A, const void* Bp, float* C, int32_t 
 extern "C" int64_t gdn_gemm_x3_tn_splits(int32_t bins, int32_t T, int32_t NI, int32_t NJ) {
     if (bins < 1 || !gemm_x3_tn_ok(T, NI, NJ)) return 0;
     return gemm_x3_tn_splits(bins, T, NI, NJ);
-}
-
-extern "C" size_t gdn_gemm_x3_ring_workspace_bytes(void) { return gemm_x3_ring_ws_bytes(); }
-
-extern "C" int gdn_gemm_x3_nt_packed(const void* Ap, const void* Bp, float* C, int32_t bins, int32_t M, int32_t N, int32_t K,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
-    (void)hipGetLastError();
-    if (!Ap || !Bp || !C || bins < 1) return GDN_ERR_BAD_ARG;
-    if (!gemm_x3_ring_ok(bins, M, N, K)) return GDN_ERR_UNSUPPORTED;
-    if (!workspace || workspace_bytes < gemm_x3_ring_ws_bytes()) return GDN_ERR_WORKSPACE;
-    launch_gemm_x3_ring(Ap, Bp, C, workspace, bins, M, N, K, (hipStream_t)stream);
-    return gdn_launch_status();
 }
 
 extern "C" int gdn_gemm_x3_tn(const float* A, const float* Bm, float* P, int32_t bins, int32_t T, int32_t NI, int32_t NJ,

@@ -72,9 +72,7 @@ _SIGS = {
     "gdn_gemm_x3_pack": (c_int32, [_P, _P, _i32, _i32, _i32, _P]),
     "gdn_gemm_x3_nt": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, _P]),
     "gdn_gemm_x3_tn": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, _i32, _P]),
-    "gdn_gemm_x3_ring_workspace_bytes": (_sz, []),
     "gdn_gemm_x3_tn_splits": (_i64, [_i32, _i32, _i32, _i32]),
-    "gdn_gemm_x3_nt_packed": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, _P, _sz, _P]),
     "gdn_transpose_taps": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P]),
     "gdn_cast": (c_int32, [_P, _P, _i64, _i32, _P]),
     "gdn_weight_to_tapmajor": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _P]),

@@ -427,13 +427,22 @@ def launch_ranks(argv, devices, module="gdn_amd.GDN_main", extra_env=None, timeo
         for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP, signal.SIGQUIT):
             prev[sg] = signal.signal(sg, on_signal)
 
+    # a SIGKILLed launcher cannot run its `finally`: the kernel delivers SIGKILL to the rank when the launcher's thread ends.
+    # the hook runs between fork and exec, possibly beside other threads of the launcher -- it must not import or
+    # dlopen anything there (a loader / import lock held by another thread at fork time would deadlock the child), so libc's
+    # prctl is resolved HERE, once; and a launcher that died before the prctl ran is noticed by the parent-pid check.
+    try:
+        import ctypes
+        _prctl = ctypes.CDLL("libc.so.6", use_errno=True).prctl
+    except Exception:  # noqa: BLE001
+        _prctl = None
+    launcher_pid, kill_sig = os.getpid(), int(signal.SIGKILL)
+
     def die_with_parent():
-        # a SIGKILLed launcher cannot run its `finally`: the kernel delivers SIGKILL to the rank when the launcher's thread ends
-        try:
-            import ctypes
-            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)      # PR_SET_PDEATHSIG
-        except Exception:  # noqa: BLE001
-            pass
+        if _prctl is not None:
+            _prctl(1, kill_sig, 0, 0, 0)      # PR_SET_PDEATHSIG
+            if os.getppid() != launcher_pid:
+                os._exit(1)
     rc = 0
     try:
         for r in range(world):

@@ -44,7 +44,22 @@ def _chk(t, name="tensor", bf16_ok=False):
 
 
 CFG_BF16 = 0x10000      # GDN_CFG_BF16
-HINT_TRAIN, HINT_NO_X3, HINT_NO_WINO_F4 = 1, 2, 4      # GDN_HINT_* bits of gdn_conv_geom.hints
+HINT_TRAIN, HINT_NO_X3, HINT_NO_WINO_F4, HINT_FFT_NP32, HINT_FFT_NP40 = 1, 2, 4, 8, 16      # GDN_HINT_* bits of gdn_conv_geom.hints
+
+
+def plan_override_hints():
+    """Test / measurement hooks of THIS BINDING (the C library reads no environment variable): GDN_PLAN_BATCH=<n>,
+    GDN_RING_CUS=<n>, GDN_FFT_NP=<32|40> become the plan-override fields of gdn_conv_geom.hints of every geometry built while
+    they are set."""
+    h = 0
+    e = os.environ
+    if e.get("GDN_PLAN_BATCH"):
+        h |= (int(e["GDN_PLAN_BATCH"]) & 0xff) << 8
+    if e.get("GDN_RING_CUS") and int(e["GDN_RING_CUS"]) >= 8:
+        h |= ((int(e["GDN_RING_CUS"]) // 8) & 0xff) << 16
+    if e.get("GDN_FFT_NP") in ("32", "40"):
+        h |= HINT_FFT_NP32 if e["GDN_FFT_NP"] == "32" else HINT_FFT_NP40
+    return h
 
 # bf16 x 3 split products for the Winograd per-bin GEMMs (DESIGN.md 2.10).  The switch lives HERE, not in the library: the
 # environment variable GDN_X3 is read once, at import; distributed._guard_shared_gpu (ranks sharing one GPU), tests and
@@ -168,6 +183,7 @@ class Conv:
             hints |= HINT_NO_X3
         if not (_f4 if f4 is None else f4):
             hints |= HINT_NO_WINO_F4
+        hints |= plan_override_hints()
         key = (B, H, W, hints)
         g = self._geom.get(key)
         if g is None:
@@ -529,15 +545,6 @@ def gemm_x3_nt(A, Bp, N, out=None):
     bins, M, K = A.shape
     C = out if out is not None else torch.empty((bins, M, N), dtype=torch.float32, device=A.device)
     lib.gdn_gemm_x3_nt(_p(A), _p(Bp), _p(C), bins, M, N, K, stream())
-    return C
-
-
-def gemm_x3_nt_packed(Ap, Bp, bins, M, N, K, out=None):
-    """C[bin] = A[bin] @ B[bin]^T with BOTH operands packed (gemm_x3_pack of [bins, M, K] and of [bins, N, K]); fp32 C [bins, M, N]."""
-    C = out if out is not None else torch.empty((bins, M, N), dtype=torch.float32, device=Ap.device)
-    nb = int(lib.gdn_gemm_x3_ring_workspace_bytes())
-    ws = workspace(nb, Ap.device, "x3ring")
-    lib.gdn_gemm_x3_nt_packed(_p(Ap), _p(Bp), _p(C), bins, M, N, K, _p(ws), nb, stream())
     return C
 
 

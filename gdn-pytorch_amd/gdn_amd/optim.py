@@ -48,24 +48,33 @@ class Adam(torch.optim.Optimizer):
                 loose.append(p)
         return arenas, loose
 
-    def _ensure_dev(self, st, group, device):
-        """Device-side step state of the capturable path for one state store: hyper float32[6] and {double beta1^t, double
-        beta2^t, int32 t, float bc1, float bc2s}; a host-side step count from before (resume) is folded in by advancing the
-        powers on the host first."""
+    @staticmethod
+    def _dev_state(group, t, device):
+        """{double beta1^t, double beta2^t, int32 t, float bc1, float bc2s} for `t` steps TAKEN so far (the kernel advances it
+        before it uses it)."""
+        import struct
+        if torch.cuda.is_current_stream_capturing():
+            raise GdnError("capturable Adam: a device step counter would be created (and reset by every replay) inside a graph "
+                           "capture; run one eager step with the same gradient coverage first")
+        b1, b2 = group["betas"]
+        raw = struct.pack("<ddiff", float(b1) ** t, float(b2) ** t, t, 0.0, 0.0)
+        return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+    def _ensure_dev(self, st, group, device, steps_taken):
+        """Device-side step state of the capturable path for one state store: hyper float32[6] and the step state of
+        _dev_state(); `steps_taken` = the host-side count of updates this store has had (a resume folds it in by advancing the
+        powers on the host first)."""
         if "hyper" not in st:
-            import struct
-            b1, b2 = group["betas"]
             st["hyper"] = torch.zeros(6, dtype=torch.float32, device=device)
-            t = st["step"] - 1
-            raw = struct.pack("<ddiff", float(b1) ** t, float(b2) ** t, t, 0.0, 0.0)
-            st["state"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+            st["state"] = self._dev_state(group, steps_taken, device)
             st["group"] = group
         self._push_hyper(st, group)
 
     def _apply(self, pdata, grad, st, group, device):
         b1, b2 = group["betas"]
         if self.capturable:
-            self._ensure_dev(st, group, device)
+            self._ensure_dev(st, group, device, st["step"] - 1)      # (step() has counted this update already)
+            st["full_dev"] = True         # the store's device counter has taken every update so far: a valid thing to copy
             ops.adam_step_dev(pdata, grad, st["m"], st["v"], st["hyper"], st["state"])
         else:
             ops.adam_step(pdata, grad, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"],
@@ -82,8 +91,11 @@ class Adam(torch.optim.Optimizer):
             st["pstep"] = {id(p): st["step"] for p, _, _, _ in ar.items}
         b1, b2 = group["betas"]
         if self.capturable:
-            had_dev = "hyper" in st
-            self._ensure_dev(st, group, ar.device)
+            # the arena's device counter may be copied only if the one-launch path has driven it (then it also holds
+            # the updates that graph replays made behind the host's back); when the very first step is already partial, there
+            # is no such counter and every parameter starts from its host count
+            had_dev = bool(st.get("full_dev"))
+            self._ensure_dev(st, group, ar.device, st["step"])
             pdev = st.setdefault("pdev", {})
         for p, o, n, tr in ar.items:
             if p.grad is None:
@@ -98,12 +110,12 @@ class Adam(torch.optim.Optimizer):
                 ds = pdev.get(id(p))
                 if ds is None:
                     if had_dev:
+                        if torch.cuda.is_current_stream_capturing():
+                            raise GdnError("capturable Adam: a per-parameter step counter would be created inside a graph capture "
+                                           "(every replay would reset it); run one eager step with this gradient coverage first")
                         ds = st["state"].clone()          # the arena's device counter so far (no host read)
                     else:
-                        import struct
-                        t = st["pstep"][id(p)] - 1
-                        raw = struct.pack("<ddiff", float(b1) ** t, float(b2) ** t, t, 0.0, 0.0)
-                        ds = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(ar.device)
+                        ds = self._dev_state(group, st["pstep"][id(p)] - 1, ar.device)
                     pdev[id(p)] = ds
                 ops.adam_step_dev(ar.data[o:o + n], gslice, st["m"][o:o + n], st["v"][o:o + n], st["hyper"], ds)
             else:
@@ -127,6 +139,11 @@ class Adam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             arenas, loose = self._arena_groups(group)
             for ar, ps in arenas.values():
+                if getattr(ar, "carry_reduced", None) is not None:
+                    # (backward, sync_gradients, backward) under data parallelism leaves the first micro-batch's
+                    # REDUCED gradient aside until the next sync_gradients() adds it back; stepping now would drop it silently
+                    raise GdnError("optimizer.step() with an accumulated, already all-reduced gradient pending: call "
+                                   "sync_gradients() after the last backward of an accumulation")
                 if len(ps) != len(ar.items):
                     loose.extend(ps)      # partial coverage: fall back to per-tensor launches
                     continue

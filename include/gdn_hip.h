@@ -40,7 +40,7 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
-/* Revision of this header (argument lists, struct layouts).  219: gdn_conv_wgrad_bf16 cfg 4 (wgrad_ring_bf16).  218: gdn_gemm_x3_tn_splits.  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+/* Revision of this header (argument lists, struct layouts).  219: gdn_conv_wgrad_bf16 cfg 4 (wgrad_ring_bf16); gdn_gemm_x3_nt_packed / gdn_gemm_x3_ring_workspace_bytes removed (the measured-and-not-wired kernel now lives under tests/diag/).  218: gdn_gemm_x3_tn_splits.  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
  * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
@@ -71,7 +71,15 @@ typedef struct {
  * frequency-domain path then tiles for the sum of both passes: 40-point tiles (32 valid outputs of a 9x9 window: 128 x 416
  * is exactly 4 x 13 of them, 26 % fewer transformed points) shorten the three per-bin GEMM chains of a training step by a
  * quarter but make the forward's single-pass transforms slower, so inference / frozen layers keep the 32-point tiles. */
-enum { GDN_HINT_TRAIN = 1, GDN_HINT_NO_X3 = 2, GDN_HINT_NO_WINO_F4 = 4 };
+enum { GDN_HINT_TRAIN = 1, GDN_HINT_NO_X3 = 2, GDN_HINT_NO_WINO_F4 = 4, GDN_HINT_FFT_NP32 = 8, GDN_HINT_FFT_NP40 = 16 };
+/* Plan overrides (tests, measurements; 0 = none), fields of `hints`: the library itself reads no environment variable.
+ *   GDN_HINT_PLAN_BATCH(n), bits 8..15: every plan that depends on the batch size is made as if the batch were n (1..255), so
+ *                           a batch-1 call takes the plans of a batch-n call and an image compares bitwise across batch sizes;
+ *   GDN_HINT_PLAN_CUS(n),   bits 16..23: the persistent kernels (conv_ring_bf16, wgrad_ring_bf16) are planned as for a chip
+ *                           with n CUs (a multiple of 8, <= 2040): small test shapes reach the multi-round / split paths;
+ *   GDN_HINT_FFT_NP32 / _NP40: gdn_fftconv_* plans 32- / 40-point tiles where it would choose the other. */
+#define GDN_HINT_PLAN_BATCH(n) (((n) & 0xff) << 8)
+#define GDN_HINT_PLAN_CUS(n) ((((n) / 8) & 0xff) << 16)
 /* GDN_HINT_NO_X3: the Winograd paths (gdn_winoconv_*, gdn_wino2conv_*) run their per-bin GEMMs on the fp32 matrix
  * instruction instead of as bf16 x 3 split products (gdn_gemm_x3_*).  Same results to rounding.  The library reads no
  * environment variable for this: the caller decides once (gdn_amd/ops.py: set_x3; ranks that share one GPU switch it off,
@@ -311,14 +319,9 @@ int gdn_gemm_x3_pack(const float* src, void* dst, int32_t bins, int32_t rows, in
 int gdn_gemm_x3_nt(const float* A, const void* Bp, float* C, int32_t bins, int32_t M, int32_t N, int32_t K, void* stream);
 int gdn_gemm_x3_tn(const float* A, const float* B, float* P, int32_t bins, int32_t T, int32_t NI, int32_t NJ, int32_t nsplit,
                    void* stream);
-/* gdn_gemm_x3_nt with A packed as well (gdn_gemm_x3_pack of [bins][M][K]): the LDS-DMA ring kernel (csrc/gemm_x3_ring.h) the
- * Winograd layers run on when their transforms write panels.  workspace: gdn_gemm_x3_ring_workspace_bytes(). */
-size_t gdn_gemm_x3_ring_workspace_bytes(void);
 /* host query: the number of reduction splits gdn_winoconv_bwd / gdn_wino2conv_bwd give gdn_gemm_x3_tn for a shape (0: shape not
  * eligible): rounds of the chip per split plus the partial-product sets read back, DESIGN.md 2.10 */
 int64_t gdn_gemm_x3_tn_splits(int32_t bins, int32_t T, int32_t NI, int32_t NJ);
-int gdn_gemm_x3_nt_packed(const void* Ap, const void* Bp, float* C, int32_t bins, int32_t M, int32_t N, int32_t K,
-                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* bf16 weight gradient (BASELINE configs[2]): x and dy hold bfloat16, dw is fp32 (the master
  * gradient arena).  Same contract as gdn_conv_wgrad otherwise.  Needs Cx and Cout multiples of

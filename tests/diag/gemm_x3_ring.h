@@ -1,3 +1,6 @@
+// NOT PART OF THE LIBRARY (moved here in round 5): the LDS-DMA ring form of the bf16 x 3 GEMM, built and measured in round 4
+// (profiles/r04d_x3_ring_time_and_clock.txt: 6-14 % faster back to back, 0-5 % between memory-bound kernels) and never wired
+// into a layer.  Kept as a record of the experiment; it was reachable through gdn_gemm_x3_nt_packed (header revisions 214-218).
 // fp32 per-bin GEMMs as bf16 x 3 split products, third structure: BOTH operands packed (gemm_x3.h panels), staged by LDS-DMA
 // into a ring of k16 sub-stages, one workgroup per CU, persistent.  (Round 4; the structure of conv_ring.h applied to the NT GEMM.)
 //

@@ -22,7 +22,6 @@ for name, bins, M, N, K in (("F4 l3", 36, 1040, 512, 512), ("F4 l4", 36, 280, 51
         ms = timed_duty(lambda: ops.gemm_x3_nt(A, Bp, N, out=C))
         print("%-6s nt variant %2s: %.3f ms" % (name, v, ms), flush=True)
     os.environ.pop("GDN_X3_NT")
-    print("%-6s ring (A packed): %.3f ms" % (name, timed_duty(lambda: ops.gemm_x3_nt_packed(Ap, Bp, bins, M, N, K, out=C))), flush=True)
     D = torch.randn(bins, M, N, device=dev)
     for ns in (1, 2, 3):
         if M // ns >= 256 or ns == 1:

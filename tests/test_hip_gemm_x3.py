@@ -72,48 +72,3 @@ def test_gemm_x3_tn_exact_on_integers(gpu):
     ref = torch.bmm(A.double().transpose(1, 2), B.double())
     P = ops.gemm_x3_tn(A.to(gpu), B.to(gpu), 2).cpu().double().sum(0)
     assert torch.equal(P, ref)
-
-
-@pytest.mark.parametrize("bins,M,N,K,cus", [(1, 128, 128, 32, 0), (3, 300, 384, 96, 0), (16, 1040, 512, 512, 0), (9, 700, 256, 128, 16),
-                                            (5, 129, 128, 64, 8), (2, 1000, 640, 256, 32)])
-def test_gemm_x3_ring_matches_nt_kernel(gpu, bins, M, N, K, cus, monkeypatch):
-    """The LDS-DMA ring kernel (csrc/gemm_x3_ring.h: both operands packed, persistent workgroups) against gemm_x3_nt: the same
-    products in the same order per accumulator, so whole units are BIT-identical; units of the last round that are cut along K
-    (fp32 partial slabs summed in order) differ by fp32 rounding of the partial sums only -- the fp64 bar of the test above.
-    cus: plan for a chip of that many CUs (GDN_RING_CUS) so small shapes reach several rounds, odd panel counts (128 x 256
-    units, a duplicated last B panel) and the K-split tail; rows past M and the padding rows of the last panel are never stored."""
-    from gdn_amd import ops
-    if cus:
-        monkeypatch.setenv("GDN_RING_CUS", str(cus))
-    g = torch.Generator().manual_seed(bins * 77 + M)
-    A = torch.randn(bins, M, K, generator=g)
-    B = torch.randn(bins, N, K, generator=g) * torch.logspace(-1, 1, N).view(1, N, 1)
-    Ap, Bp = ops.gemm_x3_pack(A.to(gpu)), ops.gemm_x3_pack(B.to(gpu))
-    C0 = ops.gemm_x3_nt(A.to(gpu), Bp, N)
-    guard = torch.full((bins * M * N + 4096,), 12345.0, device=gpu)
-    C1 = guard[:bins * M * N].view(bins, M, N)
-    ops.gemm_x3_nt_packed(Ap, Bp, bins, M, N, K, out=C1)
-    torch.cuda.synchronize()
-    assert bool((guard[bins * M * N:] == 12345.0).all()), "stored past the result"
-    ref = torch.bmm(A.double(), B.double().transpose(1, 2))
-    scale = torch.bmm(A.double().abs(), B.double().abs().transpose(1, 2))
-    err = float(((C1.cpu().double() - ref).abs() / scale).max())
-    same = float((C0 == C1).float().mean())
-    print("ring %dx%dx%dx%d cus %d: identical to nt on %.1f %% of the outputs, max err / sum|a||b| = %.3e" % (bins, M, N, K, cus, 100 * same, err))
-    assert err < 4e-6
-    monkeypatch.setenv("GDN_X3_RING_TAIL", "0")                    # no K split: every unit whole -> bit-identical
-    C2 = torch.empty_like(C0)
-    ops.gemm_x3_nt_packed(Ap, Bp, bins, M, N, K, out=C2)
-    assert torch.equal(C0, C2)
-
-
-def test_gemm_x3_ring_exact_on_integers(gpu, monkeypatch):
-    """Integer operands through the ring kernel with a K-split tail: partial sums are exact, so the result is the integer product."""
-    from gdn_amd import ops
-    monkeypatch.setenv("GDN_RING_CUS", "16")
-    g = torch.Generator().manual_seed(5)
-    bins, M, N, K = 3, 520, 256, 128
-    A = torch.randint(-8, 9, (bins, M, K), generator=g).float()
-    B = torch.randint(-8, 9, (bins, N, K), generator=g).float()
-    C = ops.gemm_x3_nt_packed(ops.gemm_x3_pack(A.to(gpu)), ops.gemm_x3_pack(B.to(gpu)), bins, M, N, K).cpu()
-    assert torch.equal(C, torch.bmm(A, B.transpose(1, 2)))

@@ -738,6 +738,41 @@ def test_adam_keeps_one_state_when_coverage_changes(gpu):
     assert st["pstep"] is not None and len(set(st["pstep"].values())) == 2      # res512_3 is one step behind, for good
 
 
+@pytest.mark.parametrize("first_partial", [True, False])
+def test_capturable_adam_partial_coverage(gpu, first_partial):
+    """the capturable (device step counter) Adam with partial gradient coverage.  first_partial: the very FIRST step
+    has gradients for a subset only and a later step brings in the rest -- those parameters must start from step 1, not from a
+    copy of a never-driven arena counter (bias correction 1 - beta^0 = 0: inf / NaN).  Otherwise: full, partial, full.  Against
+    torch.optim.Adam fed the same gradients."""
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import utils as U
+    from gdn_amd.optim import Adam
+    H, W = 32, 64
+    depth, rgb, sparse = [t.to(gpu) for t in O.synthetic_batch(1, H, W, seed=6)]
+    torch.manual_seed(5)
+    model = M.AutoEncoder_DtoD(input_dim=1, height=H, width=W).to(gpu).train()
+    opt = Adam(model.parameters(), 1e-3, [0.9, 0.999], eps=1e-08, weight_decay=5e-4, capturable=True)
+    model(depth, istrain=False)                                  # builds the arena
+    ref = {k: v.detach().clone().contiguous().requires_grad_(True) for k, v in model.named_parameters()}
+    ropt = torch.optim.Adam(list(ref.values()), 1e-3, [0.9, 0.999], eps=1e-08, weight_decay=5e-4)
+    frozen_at = (0,) if first_partial else (1,)
+    for step in range(3):
+        model.res512_3.requires_grad_(step not in frozen_at)
+        out = model(depth, istrain=False)
+        loss, _, _ = U.dtod_loss(out, depth, sparse)
+        opt.zero_grad()
+        loss.backward()
+        for k, p in model.named_parameters():
+            ref[k].grad = None if p.grad is None else p.grad.detach().clone().contiguous()
+        opt.step()
+        ropt.step()
+        for k, p in model.named_parameters():
+            assert bool(torch.isfinite(p.detach()).all()), "%s step %d: not finite" % (k, step)
+            torch.testing.assert_close(p.detach(), ref[k].detach(), rtol=2e-5, atol=2e-7, msg=lambda m, k=k, s=step: "%s step %d: %s" % (k, s, m))
+            with torch.no_grad():
+                ref[k].copy_(p.detach())
+
+
 def test_guide_batched_pass_is_bitwise_the_two_forwards(gpu):
     """RtoD latent loss with the frozen eval-mode guide: one pass over cat(depths, outputs) gives the features of the
     reference's two separate forwards (faithful mode: full network; default: encoder only) -- bitwise at this size, where the

@@ -17,11 +17,13 @@ each rank trains its own batch-20 shard and the gradient arena is all-reduced
 with RCCL (weak scaling).  Rank 0 prints ONE JSON line.
 
 The same line carries
-  roofline     -- the dominant kernel of the step, `gemm_x3_nt_kernel`: the 36 per-bin GEMMs of the level-3 Winograd
-                  F(4x4,3x3) 512->512 layer (north_star's fused 3x3 convolution) as bf16 x 3 split
-                  products, timed with HIP events on the launch stream: algorithmic fp32 FLOP / time against the
-                  bf16 MFMA peak / 6 (six bf16 products per fp32 product; 2500 / 6 = 416.7 TFLOP/s), the executed bf16
-                  rate and the replaced fp32 MFMA kernel beside it; `traffic` from the committed PMC pass;
+  step_kernel_breakdown -- device time per kernel symbol over two steps after the timed region (torch.profiler): decides which
+                  kernel `roofline` describes;
+  roofline     -- the dominant kernel of the step by that measurement: the per-bin complex GEMMs of the frequency-domain layers
+                  (`cgemm_bins_kernel`, fp32 MFMA, on the MFMA / HBM ridge; the other family is under `roofline_gemm_x3`) or
+                  `gemm_x3_nt_kernel`, the 36 per-bin GEMMs of the level-3 Winograd F(4x4,3x3) 512->512 layer as bf16 x 3 split
+                  products (algorithmic fp32 FLOP / time against the bf16 MFMA peak / 6); timed with HIP events on the launch
+                  stream; `traffic` from the committed PMC pass;
   roofline_direct3x3, roofline_fftconv -- the direct fused 3x3 kernel (fp32 MFMA peak 157.3 TFLOP/s) and a 9x9
                   frequency-domain layer (HBM-bound, 8 TB/s) measured the same way;
   mfma_util    -- whole-step MFMA utilisation replayed from profiles/ (with the commit it was collected at);
@@ -156,6 +158,133 @@ def fftconv_roofline(dev, B, reps=10):
                         "spectrum bytes and GEMM rows): fewer bytes in less time -- the byte rate falls, the layer gets faster",
                 "fwd_ms": round(tf, 4), "fwd_bytes": tby_f, "fwd_achieved": round(tby_f / tf / 1e6, 1),
                 "bwd_ms": round(tb, 4), "bwd_bytes": tby_b, "bwd_achieved": round(tby_b / tb / 1e6, 1)}}
+
+
+def cgemm_roofline(dev, B, reps=20):
+    """The per-bin complex GEMMs of the frequency-domain layers (cgemm_bins_kernel<false|true>, cgemm_tn_bins_kernel: the largest
+    symbol family of the headline step) on the 9x9 64->64 layer's TRAINING plan at level 0: 40-point tiles, 840 bins x
+    [1040 x 64] x [64 x 64] complex = three real fp32-MFMA products each (Gauss).  Timed alone, and the backward's pair
+    (data gradient + weight-gradient reduction) on two streams as the step runs them.  The GEMM sits on the ridge of the fp32
+    matrix pipe and HBM (23 FLOP/B): both fractions are reported."""
+    from gdn_amd import ops
+    H, W, C, k = 128, 416, 64, 9
+    op = ops.Conv(C, C, k, 1, k // 2)
+    ws, bins, M, npnt = op.fft_cgemm_only(B, H, W, 0, train=True)
+    s2 = torch.cuda.Stream()
+
+    def timed(fn, sync_side=False):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        if sync_side:
+            torch.cuda.current_stream().wait_stream(s2)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def pair():
+        s2.wait_stream(torch.cuda.current_stream())
+        op.fft_cgemm_only(B, H, W, 1, ws=ws, train=True)
+        op.fft_cgemm_only(B, H, W, 2, ws=ws, train=True, st=s2.cuda_stream)
+        torch.cuda.current_stream().wait_stream(s2)
+
+    ms = [1e9, 1e9, 1e9]
+    ms_pair = 1e9
+    for _ in range(3):                                     # interleaved rounds, best of three (cdna_hip_programming.md rule 24)
+        for which in range(3):
+            ms[which] = min(ms[which], timed(lambda w=which: op.fft_cgemm_only(B, H, W, w, ws=ws, train=True)))
+        ms_pair = min(ms_pair, timed(pair, sync_side=True))
+    flop = 3 * 2.0 * bins * M * C * C                      # three real products per complex product
+    by = 2 * M * bins * C * 8 + bins * 3 * C * C * 4       # one spectrum in, one out, the weight planes
+    by_tn = 2 * M * bins * C * 8 + bins * 2 * C * C * 4
+    a = flop / (ms[0] * 1e-3) / 1e12
+
+    def one(t, b):
+        return {"ms_per_launch": round(t, 4), "achieved": round(flop / (t * 1e-3) / 1e12, 2),
+                "frac": round(flop / (t * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "hbm_gbps": round(b / t / 1e6, 1),
+                "hbm_frac": round(b / t / 1e6 / 8000.0, 4)}
+    return {"kernel": "cgemm_bins_kernel<false>: the %d per-bin complex GEMMs [%d x 64] x [64 x 64] of the 9x9 s1 64->64 layer's training plan "
+                      "(%d-point tiles), B=%d 128x416 (level 0), 3 real fp32 products per complex product on v_mfma_f32_32x32x2_f32"
+                      % (bins, M, npnt, B),
+            "bound": "mfma", "unit": "TFLOP/s", "achieved": round(a, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+            "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4), "gflop_per_launch": round(flop / 1e9, 2), "ms_per_launch": round(ms[0], 4),
+            "bytes_per_launch": by, "hbm_gbps": round(by / ms[0] / 1e6, 1), "hbm_frac": round(by / ms[0] / 1e6 / 8000.0, 4),
+            "traffic": None,
+            "note": "arithmetic intensity %.1f FLOP/B: on the ridge between the fp32 matrix pipe (157.3 TFLOP/s) and HBM (8 TB/s); frac is "
+                    "against the pipe, hbm_frac against the memory" % (flop / by),
+            "dgrad_cgemm_bins_true": one(ms[1], by), "wgrad_cgemm_tn_bins": one(ms[2], by_tn),
+            "backward_pair_two_streams": {"ms": round(ms_pair, 4), "sum_alone_ms": round(ms[1] + ms[2], 4),
+                                          "achieved": round(2 * flop / (ms_pair * 1e-3) / 1e12, 2),
+                                          "frac": round(2 * flop / (ms_pair * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}}
+
+
+def wgrad_ring_roofline(dev, B, reps=20):
+    """wgrad_ring_bf16<9> (round 5, csrc/wgrad_ring.h): the 9x9 64->64 weight gradient at level 0 on the bf16 matrix pipe, with the
+    fixed-order slab reduce, against the round-1 kernel."""
+    from gdn_amd import ops
+    H, W, C, k = 128, 416, 64, 9
+    op = ops.Conv(C, C, k, 1, k // 2)
+    x = torch.randn(B, H, W, C, device=dev).bfloat16()
+    gy = torch.randn(B, H, W, C, device=dev).bfloat16()
+    dw = torch.empty(k * k, C, C, device=dev)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ms_new = ms_old = 1e9
+    for _ in range(3):
+        ms_old = min(ms_old, timed(lambda: op.wgrad(x, gy, dw, cfg=2)))
+        ms_new = min(ms_new, timed(lambda: op.wgrad(x, gy, dw, cfg=4)))
+    flop = 2.0 * B * H * W * k * k * C * C
+    a = flop / (ms_new * 1e-3) / 1e12
+    return {"kernel": "wgrad_ring_bf16<9, true> + wgrad_bf16_reduce: 9x9 s1 64->64 weight gradient, B=%d 128x416 (level 0), bf16 in / fp32 "
+                      "accumulate, fp32 dW (DESIGN.md 2.12)" % B,
+            "bound": "mfma", "unit": "TFLOP/s", "achieved": round(a, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+            "frac": round(a / PEAK_BF16_MFMA_TFLOPS, 4), "gflop_per_launch": round(flop / 1e9, 1), "ms_per_launch": round(ms_new, 4),
+            "traffic": pmc_traffic("r05_wgrad_ring_pmc.json"),
+            "round1_kernel": {"kernel": "conv_wgrad_bf16<9, 8, 7> (cfg 2)", "ms_per_launch": round(ms_old, 4),
+                              "achieved": round(flop / (ms_old * 1e-3) / 1e12, 1)}}
+
+
+def step_kernel_breakdown(step, nsteps=2, top=8):
+    """Device time per kernel SYMBOL (template arguments and namespaces stripped) over `nsteps` steps run after the timed region,
+    from torch.profiler (roctracer): which kernel the step spends most of its time in is measured, not asserted."""
+    import re
+    from torch.profiler import ProfilerActivity, profile
+    try:
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(nsteps):
+                step()
+            torch.cuda.synchronize()
+        agg, total = {}, 0.0
+        for e in prof.key_averages():
+            t = float(getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0))
+            if t <= 0.0:
+                continue
+            name = e.key.replace("(anonymous namespace)::", "").replace("void ", "")
+            name = re.sub(r"[<(].*", "", name).split("::")[-1].strip()
+            a = agg.setdefault(name, [0.0, 0])
+            a[0] += t
+            a[1] += int(e.count)
+            total += t
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]
+        return {"steps": nsteps, "kernel_ms_per_step": round(total / nsteps / 1e3, 3),
+                "top": [{"symbol": k, "ms_per_step": round(v[0] / nsteps / 1e3, 3), "share": round(v[0] / total, 4),
+                         "launches_per_step": round(v[1] / nsteps, 1)} for k, v in rows]}
+    except Exception as e:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def ring_roofline(dev, B, reps=20):
@@ -445,6 +574,10 @@ def other_configs(dev, B, depth, rgb, sparse):
         out["roofline_rtod_bf16"] = ring_roofline(dev, B)
     except Exception as e:  # noqa: BLE001
         out["roofline_rtod_bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:
+        out["roofline_wgrad_ring_bf16"] = wgrad_ring_roofline(dev, B)
+    except Exception as e:  # noqa: BLE001
+        out["roofline_wgrad_ring_bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}
     for key, dt in (("infer_b64_graph", "fp32"), ("infer_b64_graph_bf16", "bf16")):
         try:
             ms, chk = infer_measure(dev, 64, dt, 3, 1, graph=True)
@@ -699,7 +832,7 @@ def main():
             ms_g, fl_g, ms_l, fl_l, ms_x, fl_x = wino_roofline(dev, B)
             ax = fl_x / (ms_x * 1e-3) / 1e12                   # algorithmic (fp32) TFLOP/s
             ag = fl_g / (ms_g * 1e-3) / 1e12
-            rec["roofline"] = {
+            x3_rec = {
                 "kernel": "gemm_x3_nt_kernel: the 36 per-bin fp32 GEMMs [%d x 512] x [512 x 512] of the Winograd F(4x4,3x3) 3x3 s1 "
                           "512->512 layer, B=%d 16x52 (level 3), as bf16 x 3 split products (6 bf16 MFMA products per fp32 "
                           "product, fp32 accumulate)" % (B * 4 * 13, B),
@@ -724,6 +857,23 @@ def main():
                                   "note": "whole layer forward (transforms + GEMMs + BN-stats epilogue) counted in the direct "
                                           "convolution's FLOPs (SURVEY 8d unit, 78.5 GFLOP): 2.25x fewer multiplies are executed"},
             }
+            cg_rec = cgemm_roofline(dev, B)
+            # which of the two is THE roofline record is decided by the measured step: the symbol family with the largest share of
+            # the step's kernel time (torch.profiler over two steps after the timed region); the other one keeps its own key
+            brk = step_kernel_breakdown(step)
+            rec["step_kernel_breakdown"] = brk
+            share = {"cgemm": 0.0, "gemm_x3": 0.0}
+            for r_ in brk.get("top", []):
+                for fam in share:
+                    if r_["symbol"].startswith(fam):
+                        share[fam] += r_["share"]
+            dominant = "cgemm" if share["cgemm"] >= share["gemm_x3"] else "gemm_x3"
+            for fam, rr in (("cgemm", cg_rec), ("gemm_x3", x3_rec)):
+                rr["share_of_step_kernel_time"] = round(share[fam], 4)
+            rec["roofline"] = cg_rec if dominant == "cgemm" else x3_rec
+            rec["roofline"]["chosen_by"] = "largest symbol family of step_kernel_breakdown (cgemm* %.3f vs gemm_x3* %.3f of the kernel time)" % (
+                share["cgemm"], share["gemm_x3"])
+            rec["roofline_gemm_x3" if dominant == "cgemm" else "roofline_cgemm"] = x3_rec if dominant == "cgemm" else cg_rec
             rec["roofline_direct3x3"] = direct
             # second-largest share of the step: the frequency-domain layers, HBM-bound
             rec["roofline_fftconv"] = fftconv_roofline(dev, B)

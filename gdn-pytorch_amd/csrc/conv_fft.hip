@@ -39,6 +39,9 @@ static_assert(FFT_BINS_OF(32) % 8 == 0 && FFT_BINS_OF(16) % 8 == 0 && FFT_BINS_O
 // not fold it back into multiplies.
 #define GDN_KEEP(v) asm volatile("" : "+v"(v))
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+
 namespace {
 
 // cos/sin(2*pi*j/32), j = 0..31
@@ -259,36 +262,62 @@ __global__ __launch_bounds__(256) void fft_weights_kernel(const float* __restric
 // the product stage, still below a direct fp32 convolution (tests/test_fftconv_model_cpu.py).
 // Workgroups are dealt XCD-aware: XCD j owns the bins = j (mod 8) and walks them bin-major with the N-tiles of one M-tile
 // back to back, so a bin's weight planes stay in that XCD's L2 and an A tile is fetched from the fabric once.
+// Round 5: PERSISTENT workgroups, all addressing on the scalar unit.  A one-shot workgroup loads, computes and stores in turn,
+// and the four workgroups of a CU do so in phase (PMC: traffic = algorithmic, matrix pipe 57 % busy on the 64-channel layers,
+// whose MFMA time and HBM time are equal -- the two were adding up); and an fp32 MFMA does not hide vector-ALU work the way a
+// bf16 one does (time per MFMA ~ 64 + 4 x VALU instructions per MFMA): with four k-steps per unit, the unit's
+// index arithmetic, 64-bit address math and predicated epilogue came to 3.7 vector instructions per MFMA.  Now
+//   * 4 x CUs workgroups walk the (bin, M-tile, N-tile) units u, u + G, ... (mixed-radix increments, no division): the first
+//     slab of the NEXT unit is requested before the last k-step of the current one and written to LDS behind its last barrier,
+//     and the current unit's stores drain under the next unit's MFMAs;
+//   * every global access is a raw buffer access through a per-unit descriptor (the bin's slice of A / C from the unit's first
+//     row on, the bin's planes of W; 12 MB at most, so spectra beyond 4 GiB work): the per-lane offset is a constant of the
+//     thread, what changes inside a unit (k-slab, N-tile) rides in the scalar offset, and rows >= M fall outside the descriptor
+//     (the hardware checks the per-lane offset) -- they load as zero and their stores are dropped, no predicate.
 template <bool DGRAD>
 __global__ __launch_bounds__(256, 4) void cgemm_bins_kernel(const float* __restrict__ A, const float* __restrict__ Wf,
                                                          float* __restrict__ Cm, int M, int Nc /* complex outputs */,
-                                                         int Kc /* complex reduction */) {
+                                                         int Kc /* complex reduction */, int nunits) {
     constexpr int LDA = 36;                                 // plane images: pitch 20 ([n][c]) or 64 ([n][c] rows, DGRAD)
     __shared__ __attribute__((aligned(16))) float As[64 * LDA], Bs[3 * (DGRAD ? 16 * 64 : 64 * 20)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int NT = Nc / 64, MT = (M + 63) / 64;
-    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int bin = (sq / (NT * MT)) * 8 + xcd, m0 = ((sq / NT) % MT) * 64, n0 = (sq % NT) * 64;
-    const float* Ab = A + (size_t)bin * M * Kc * 2;
     // planes: forward [p][n = output][c = reduction] (row length Kc); data gradient [p][n = reduction][c = output] (row length Nc)
-    const size_t plane = (size_t)Nc * Kc;
-    const float* Wb = Wf + (size_t)bin * 3 * plane;
-    f32x16 acc1, acc2, acc3;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+    const unsigned plane_b = (unsigned)Nc * Kc * 4;         // bytes of one plane of one bin
     const int ar = tid >> 3, ac = (tid & 7) * 4;          // A: 32 rows per pass, 8 lanes x 16 B = 16 complex per row
+    const int h = lane >> 5, r32 = lane & 31;
+    const int a_off = (wm * 32 + r32) * LDA + h * 16;
+    const int b_off = DGRAD ? (h * 8) * 64 + wn * 32 + r32 : (wn * 32 + r32) * 20 + h * 8;
+    // per-lane byte offsets (constants of the thread)
+    const unsigned voA = (unsigned)(ar * Kc * 2 + ac) * 4u;                                  // + 32 rows for the second pass
+    const unsigned voW = DGRAD ? (unsigned)((tid >> 4) * Nc + (tid & 15) * 4) * 4u : (unsigned)((tid >> 2) * Kc + (tid & 3) * 4) * 4u;
+    const unsigned voC = (unsigned)((wm * 32 + 4 * h) * Nc + wn * 32 + r32) * 8u;
+    const unsigned a_pass = (unsigned)(32 * Kc * 2) * 4u;
+    const unsigned c_row = (unsigned)Nc * 8u;
     f32x4 ra[2], rb[3];
-    auto gload = [&](int k0) {                            // k0: first complex reduction index of the slab
+    // unit u = ((bin / 8 * MT + mt) * NT + nt) * 8 + (bin % 8): XCD j owns the bins = j (mod 8) and walks them bin-major with the
+    // N-tiles of one M-tile back to back.  The stride G is a multiple of 8: its digits in (nt, mt, bin / 8) advance a unit.
+    const int G8 = (int)gridDim.x >> 3;
+    const int d_nt = G8 % NT, d_mt = (G8 / NT) % MT, d_b8 = G8 / (NT * MT);
+    int u = blockIdx.x;
+    if (u >= nunits) return;
+    const int xcd = u & 7;
+    int nt, mt, b8;
+    { const int sq = u >> 3; nt = sq % NT; mt = (sq / NT) % MT; b8 = sq / (NT * MT); }
+    __amdgpu_buffer_rsrc_t rsA, rsW, rsC, rsA_n, rsW_n;
+    auto make_rs = [&](int bin, int m0, __amdgpu_buffer_rsrc_t& a_, __amdgpu_buffer_rsrc_t& w_) {
+        a_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A) + ((size_t)bin * M + m0) * Kc * 2, 0, (int)((unsigned)(M - m0) * Kc * 8u), 0x00020000);
+        w_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wf) + (size_t)bin * 3 * Nc * Kc, 0, (int)(3 * plane_b), 0x00020000);
+    };
+    auto gload = [&](const __amdgpu_buffer_rsrc_t& a_, const __amdgpu_buffer_rsrc_t& w_, int n0, int k0) {
+        const unsigned soA = (unsigned)k0 * 8u;
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int m = m0 + ps * 32 + ar;
-            ra[ps] = m < M ? *reinterpret_cast<const f32x4*>(Ab + ((size_t)m * Kc + k0) * 2 + ac) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int ps = 0; ps < 2; ++ps)
+            ra[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_, voA + ps * a_pass, soA, 0));
+        const unsigned soW = DGRAD ? (unsigned)(k0 * Nc + n0) * 4u : (unsigned)(n0 * Kc + k0) * 4u;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            if (DGRAD) rb[p] = *reinterpret_cast<const f32x4*>(Wb + p * plane + (size_t)(k0 + (tid >> 4)) * Nc + n0 + (tid & 15) * 4);
-            else rb[p] = *reinterpret_cast<const f32x4*>(Wb + p * plane + (size_t)(n0 + (tid >> 2)) * Kc + k0 + (tid & 3) * 4);
-        }
+        for (int p = 0; p < 3; ++p)
+            rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_, voW, soW + p * plane_b, 0));
     };
     auto lstore = [&]() {
 #pragma unroll
@@ -299,54 +328,68 @@ __global__ __launch_bounds__(256, 4) void cgemm_bins_kernel(const float* __restr
             else *reinterpret_cast<f32x4*>(&Bs[p * 64 * 20 + (tid >> 2) * 20 + (tid & 3) * 4]) = rb[p];
         }
     };
-    const int h = lane >> 5, r32 = lane & 31;
-    const int a_off = (wm * 32 + r32) * LDA + h * 16;
-    const int b_off = DGRAD ? (h * 8) * 64 + wn * 32 + r32 : (wn * 32 + r32) * 20 + h * 8;
-    gload(0);
+    make_rs(b8 * 8 + xcd, mt * 64, rsA, rsW);
+    gload(rsA, rsW, nt * 64, 0);
     lstore();
     __syncthreads();
-    for (int k0 = 0; k0 < Kc; k0 += 16) {
-        if (k0 + 16 < Kc) gload(k0 + 16);
-        f32x4 b4[3][2];
-        if (!DGRAD) {
+    for (;;) {
+        const int bin = b8 * 8 + xcd, m0 = mt * 64, n0 = nt * 64;
+        const int un = u + (int)gridDim.x;
+        const bool has_next = un < nunits;
+        int nt_n = nt + d_nt, mt_n = mt + d_mt, b8_n = b8 + d_b8;
+        if (nt_n >= NT) { nt_n -= NT; ++mt_n; }
+        if (mt_n >= MT) { mt_n -= MT; ++b8_n; }
+        if (has_next) make_rs(b8_n * 8 + xcd, mt_n * 64, rsA_n, rsW_n);
+        rsC = __builtin_amdgcn_make_buffer_rsrc(Cm + ((size_t)bin * M + m0) * Nc * 2, 0, (int)((unsigned)(M - m0) * Nc * 8u), 0x00020000);
+        f32x16 acc1, acc2, acc3;
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+        for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+        for (int k0 = 0; k0 < Kc; k0 += 16) {
+            const bool last = k0 + 16 >= Kc;
+            if (!last) gload(rsA, rsW, n0, k0 + 16);
+            else if (has_next) gload(rsA_n, rsW_n, nt_n * 64, 0);
+            f32x4 b4[3][2];
+            if (!DGRAD) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) b4[p][q] = *reinterpret_cast<const f32x4*>(&Bs[p * 64 * 20 + b_off + q * 4]);
-        }
+                for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&As[a_off + g * 4]);
+                    for (int q = 0; q < 2; ++q) b4[p][q] = *reinterpret_cast<const f32x4*>(&Bs[p * 64 * 20 + b_off + q * 4]);
+            }
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float xr = a4[2 * e], xi = a4[2 * e + 1];
-                float b1, b2, b3;
-                if (DGRAD) {
-                    const int row = (2 * g + e) * 64;
-                    b1 = Bs[b_off + row]; b2 = Bs[16 * 64 + b_off + row]; b3 = Bs[2 * 16 * 64 + b_off + row];
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xr + xi, b1, acc1, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, b2, acc2, 0, 0, 0);
-                    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(xr, b3, acc3, 0, 0, 0);
-                } else {
-                    const int q = g >> 1, idx = 2 * (g & 1) + e;
-                    b1 = b4[0][q][idx]; b2 = b4[1][q][idx]; b3 = b4[2][q][idx];
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xr + xi, b1, acc1, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xr, b2, acc2, 0, 0, 0);
-                    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, b3, acc3, 0, 0, 0);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&As[a_off + g * 4]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float xr = a4[2 * e], xi = a4[2 * e + 1];
+                    float b1, b2, b3;
+                    if (DGRAD) {
+                        const int row = (2 * g + e) * 64;
+                        b1 = Bs[b_off + row]; b2 = Bs[16 * 64 + b_off + row]; b3 = Bs[2 * 16 * 64 + b_off + row];
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xr + xi, b1, acc1, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, b2, acc2, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(xr, b3, acc3, 0, 0, 0);
+                    } else {
+                        const int q = g >> 1, idx = 2 * (g & 1) + e;
+                        b1 = b4[0][q][idx]; b2 = b4[1][q][idx]; b3 = b4[2][q][idx];
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xr + xi, b1, acc1, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xr, b2, acc2, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, b3, acc3, 0, 0, 0);
+                    }
                 }
             }
+            __syncthreads();
+            if (!last || has_next) { lstore(); __syncthreads(); }
         }
-        __syncthreads();
-        if (k0 + 16 < Kc) { lstore(); __syncthreads(); }
-    }
-    float2* Cb = reinterpret_cast<float2*>(Cm) + (size_t)bin * M * Nc;
-    const int col = n0 + wn * 32 + r32;
+        // accumulator register r = row (r & 3) + 8 (r >> 2) (+ 4h, in voC) of the wave's 32-row tile (in the per-lane offset: the
+        // range check must see the row)
+        const unsigned soC = (unsigned)n0 * 8u;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < M)
-            Cb[(size_t)m * Nc + col] = DGRAD ? make_float2(acc1[r] + acc2[r], acc1[r] - acc3[r])
-                                             : make_float2(acc1[r] - acc3[r], acc1[r] + acc2[r]);
+        for (int r = 0; r < 16; ++r) {
+            f32x2 v = DGRAD ? f32x2{acc1[r] + acc2[r], acc1[r] - acc3[r]} : f32x2{acc1[r] - acc3[r], acc1[r] + acc2[r]};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, v), rsC, voC + (unsigned)((r & 3) + 8 * (r >> 2)) * c_row, soC, 0);
+        }
+        if (!has_next) break;
+        u = un; nt = nt_n; mt = mt_n; b8 = b8_n; rsA = rsA_n; rsW = rsW_n;
     }
 }
 
@@ -950,6 +993,8 @@ bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
 }
 
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+// persistent grid of cgemm_bins_kernel: four workgroups per CU (a multiple of 8: a workgroup stays on one XCD's bins)
+inline int cgemm_grid(int nunits) { const int g = 4 * gdn_num_cus(); return nunits < g ? (nunits + 7) / 8 * 8 : g; }
 
 // splits of the weight-gradient reduction: enough workgroups for ~4 per CU, chunks of at least 64 tiles
 inline int tn_splits(const FftGeom& f) {
@@ -1049,8 +1094,11 @@ extern "C" int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t l
     }
     launch_fft2d_fwd(f, f.C, x, ldx, Xf, 1, in_scale, in_shift, in_relu, nullptr, 0, nullptr, nullptr, in_up2x, st);
     launch_weights(f, w, Wf, st);
-    hipLaunchKernelGGL(cgemm_bins_kernel<false>, dim3(cdiv(f.M, 64) * (f.N / 64) * f.bins), dim3(256), 0, st,
-                       (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, f.N, f.C);
+    {
+        const int nu = cdiv(f.M, 64) * (f.N / 64) * f.bins;
+        hipLaunchKernelGGL(cgemm_bins_kernel<false>, dim3(cgemm_grid(nu)), dim3(256), 0, st,
+                           (const float*)Xf, (const float*)Wf, (float*)Yf, f.M, f.N, f.C, nu);
+    }
     const dim3 gv(f.N / FFT_CG_OF(f.np) * 8 * cdiv(f.M, 8)), bv(f.np * FFT_CG_OF(f.np));
     if (f.np == 16)
         hipLaunchKernelGGL(ifft2d_valid_kernel<16>, gv, bv, 0, st, (const float2*)Yf, y, ldy, addsrc, ld_add, stats,
@@ -1133,8 +1181,9 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     if (dx && (phases & GDN_FFT_BWD_DX)) {
         const float* Wsaved = xf ? (const float*)((const char*)xf + al256((size_t)f.M * f.bins * f.C * 8)) : nullptr;
         if (!Wsaved) launch_weights(f, w, Wf, st);
-        hipLaunchKernelGGL(cgemm_bins_kernel<true>, dim3(cdiv(f.M, 64) * (f.C / 64) * f.bins), dim3(256), 0, st,
-                           (const float*)Df, Wsaved ? Wsaved : (const float*)Wf, (float*)Ef, f.M, f.C, f.N);
+        const int nu = cdiv(f.M, 64) * (f.C / 64) * f.bins;
+        hipLaunchKernelGGL(cgemm_bins_kernel<true>, dim3(cgemm_grid(nu)), dim3(256), 0, st,
+                           (const float*)Df, Wsaved ? Wsaved : (const float*)Wf, (float*)Ef, f.M, f.C, f.N, nu);
         // inverse along ky into S, then rows: the tile rows that reach an image row are summed in the frequency domain
         int cq_shift = 0;
         while ((64 << cq_shift) < f.C) ++cq_shift;           // C / 64 is 1, 2 or 4
@@ -1176,3 +1225,50 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     return gdn_launch_status();
 }
 
+// Measurement hook (bench.py roofline_cgemm): ONLY the per-bin complex GEMMs of a frequency-domain layer, on
+// whatever the workspace holds -- which: 0 the forward's cgemm_bins<false> (Y = X W), 1 the data gradient's cgemm_bins<true>
+// (E = D conj-transposed W), 2 the weight gradient's reduction cgemm_tn_bins (P = sum over tiles D^H X).  Three real products per
+// complex product (Gauss).  workspace: gdn_fftconv_cgemm_workspace_bytes(); 1 and 2 read the same D, so a caller may run them
+// on two streams of its own as the backward does.
+extern "C" size_t gdn_fftconv_cgemm_workspace_bytes(const gdn_conv_geom* g) {
+    FftGeom f;
+    if (!fft_geom(g, f)) return 0;
+    const size_t cm = f.C > f.N ? f.C : f.N;
+    return 3 * al256((size_t)f.M * f.bins * cm * 8) + wf_region_bytes(f) + al256((size_t)f.bins * 3 * f.C * f.N * 4);
+}
+extern "C" int gdn_fftconv_cgemm(const gdn_conv_geom* g, int32_t which, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    FftGeom f;
+    if (!fft_geom(g, f) || which < 0 || which > 2) return GDN_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < gdn_fftconv_cgemm_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t cm = f.C > f.N ? f.C : f.N, sp = al256((size_t)f.M * f.bins * cm * 8);
+    char* p = (char*)workspace;
+    const float* A = (const float*)p;                   // X (0) / D (1, 2)
+    float* O = (float*)(p + (which == 0 ? sp : 2 * sp));    // Y / E: 1 and 2 may run side by side (E and P are different regions)
+    const float* X2 = (const float*)(p + sp);           // (2) the saved input spectrum
+    float* P = (float*)(p + 3 * sp);
+    const float* Wf = (const float*)(p + 3 * sp + wf_region_bytes(f));
+    if (which == 0) {
+        const int nu = cdiv(f.M, 64) * (f.N / 64) * f.bins;
+        hipLaunchKernelGGL(cgemm_bins_kernel<false>, dim3(cgemm_grid(nu)), dim3(256), 0, st, A, Wf, O, f.M, f.N, f.C, nu);
+    } else if (which == 1) {
+        const int nu = cdiv(f.M, 64) * (f.C / 64) * f.bins;
+        hipLaunchKernelGGL(cgemm_bins_kernel<true>, dim3(cgemm_grid(nu)), dim3(256), 0, st, A, Wf, O, f.M, f.C, f.N, nu);
+    }
+    else {
+        const int ns = tn_splits(f);
+        if (ns > FFT_TN_MAX_SPLITS) return GDN_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(cgemm_tn_bins_kernel, dim3((f.N / 64) * (f.C / 64) * f.bins * ns), dim3(256), 0, st, A, X2, P, f.M, f.N, f.C, ns, f.bins);
+    }
+    return gdn_launch_status();
+}
+// host query: {bins, tiles M, Gauss real products}: the GEMM shape behind the hook above
+extern "C" int gdn_fftconv_cgemm_shape(const gdn_conv_geom* g, int32_t* bins, int32_t* M, int32_t* np) {
+    FftGeom f;
+    if (!fft_geom(g, f)) return GDN_ERR_UNSUPPORTED;
+    if (bins) *bins = f.bins;
+    if (M) *M = f.M;
+    if (np) *np = f.np;
+    return GDN_OK;
+}

@@ -49,6 +49,9 @@ _SIGS = {
     "gdn_fftconv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _P, _P, _i32, _i32, _P, _P, _sz, _P]),
     "gdn_fftconv_bwd_workspace_bytes": (_sz, [_PG]),
     "gdn_fftconv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _P, _i32, _P, _i32, _P, _P, _i32, _P, _P, _i32, _i32, _i32, _P, _sz, _P]),
+    "gdn_fftconv_cgemm_workspace_bytes": (_sz, [_PG]),
+    "gdn_fftconv_cgemm": (c_int32, [_PG, _i32, _P, _sz, _P]),
+    "gdn_fftconv_cgemm_shape": (c_int32, [_PG, _P, _P, _P]),
     "gdn_winoconv_fwd_workspace_bytes": (_sz, [_PG]),
     "gdn_winoconv_state_bytes": (_sz, [_PG]),
     "gdn_winoconv_stats_slots": (_i64, [_PG]),

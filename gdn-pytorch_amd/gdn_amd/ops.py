@@ -360,6 +360,20 @@ class Conv:
         return dx
 
     # ---- Winograd F(2x2,3x3) path (csrc/conv_wino.hip): 3x3 stride-1 zero-padded fp32 layers with 64..512 channels ----
+    def fft_cgemm_only(self, B, H, W, which, ws=None, train=False, st=None):
+        """Measurement hook: only the per-bin complex GEMMs of this layer's frequency-domain plan (which: 0 forward, 1 data
+        gradient, 2 weight-gradient reduction) on a scratch workspace; returns (workspace, bins, tiles, points)."""
+        _, ref, _, _ = self.geom(B, H, W, hints=HINT_TRAIN if train else 0)
+        nb = int(lib.gdn_fftconv_cgemm_workspace_bytes(ref))
+        if nb == 0:
+            raise GdnError("fftconv: unsupported layer k=%d stride=%d" % (self.k, self.stride))
+        if ws is None:
+            ws = torch.empty(nb // 4, dtype=torch.float32, device="cuda").normal_()
+        lib.gdn_fftconv_cgemm(ref, int(which), _p(ws), nb, stream() if st is None else st)
+        bins, M, npnt = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        lib.gdn_fftconv_cgemm_shape(ref, ctypes.byref(bins), ctypes.byref(M), ctypes.byref(npnt))
+        return ws, bins.value, M.value, npnt.value
+
     def wino_ok(self, B, H, W):
         _, ref, _, _ = self.geom(B, H, W)
         return int(lib.gdn_winoconv_state_bytes(ref)) > 0

@@ -40,7 +40,7 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
-/* Revision of this header (argument lists, struct layouts).  219: gdn_conv_wgrad_bf16 cfg 4 (wgrad_ring_bf16); gdn_gemm_x3_nt_packed / gdn_gemm_x3_ring_workspace_bytes removed (the measured-and-not-wired kernel now lives under tests/diag/).  218: gdn_gemm_x3_tn_splits.  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+/* Revision of this header (argument lists, struct layouts).  219: gdn_conv_wgrad_bf16 cfg 4 (wgrad_ring_bf16); gdn_fftconv_cgemm* measurement hooks; plan overrides in gdn_conv_geom.hints; gdn_gemm_x3_nt_packed / gdn_gemm_x3_ring_workspace_bytes removed (the measured-and-not-wired kernel now lives under tests/diag/).  218: gdn_gemm_x3_tn_splits.  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
  * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
@@ -220,6 +220,15 @@ int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const 
                     float* dw, const float* dyb_y, int32_t ld_dyb, const float* dyb_co,
                     const float* dyb_kk, int32_t dyb_relu, int32_t dx_up2x, int32_t phases,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* Measurement hooks (bench.py roofline_cgemm): launch ONLY the per-bin complex GEMMs of the frequency-domain layer `g` on
+ * whatever the workspace holds -- which: 0 forward (Y = X W), 1 data gradient, 2 the weight gradient's reduction over the
+ * tiles; 1 and 2 use disjoint outputs and may run on two streams like gdn_fftconv_bwd's chains.  gdn_fftconv_cgemm_shape:
+ * host query of {frequency bins, tiles M, transform points}: per bin the GEMM is [M x Cin] x [Cin x Cout] complex, executed
+ * as three real products (Gauss) on v_mfma_f32_32x32x2_f32.  Replace nothing of the reference: the product path reaches these
+ * kernels through gdn_fftconv_fwd / _bwd (AE_model_unet.py:50,53: the 5x5 ... 9x9 ResidualBlock convolutions). */
+size_t gdn_fftconv_cgemm_workspace_bytes(const gdn_conv_geom* g);
+int gdn_fftconv_cgemm(const gdn_conv_geom* g, int32_t which, void* workspace, size_t workspace_bytes, void* stream);
+int gdn_fftconv_cgemm_shape(const gdn_conv_geom* g, int32_t* bins, int32_t* M, int32_t* np);
 
 /* Winograd F(2x2,3x3) convolution for the 3x3 stride-1 layers (zero or reflection padding 1) on
  * 64..512 channels (the 512-channel ResidualBlocks of levels 3 and 4, AE_model_unet.py:45-57; R's

@@ -439,20 +439,29 @@ __global__ __launch_bounds__(256, 4) void cgemm_tn_bins_kernel(const float* __re
     const int i0 = ((sq / TJ) % TI) * 64, j0 = (sq % TJ) * 64;
     const int mchunk = ((M + nsplit - 1) / nsplit + 15) / 16 * 16;
     const int mb = split * mchunk, me = mb + mchunk < M ? mb + mchunk : M;        // this workgroup reduces tiles [mb, me)
-    const float* Db = D + ((size_t)bin * M * N + i0) * 2;
-    const float* Xb = X + ((size_t)bin * M * C + j0) * 2;
+    // raw buffer loads through descriptors of this workgroup's rows [mb, me) of the two spectra (columns from i0 / j0 on): the
+    // per-lane offset is (row of the pass) x pitch + column, advanced by 16 rows per k-step; rows >= me fall outside the
+    // descriptor and load as zero -- no predicate, no 64-bit address arithmetic (cgemm_bins_kernel above)
+    const int nrow = me > mb ? me - mb : 0;
+    __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(D) + (((size_t)bin * M + mb) * N + i0) * 2, 0,
+                                                                   (int)((unsigned)nrow * N * 8u - (nrow ? (unsigned)i0 * 8u : 0u)), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X) + (((size_t)bin * M + mb) * C + j0) * 2, 0,
+                                                                   (int)((unsigned)nrow * C * 8u - (nrow ? (unsigned)j0 * 8u : 0u)), 0x00020000);
     f32x16 acc1, acc2, acc3;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
     const int lr = tid >> 5, lc = (tid & 31) * 4;         // 8 rows per pass, 32 lanes x 16 B per 512-byte row
+    unsigned voD = (unsigned)(lr * N * 2 + lc) * 4u, voX = (unsigned)(lr * C * 2 + lc) * 4u;
+    const unsigned passD = (unsigned)N * 64u, passX = (unsigned)C * 64u;          // 8 rows
     f32x4 rd[2], rx[2];
     auto gload = [&](int m0) {
+        (void)m0;
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-            const int m = m0 + ps * 8 + lr;
-            rd[ps] = m < me ? *reinterpret_cast<const f32x4*>(Db + (size_t)m * N * 2 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rx[ps] = m < me ? *reinterpret_cast<const f32x4*>(Xb + (size_t)m * C * 2 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rd[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, voD + ps * passD, 0, 0));
+            rx[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voX + ps * passX, 0, 0));
         }
+        voD += 2 * passD; voX += 2 * passX;
     };
     auto lstore = [&]() {
 #pragma unroll

@@ -59,7 +59,7 @@ if res.get("GRBM_GUI_ACTIVE"):
     row["mfma_pipe_busy_pct"] = round(100.0 * res["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * res["GRBM_GUI_ACTIVE"] / 8), 1)
     if dur:
         row["clock_ghz_profiled"] = round(res["GRBM_GUI_ACTIVE"] / 8 / (sum(dur) / len(dur)) / 1e3, 2)
-        row["tflops_profiled"] = round(row["algorithmic_gflop"] / (sum(dur) / len(dur)) * 1e3 / 1e3, 1)
+        row["tflops_profiled"] = round(row["algorithmic_gflop"] / (sum(dur) / len(dur)) * 1e3, 1)
 row["note"] = "traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950: FETCH_SIZE reads half of a wide coalesced stream); L2 -> fabric requests, Infinity-Cache hits included"
 row["command"] = "bash tools/pmc_wgrad.sh " + " ".join(sys.argv[2:7])
 row["collected_at"] = os.environ.get("GDN_COMMIT") or None

@@ -362,9 +362,6 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
                     if (g + 1 < NG) load_frags(cur ^ 1, par, kx, (ubase + kx) & (NSLOT - 1), g + 1);
                     else if (stage + 1 < ns || kx + 1 < KW)
                         load_frags(cur ^ 1, kx + 1 < KW ? par : par ^ 1, kx + 1 < KW ? kx + 1 : 0, (ubase + kx + 1) & (NSLOT - 1), 0);
-                    // (pin the order: left alone the scheduler sinks these reads behind three of the four MFMAs below to save
-                    //  registers, and every group then waits for reads issued one MFMA earlier)
-                    __builtin_amdgcn_sched_barrier(0);
                     // (measured and not kept: the same operands through v_mfma_f32_16x16x32_bf16 -- 1080 vs 1092-1098 TFLOP/s)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
@@ -372,16 +369,27 @@ __global__ __launch_bounds__(512, 2) void conv_ring_bf16(const IgemmParams p) {
                         for (int j = 0; j < 2; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
                     if (g == 0) {
-                        // this step's LDS-DMA issue sits UNDER the first MFMAs (whose operands the read-ahead already delivered):
+                        // this step's LDS-DMA issue sits UNDER the MFMAs (whose operands the read-ahead already delivered):
                         // straight after the barrier the matrix pipe would idle while every wave issues its pieces
-                        __builtin_amdgcn_sched_barrier(0);
                         const int vb = kx + 1 + DP;                // compile-time after unrolling
                         dma_b(ubase + vb, (vb < KW ? soff_c : soff_n) + (vb % KW) * tap2);
 #pragma unroll
                         for (int e = 0; e < NA; ++e)
                             if (e >= S::a_first(kx) && e < S::a_first(kx) + S::a_cnt(kx)) dma_a(par ^ 1, cc_n, e);
-                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    // Round 5 (the schedule wgrad_ring.h arrived at): one MFMA, one fragment read of the NEXT k-substep, a
+                    // couple of vector / scalar instructions and at most one LDS-DMA, four times -- instead of the blocks
+                    // [4 reads][4 MFMAs][DMA] the scheduler was pinned to before, in which every read waited for issue behind the
+                    // block in front of it
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             soff_c = soff_n;

@@ -71,7 +71,7 @@ def timeit(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
-print("%-16s %9s | %-32s | %-32s | %s" % ("layer", "GFLOP", "fwd TF/s per cfg", "dgrad TF/s per cfg", "wgrad TF/s"))
+print("%-16s %9s | %-32s | %-32s | %s" % ("layer", "GFLOP", "fwd TF/s per cfg", "dgrad TF/s per cfg", "wgrad TF/s (bf16: cfg 0 auto, 1, 3, 2 round-1 classes, 4 ring)"))
 for (name, ci, co, k, s, p, refl, tr, H, W) in SHAPES:
     if only and only not in name:
         continue
@@ -103,9 +103,12 @@ for (name, ci, co, k, s, p, refl, tr, H, W) in SHAPES:
     if BF16:
         dw = torch.empty(w.shape, device=dev)
         wg = []
-        for c in (0, 1, 3, 2):      # automatic / small / medium / large staging class
+        for c in (0, 1, 3, 2, 4):   # automatic / small / medium / large staging class of the round-1 kernel / wgrad_ring_bf16 (round 5)
             try:
-                wg.append(gf / timeit(lambda: op.wgrad(x, gy, dw, cfg=c), reps=3))
+                best = 1e9
+                for _ in range(3):                                  # best of three interleaved rounds: the first timing after another kernel reads low
+                    best = min(best, timeit(lambda: op.wgrad(x, gy, dw, cfg=c), reps=5))
+                wg.append(gf / best)
             except Exception:
                 wg.append(0.0)
         print("%-16s %9.1f | %-32s | %-32s | %s" % (name, gf, " ".join("%6.1f" % v for v in fw),

@@ -213,7 +213,7 @@ def cgemm_roofline(dev, B, reps=20):
             "bound": "mfma", "unit": "TFLOP/s", "achieved": round(a, 2), "peak": PEAK_F32_MFMA_TFLOPS,
             "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4), "gflop_per_launch": round(flop / 1e9, 2), "ms_per_launch": round(ms[0], 4),
             "bytes_per_launch": by, "hbm_gbps": round(by / ms[0] / 1e6, 1), "hbm_frac": round(by / ms[0] / 1e6 / 8000.0, 4),
-            "traffic": None,
+            "traffic": pmc_traffic("r05_cgemm_pmc.json"),
             "note": "arithmetic intensity %.1f FLOP/B: on the ridge between the fp32 matrix pipe (157.3 TFLOP/s) and HBM (8 TB/s); frac is "
                     "against the pipe, hbm_frac against the memory" % (flop / by),
             "dgrad_cgemm_bins_true": one(ms[1], by), "wgrad_cgemm_tn_bins": one(ms[2], by_tn),

@@ -23,3 +23,36 @@ print("total kernel time %.2f ms over %d dispatches" % (tot / 1e3, len(rows)))
 print("%-62s %-16s %6s %10s %10s %6s" % ("kernel", "grid(threads)", "calls", "mean_us", "total_ms", "%"))
 for (name, grid), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
     print("%-62s %-16s %6d %10.1f %10.2f %6.1f" % (name, grid, n, t / n, t / 1e3, 100 * t / tot))
+
+# ---- persistent kernels: their grid is the CU count whatever the layer, so (kernel, grid) averages every
+# layer and batch size that runs on one symbol.  A training step launches its kernels in a fixed order: the i-th launch of a
+# symbol between two adam kernels is the same layer call in every step.  Per (symbol, ordinal): mean / min / max over the steps.
+PERSISTENT = re.compile(r"conv_ring_bf16|wgrad_ring_bf16|cgemm_bins_kernel")
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+steps, cur = [], []
+for r in rows:
+    cur.append(r)
+    if "adam" in r["Kernel_Name"]:
+        steps.append(cur)
+        cur = []
+steps = steps[1:]                       # (the first segment holds set-up and warm-up differences)
+if len(steps) >= 3:
+    per = collections.defaultdict(list)
+    counts = collections.Counter()
+    for st in steps:
+        seen = collections.Counter()
+        for r in st:
+            name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+            name = re.sub(r"\(.*", "", name)[:60]
+            if not PERSISTENT.search(name):
+                continue
+            per[(name, seen[name])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            seen[name] += 1
+        for k, v in seen.items():
+            counts[(k, v)] += 1
+    stable = {k for k in {n for n, _ in per} if len({c for (n, c) in counts if n == k}) == 1}
+    print("\npersistent kernels by call ordinal within a step (%d steps; symbols whose launch count differs between steps are skipped)" % len(steps))
+    print("%-62s %4s %10s %10s %10s" % ("kernel", "#", "mean_us", "min_us", "max_us"))
+    for (name, i), v in sorted(per.items(), key=lambda kv: (kv[0][0], kv[0][1])):
+        if name in stable:
+            print("%-62s %4d %10.1f %10.1f %10.1f" % (name, i, sum(v) / len(v), min(v), max(v)))

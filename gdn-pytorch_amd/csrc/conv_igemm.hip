@@ -908,6 +908,7 @@ __global__ __launch_bounds__(256, 3) void conv_rowpatch_bf16(const IgemmParams p
 }
 
 #include "conv_ring.h"
+#include "conv_ring2.h"
 
 // ---------------------------------------------------------------------------
 // Host side: geometry -> phases / tap lists, tile selection, launch.
@@ -1011,9 +1012,10 @@ struct TileCfg { int bm, bn; };
 // cfg ids: 1: 128x128  2: 128x64  3: 64x64  4: 128x32  (5: scalar-gather 128x64)  6: 32x128  7: 64x128
 //          8: row-patch 256x128  9: row-patch 256x64 (bf16, stride-1 layers with k >= 3)
 //          10: LDS-DMA ring 256x64  11: LDS-DMA ring 256x128 (conv_ring.h: bf16, stride-1 layers with k in {3,5,7,9})
-#define NUM_CFG 12
+//          12: LDS-DMA ring 512x64  13: LDS-DMA ring 512x128 (conv_ring2.h: 32-channel slabs)
+#define NUM_CFG 14
 const TileCfg kCfg[NUM_CFG] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 64}, {32, 128}, {64, 128},
-                               {256, 128}, {256, 64}, {256, 64}, {256, 128}};
+                               {256, 128}, {256, 64}, {256, 64}, {256, 128}, {512, 64}, {512, 128}};
 
 // Row-patch kernel eligibility (geometry only, so the slot/workspace queries agree with the launch): one phase,
 // stride 1, >= 3 taps per filter row with consecutive dx, 64-channel slabs, and a 256-pixel tile whose touched
@@ -1040,7 +1042,7 @@ bool rowpatch_ok(const IgemmParams& P) {
 
 // LDS-DMA ring kernel eligibility (geometry only): as the row-patch kernel, with an odd window of 3..9 taps per row (the
 // instantiated schedules), whole BN-channel tiles, and the touched rows' halos within the 64 spare positions of the patch.
-int ring_kw(const IgemmParams& P) {
+int ring_kw(const IgemmParams& P, int bm = RG_BM) {
     if (P.nphase != 1 || P.stride != 1 || (P.Cred % 64)) return 0;
     const IgemmPhase& ph = P.ph[0];
     const int ntap = ph.tap_end - ph.tap_begin;
@@ -1055,24 +1057,25 @@ int ring_kw(const IgemmParams& P) {
             const int i = ph.tap_begin + r * kw + t, i0 = ph.tap_begin + r * kw;
             if (P.tdy[i] != P.tdy[i0] || P.tdx[i] != P.tdx[ph.tap_begin] + dir * t || P.twi[i] != P.twi[i0] + t) return 0;
         }
-    const int nrows_max = (RG_BM - 1 + ph.Wo - 1) / ph.Wo + 1;
-    if (nrows_max > RG_NRMAX || RG_BM + nrows_max * (kw - 1) > RG_APOS) return 0;
+    const int nrows_max = (bm - 1 + ph.Wo - 1) / ph.Wo + 1;
+    if (nrows_max > (bm == RG_BM ? RG_NRMAX : RG2_NRMAX) || bm + nrows_max * (kw - 1) > (bm == RG_BM ? RG_APOS : RG2_APOS)) return 0;
     return kw;
 }
-bool ring_ok(const IgemmParams& P, int bn) { return ring_kw(P) != 0 && P.N % bn == 0 && !P.x2; }
+bool ring_ok(const IgemmParams& P, int bn, int bm = RG_BM) { return ring_kw(P, bm) != 0 && P.N % bn == 0 && !P.x2; }
 
 // How the persistent workgroups of conv_ring_bf16 cover the (M-tile, N-tile) units: G workgroups (one per CU), `main` units in
 // full rounds, and -- when the last round would be a small fraction of one (B = 20: 65/64 of a power of two tiles at every
 // level) -- its `tail` units cut into `parts` stage ranges of `sp` stages, one per workgroup, summed by splitk_combine_kernel.
 struct RingPlan { int G, grid_m, grid_n, main_units, tail_units, parts, sp, slabs, main_mtiles; int64_t tail_px; };
-RingPlan ring_plan(const IgemmParams& P, int bn) {
+RingPlan ring_plan(const IgemmParams& P, int cfg) {
     RingPlan r{};
+    const int bm = kCfg[cfg].bm, bn = kCfg[cfg].bn;
     const IgemmPhase& ph = P.ph[0];
     const int64_t M = (int64_t)P.B * ph.Ho * ph.Wo;
-    r.grid_m = (int)cdiv64(M, RG_BM); r.grid_n = P.N / bn;
+    r.grid_m = (int)cdiv64(M, bm); r.grid_n = P.N / bn;
     const int units = r.grid_m * r.grid_n, units_xcd = cdiv(r.grid_m, 8) * r.grid_n, cus_xcd = P.plan_cus / 8 > 0 ? P.plan_cus / 8 : 32;
     r.G = 8 * (units_xcd < cus_xcd ? units_xcd : cus_xcd);
-    const int kw = ring_kw(P), nstage = kw ? (ph.tap_end - ph.tap_begin) / kw * (P.Cred / 64) : 0;
+    const int kw = ring_kw(P, bm), nstage = kw ? (ph.tap_end - ph.tap_begin) / kw * (P.Cred / (bm == RG_BM ? 64 : 32)) : 0;
     const int rounds = units / r.G, tail = units % r.G;
     r.main_units = units; r.parts = 1; r.sp = nstage; r.slabs = 0; r.main_mtiles = r.grid_m; r.tail_px = 0;
     if (P.ring_notail) return r;                                       // (tile_cfg & 0x800: every unit whole)
@@ -1083,14 +1086,14 @@ RingPlan ring_plan(const IgemmParams& P, int bn) {
         r.parts = cdiv(nstage, r.sp);
         r.main_units = rounds * r.G; r.tail_units = tail;
         r.main_mtiles = r.main_units / r.grid_n;
-        r.tail_px = M - (int64_t)r.main_mtiles * RG_BM;
-        r.slabs = r.parts * (bn == 64 ? 2 : 1);
+        r.tail_px = M - (int64_t)r.main_mtiles * bm;
+        r.slabs = r.parts * (cfg == 10 ? 2 : 1);
     }
     return r;
 }
 size_t ring_ws_bytes(const IgemmParams& P, int cfg) {
     if (cfg < 10) return 0;
-    const RingPlan r = ring_plan(P, cfg == 10 ? 64 : 128);
+    const RingPlan r = ring_plan(P, cfg);
     return r.parts > 1 ? (size_t)r.slabs * r.tail_px * P.N * sizeof(float) : 0;
 }
 
@@ -1101,6 +1104,7 @@ int pick_cfg_bf16(const IgemmParams& P, int64_t M, int N, int forced) {
     if ((forced == 8 || forced == 9) && rp) return forced;
     if (forced == 10 && ring_ok(P, 64)) return 10;
     if (forced == 11 && ring_ok(P, 128)) return 11;
+    if (forced == 12 && ring_ok(P, 64, RG2_BM)) return 12;
     // round 4 (tests/diag/ring_check.py, ring_probe.py at B = 20): the LDS-DMA ring kernel (conv_ring.h) beats both round-1
     // kernels on every stride-1 layer with a 3..9 window -- 9x9 / 64 ch 1070 vs 930, 7x7 / 128 ch 1045 vs 886, 5x5 / 256 ch 885
     // vs 725, 3x3 / 512 ch at 8x26 418 vs 266 TFLOP/s, level with them at 16x52 (603) -- and its data gradients with a residual
@@ -1110,6 +1114,10 @@ int pick_cfg_bf16(const IgemmParams& P, int64_t M, int N, int forced) {
         // 256 x 128 tiles (0.75 fragment reads per MFMA instead of 1, no exchange of reduction halves) wherever they give every
         // CU at least one unit; else 256 x 64 (8x26 level: 68 units of 256 x 128 for 256 CUs)
         if (N % 128 == 0 && cdiv64(M, RG_BM) * (N / 128) >= P.plan_cus) return 11;
+        // round 5: 512 x 64 tiles on 32-channel slabs (conv_ring2.h) for the 64-output-channel layers with wide windows -- half
+        // the per-tile set-up and epilogue barriers per pixel, 2/3 of the LDS-DMA bytes (tests/diag/ring2_check.py at B = 20:
+        // 9x9 / 64 ch 1104 vs 1070 TFLOP/s, reflect 7x7 128 -> 64 1101 vs 1048; N >= 128 layers lose 4-8 %)
+        if (N == 64 && ring_kw(P, RG2_BM) >= 7 && cdiv64(M, RG2_BM) >= 2 * P.plan_cus) return 12;
         return 10;
     }
     if (rp && N <= 128 && cdiv64(M, RP_BM) * cdiv(N, 64) >= 448) return 9;
@@ -1256,22 +1264,27 @@ int launch_igemm(IgemmParams& P, int cfg, hipStream_t st, int ksplit = 1, void* 
             case 3: hipLaunchKernelGGL((conv_igemm_bf16<64, 64, 2, 2>), grid, dim3(256), 0, st, P); break;
             case 8: hipLaunchKernelGGL((conv_rowpatch_bf16<128, 2, 2>), dim3(gm_pad * P.grid_n), dim3(256), 0, st, P); break;
             case 9: hipLaunchKernelGGL((conv_rowpatch_bf16<64, 4, 1>), dim3(gm_pad * P.grid_n), dim3(256), 0, st, P); break;
-            case 10: case 11: {
+            case 10: case 11: case 12: case 13: {
                 // persistent workgroups, one per CU: every XCD (workgroups b, b + 8, ...) walks its band of tiles
-                const RingPlan rp = ring_plan(P, cfg == 10 ? 64 : 128);
+                const RingPlan rp = ring_plan(P, cfg);
                 const dim3 g1(rp.G), b1(512);
                 P.ksplit = rp.parts; P.ring_main = rp.main_units; P.ring_sp = rp.sp;
                 if (rp.parts > 1 && !split_ws) return GDN_ERR_WORKSPACE;
 #define GDN_RING(BNV, KWV) do { if (P.bnb_y) hipLaunchKernelGGL((conv_ring_bf16<BNV, KWV, 0, true>), g1, b1, 0, st, P); \
                                 else hipLaunchKernelGGL((conv_ring_bf16<BNV, KWV>), g1, b1, 0, st, P); } while (0)
-                const int kw = ring_kw(P);
-                if (cfg == 10) { if (kw == 3) GDN_RING(64, 3); else if (kw == 5) GDN_RING(64, 5); else if (kw == 7) GDN_RING(64, 7); else if (kw == 9) GDN_RING(64, 9); else return GDN_ERR_UNSUPPORTED; }
+#define GDN_RING2(BNV, KWV) do { if (P.bnb_y) hipLaunchKernelGGL((conv_ring2_bf16<BNV, KWV, 0, true>), g1, b1, 0, st, P); \
+                                 else hipLaunchKernelGGL((conv_ring2_bf16<BNV, KWV>), g1, b1, 0, st, P); } while (0)
+                const int kw = ring_kw(P, tc.bm);
+                if (cfg == 12) { if (kw == 3) GDN_RING2(64, 3); else if (kw == 5) GDN_RING2(64, 5); else if (kw == 7) GDN_RING2(64, 7); else if (kw == 9) GDN_RING2(64, 9); else return GDN_ERR_UNSUPPORTED; }
+                else if (cfg == 13) return GDN_ERR_UNSUPPORTED;    // (512 x 128: 128 accumulator registers per lane of 256 -- spills)
+                else if (cfg == 10) { if (kw == 3) GDN_RING(64, 3); else if (kw == 5) GDN_RING(64, 5); else if (kw == 7) GDN_RING(64, 7); else if (kw == 9) GDN_RING(64, 9); else return GDN_ERR_UNSUPPORTED; }
                 else { if (kw == 3) GDN_RING(128, 3); else if (kw == 5) GDN_RING(128, 5); else if (kw == 7) GDN_RING(128, 7); else if (kw == 9) GDN_RING(128, 9); else return GDN_ERR_UNSUPPORTED; }
 #undef GDN_RING
+#undef GDN_RING2
                 if (rp.parts > 1) {
                     // the tail ranges' slabs -> y / stats for the pixels [main_mtiles * 256, M) (a dense pixel range: ring layers have
                     // one phase and unit stride, so output pixel index == m)
-                    const int64_t p0 = (int64_t)rp.main_mtiles * RG_BM;
+                    const int64_t p0 = (int64_t)rp.main_mtiles * tc.bm;
                     const int blocks = (int)cdiv64(rp.tail_px, SK_ROWS);
                     hipLaunchKernelGGL(splitk_combine_kernel, dim3(blocks), dim3(256), 0, st, (const float*)P.part, rp.slabs, (long long)rp.tail_px,
                                        P.N, (void*)((unsigned short*)P.y + p0 * P.ldy), P.ldy,
@@ -1411,7 +1424,7 @@ extern "C" int64_t gdn_conv_stats_slots(const gdn_conv_geom* g, int32_t tile_cfg
     const int cfg = pick_cfg(P, g->Cout, scalar, tile_cfg);
     if (pick_ksplit(P, cfg, scalar, tile_cfg) > 1) return cdiv64((int64_t)P.B * P.Hy * P.Wy, SK_ROWS);
     if (cfg >= 10) {
-        const RingPlan rp = ring_plan(P, cfg == 10 ? 64 : 128);
+        const RingPlan rp = ring_plan(P, cfg);
         if (rp.parts > 1) return rp.main_mtiles + cdiv64(rp.tail_px, SK_ROWS);
     }
     return (int64_t)P.nphase * cdiv64(max_phase_m(P), kCfg[cfg].bm);
@@ -1531,7 +1544,7 @@ extern "C" int64_t gdn_conv_dgrad_bnb_slots(const gdn_conv_geom* g, int32_t tile
     P.ring_notail = (tile_cfg & 0x800) ? 1 : 0;
     const int cfg = pick_cfg(P, P.N, scalar, tile_cfg);
     if (cfg < 10) return 0;
-    const RingPlan rp = ring_plan(P, cfg == 10 ? 64 : 128);
+    const RingPlan rp = ring_plan(P, cfg);
     if (rp.parts > 1) return rp.main_mtiles + cdiv64(rp.tail_px, SK_ROWS);
     return (int64_t)P.nphase * cdiv64(max_phase_m(P), kCfg[cfg].bm);
 }

@@ -100,8 +100,10 @@ enum { GDN_ACT_NONE = 0, GDN_ACT_TANH = 1, GDN_ACT_RELU = 2 };   /* bit flags */
  * 256 x 128: the LDS-DMA ring kernel of the stride-1 layers with a 3/5/7/9 window, the automatic choice for them; its persistent
  * workgroups may cut the last round of tiles into stage ranges, whose fp32 slabs live in `workspace`: the forward and the
  * data-gradient workspace queries include them; bit 0x800, "single stage", keeps every unit whole, as it keeps the other
- * kernels from splitting over the filter taps).  For ids 10/11 bits 12..15 are measurement knobs of that kernel (timing-only
- * variants that drop an operand's LDS-DMA traffic or skip the tap loop; 0 in production). */
+ * kernels from splitting over the filter taps), 12 conv_ring2_bf16 (the same kernel on 512 x 64 tiles and 32-channel slabs:
+ * the automatic choice for 64-output-channel layers with a 7 / 9 window that fill the chip twice).  For ids 10..12 bits 12..15
+ * are measurement knobs of that kernel (timing-only variants that drop an operand's LDS-DMA traffic or skip the tap loop; 0 in
+ * production). */
 enum { GDN_CFG_KC64 = 0x200, GDN_CFG_NO_SPLITK = 0x800, GDN_CFG_BF16 = 0x10000 };
 
 /* Output spatial dims of the layer. */

@@ -61,8 +61,9 @@ def test_conv_bf16_fwd_dgrad(gpu, case):
     yr = y_ref.detach().double()
     close(st[:, 0, :].double().sum(0).cpu(), yr.sum((0, 2, 3)), rtol=1e-3, atol_scale=1e-3, what=name + " stats sum")
     close(st[:, 1, :].double().sum(0).cpu(), (yr * yr).sum((0, 2, 3)), what=name + " stats sumsq")
-    # 8, 9: row-patch kernel, 10, 11: LDS-DMA ring kernel (round 4) -- where the geometry allows it, else the automatic choice
-    for cfg in (1, 2, 3, 8, 9, 10, 11):
+    # 8, 9: row-patch kernel, 10, 11: LDS-DMA ring kernel (round 4), 12: its 512-pixel form (round 5) -- where the geometry
+    # allows it, else the automatic choice
+    for cfg in (1, 2, 3, 8, 9, 10, 11, 12):
         yc, stc = op.fwd(xd, wd, stats=True, tile_cfg=cfg | 0x800)
         close(nchw(yc.float()), y_ref, rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=name + " fwd cfg%d" % cfg)
         close(stc[:, 0, :].double().sum(0).cpu(), yr.sum((0, 2, 3)), rtol=1e-3, atol_scale=1e-3, what=name + " stats sum cfg%d" % cfg)
@@ -76,7 +77,7 @@ def test_conv_bf16_fwd_dgrad(gpu, case):
     add = r16(torch.randn(B, H, W, ci, generator=torch.Generator().manual_seed(2)))
     dx2 = op.dgrad(gyd, wt, (H, W), addsrc=add.to(gpu).bfloat16())
     close(nchw(dx2.float()), x.grad + nchw(add), rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=name + " dgrad+addsrc")
-    for cfg in (1, 8, 9, 10, 11):
+    for cfg in (1, 8, 9, 10, 11, 12):
         dx3 = op.dgrad(gyd, wt, (H, W), addsrc=add.to(gpu).bfloat16(), tile_cfg=cfg)
         close(nchw(dx3.float()), x.grad + nchw(add), rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=name + " dgrad cfg%d" % cfg)
     # weight gradient: bf16 operands, fp32 accumulation and fp32 result -> only the summation order differs
@@ -521,6 +522,19 @@ def test_bf16_rtod_vs_emulation(gpu, B):
                                   ("k5_refl", 128, 64, 5, 2, True, 2, 36, 64), ("k9_64", 64, 64, 9, 4, False, 1, 72, 64)],
                          ids=lambda c: c[0])
 def test_ring_kernel_rounds_and_tail_split(gpu, case, monkeypatch):
+    _ring_rounds_and_tail(gpu, case, monkeypatch, (10, 11))
+
+
+@pytest.mark.parametrize("case", [("k7_128", 128, 128, 7, 3, False, 2, 36, 64), ("k3_256", 256, 256, 3, 1, False, 3, 16, 48),
+                                  ("k5_refl", 128, 64, 5, 2, True, 4, 34, 64), ("k9_64", 64, 64, 9, 4, False, 2, 68, 64),
+                                  ("k9_wide", 64, 64, 9, 4, False, 1, 21, 416)],
+                         ids=lambda c: c[0])
+def test_ring2_kernel_rounds_and_tail_split(gpu, case, monkeypatch):
+    """The same for conv_ring2_bf16 (cfg 12: 512 x 64 tiles on 32-channel slabs): 17 / 18 / 20 units on the 16-CU plan."""
+    _ring_rounds_and_tail(gpu, case, monkeypatch, (12,))
+
+
+def _ring_rounds_and_tail(gpu, case, monkeypatch, cfgs):
     """conv_ring_bf16 as the driver's B = 20 shapes run it -- persistent workgroups over SEVERAL rounds of tiles, the last
     round's units cut into stage ranges whose fp32 slabs splitk_combine_kernel sums -- on shapes small enough for the CPU
     reference: GDN_RING_CUS=16 plans for a 16-CU chip (9 or 18 tiles of 256 pixels -> full rounds + a split tail of 2-4 units).  Forward (+ BatchNorm
@@ -542,8 +556,8 @@ def test_ring_kernel_rounds_and_tail_split(gpu, case, monkeypatch):
     for tail in ("1", "0"):
         monkeypatch.setenv("GDN_RING_CUS", "16")
         single = 0 if tail == "1" else 0x800                   # tile_cfg bit "single stage": the last round's units stay whole
-        for cfg in (10, 11):
-            if co % (64 if cfg == 10 else 128):
+        for cfg in cfgs:
+            if co % (128 if cfg == 11 else 64):
                 continue
             op = ops.Conv(ci, co, k, 1, p, reflect=refl)       # (a fresh op: its cached workspace size belongs to one plan)
             y, st = op.fwd(xd, wd, stats=True, tile_cfg=cfg | single)
@@ -555,7 +569,7 @@ def test_ring_kernel_rounds_and_tail_split(gpu, case, monkeypatch):
                 dx = op.dgrad(gyd, wt, (H, W), addsrc=add.to(gpu).bfloat16(), tile_cfg=cfg | single)
                 close(nchw(dx.float()), x.grad + nchw(add), rtol=RTOL_BF16, atol_scale=ATOL_BF16, what=what + " dgrad")
             res[(cfg, tail)] = (y.float().cpu(), st.shape[0])
-    for cfg in (10, 11):
+    for cfg in cfgs:
         if (cfg, "1") in res:
             a, b = res[(cfg, "1")], res[(cfg, "0")]
             assert a[1] != b[1], "the split did not happen (same slot count)"
@@ -595,9 +609,11 @@ def test_head_bf16_on_the_matrix_pipe(gpu, tr, B, H, W):
     close(nchw(y32), ref64.float(), rtol=1e-5, atol_scale=2e-6, what="fp32 head on the matrix pipe tr=%s" % tr)
 
 
-@pytest.mark.parametrize("case,cus", [(("bnb_k3_l3", 128, 128, 3, 2, 16, 52), 0), (("bnb_k9_64", 64, 64, 9, 2, 24, 64), 0),
-                                      (("bnb_k5_tail", 64, 64, 5, 4, 17, 64), 16), (("bnb_k7_relu_off", 64, 128, 7, 1, 16, 40), 0)])
-def test_ring_dgrad_emits_batchnorm_backward_partials(gpu, case, cus, monkeypatch):
+@pytest.mark.parametrize("case,cus,cfg", [(("bnb_k3_l3", 128, 128, 3, 2, 16, 52), 0, 0), (("bnb_k9_64", 64, 64, 9, 2, 24, 64), 0, 0),
+                                          (("bnb_k5_tail", 64, 64, 5, 4, 17, 64), 16, 0), (("bnb_k7_relu_off", 64, 128, 7, 1, 16, 40), 0, 0),
+                                          (("bnb_k9_64_ring2", 64, 64, 9, 2, 24, 64), 0, 12), (("bnb_k7_tail_ring2", 64, 64, 7, 8, 17, 64), 16, 12),
+                                          (("bnb_k5_128_ring2", 128, 64, 5, 3, 20, 52), 0, 12)])
+def test_ring_dgrad_emits_batchnorm_backward_partials(gpu, case, cus, cfg, monkeypatch):
     """Data gradient of a bf16 stride-1 layer on the LDS-DMA ring kernel with the producer BatchNorm's backward reduction fused
     into its epilogue (gdn_conv_dgrad bnb_*): dx is unchanged bit for bit, and the partial sums -- sum dz and sum dz * xhat with
     dz = dx [z > 0] taken from the gradient AS STORED (bf16) -- match a torch evaluation of the same stored tensors to fp32
@@ -615,14 +631,16 @@ def test_ring_dgrad_emits_batchnorm_backward_partials(gpu, case, cus, monkeypatc
                         torch.rand(ci, generator=g) + 0.5])              # scale, shift, mean, invstd
     relu = "relu_off" not in name
     op = ops.Conv(ci, co, k, 1, k // 2)
-    slots = op.dgrad_bnb_slots(B, H, W, torch.bfloat16)
+    slots = op.dgrad_bnb_slots(B, H, W, torch.bfloat16, tile_cfg=cfg)
     assert slots > 0
     if "tail" in name:       # 17 tiles on a 16-CU plan: one full round + a tail unit cut along K, finished by splitk_combine_kernel
-        assert slots != -(-B * H * W // 256), "the plan has no K-split tail"
+        assert slots != -(-B * H * W // (512 if cfg == 12 else 256)), "the plan has no K-split tail"
+    if cfg == 12 and not cus:
+        assert slots == -(-B * H * W // 512), "cfg 12 did not select the 512-pixel tiles"
     gyd, wtd, addd, yd, cd = [t.to(gpu) for t in (gy.bfloat16(), wt.bfloat16(), add.bfloat16(), y.bfloat16(), coef)]
-    dx0 = op.dgrad(gyd, wtd, (H, W), addsrc=addd)
+    dx0 = op.dgrad(gyd, wtd, (H, W), addsrc=addd, tile_cfg=cfg)
     part = torch.full((slots, 2, ci), float("nan"), device=gpu)
-    dx1 = op.dgrad(gyd, wtd, (H, W), addsrc=addd, bnb=(yd, cd, relu, part))
+    dx1 = op.dgrad(gyd, wtd, (H, W), addsrc=addd, bnb=(yd, cd, relu, part), tile_cfg=cfg)
     assert torch.equal(dx0, dx1)
     dxs, ys = dx1.float().cpu().double(), y.double()
     mask = ((ys * coef[0].double() + coef[1].double()) > 0) if relu else torch.ones_like(ys, dtype=torch.bool)

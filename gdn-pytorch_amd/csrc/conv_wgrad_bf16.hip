@@ -414,8 +414,11 @@ bool make_plan_ring(const gdn_conv_geom* g, int Cx_in, bool forced, PlanRing& pl
         P.TWp = P.TW; P.nr = 1;
     }
     P.ring = P.nr == 1;
-    P.RP = P.TWp + 8;
     P.nks = cdiv(P.nr * P.TWp, 16);
+    // X row pitch: the last k-step's windows end 8 positions past its 16 pixels.  A ring row is read in whole k-steps, so a width
+    // that is 8 mod 16 needs the pitch of the next multiple of 16 (the pixels past TWp meet a zero dY, but they must be LDS this
+    // launch wrote: stale NaN bit patterns times zero are NaN -- tests/diag/wgrad_ring_poison.py)
+    P.RP = (P.ring ? P.nks * 16 : P.TWp) + 8;
     if (P.nks * 16 > WR_GPX) return false;
     if ((size_t)(P.ring ? 3 : 2 * (P.nr + 1)) * P.RP * 128 > WR_XBYTES) return false;
     if ((P.ring ? 1 : P.nr + 1) * (P.RP / 8) > (P.ring ? 32 : 48)) return false;     // DMA pieces per stage the kernel unrolls

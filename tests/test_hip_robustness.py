@@ -590,3 +590,61 @@ def test_training_does_not_read_lds_left_by_other_workgroups(gpu):
         assert r.returncode == 0, r.stderr[-2000:]
     clean = _diag_child("lds_poison.py", [-1, 2, 32, 64, 2])
     assert _diag_child("lds_poison.py", [0xFFFFFFFF, 2, 32, 64, 2]) == clean
+
+
+def _lds_fill_lib():
+    """tests/diag/lds_fill.hip as a shared object (built here with hipcc when the snapshot does not carry it)."""
+    import ctypes
+    import pathlib
+    import shutil
+    import subprocess
+    root = pathlib.Path(__file__).resolve().parent.parent
+    so = root / "tests" / "diag" / "_build" / "liblds_fill.so"
+    if not so.exists():
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        so.parent.mkdir(exist_ok=True)
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", str(so),
+                            str(root / "tests" / "diag" / "lds_fill.hip")], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+    lf = ctypes.CDLL(str(so))
+    lf.lds_fill.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    return lf
+
+
+@pytest.mark.gpu
+def test_bf16_lds_dma_kernels_do_not_read_stale_lds(gpu):
+    """The LDS-DMA kernels of the bf16 path (conv_ring_bf16, conv_ring2_bf16, wgrad_ring_bf16) with the whole LDS of every CU
+    filled with NaN bit patterns before each launch: same bits as the clean launch, on the shapes that walk every staging path
+    (round 5: a ring row whose width is 8 mod 16 was read 8 positions past what the launch had written -- stale values times a
+    zero gradient, harmless until the stale value is a NaN)."""
+    from gdn_amd import ops
+    from test_hip_bf16 import RING_WGRAD_CASES
+    lf = _lds_fill_lib()
+    sink = torch.zeros(4, dtype=torch.int32, device=gpu)
+    g = torch.Generator(device=gpu).manual_seed(0)
+
+    def poisoned(fn):
+        ref = fn()
+        for pat in (0xFFFFFFFF, 0x7F007F00):
+            assert lf.lds_fill(pat, sink.data_ptr(), ops.stream()) == 0
+            out = fn()
+            for a, b in zip(ref if isinstance(ref, tuple) else (ref,), out if isinstance(out, tuple) else (out,)):
+                assert torch.equal(a, b), "LDS pattern %#x changes the result" % pat
+    for name, ci, co, k, p, refl, B, H, W in RING_WGRAD_CASES + [("k9_b3_128x416", 64, 64, 9, 4, False, 3, 128, 416)]:
+        op = ops.Conv(ci, co, k, 1, p, reflect=refl)
+        Ho, Wo = H + 2 * p - k + 1, W + 2 * p - k + 1
+        x = torch.randn(B, H, W, ci, device=gpu, generator=g).bfloat16()
+        gy = torch.randn(B, Ho, Wo, co, device=gpu, generator=g).bfloat16()
+
+        def wgrad():
+            dw = torch.zeros(k * k, co, ci, device=gpu)
+            op.wgrad(x, gy, dw, cfg=4)
+            return dw
+        poisoned(wgrad)
+        if p == k // 2:
+            w = (torch.randn(k * k, co, ci, device=gpu, generator=g) * 0.05).bfloat16()
+            wt = ops.transpose_taps(w)
+            for cfg in (10, 11, 12):
+                poisoned(lambda: op.fwd(x, w, stats=True, tile_cfg=cfg))
+                if not refl:
+                    poisoned(lambda: op.dgrad(gy, wt, (H, W), addsrc=x, tile_cfg=cfg))

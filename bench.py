@@ -288,8 +288,10 @@ def step_kernel_breakdown(step, nsteps=2, top=8):
 
 
 def ring_roofline(dev, B, reps=20):
-    """BASELINE configs[2]'s dominant kernel (round 4): conv_ring_bf16<64, 9>, the 9x9 64->64 stride-1 layer at level 0
-    (128x416) on the bf16 matrix pipe -- forward with the BatchNorm partials, and the data gradient with a residual."""
+    """BASELINE configs[2]'s dominant kernel: the LDS-DMA ring kernel on the 9x9 64->64 stride-1 layer at level 0 (128x416) on the
+    bf16 matrix pipe -- conv_ring2_bf16<64, 9> (round 5: 512 x 64 tiles on 32-channel slabs, the automatic choice), round 4's
+    conv_ring_bf16<64, 9> (256 x 64, tile id 10) beside it -- forward with the BatchNorm partials, and the data gradient with a
+    residual."""
     from gdn_amd import ops
     H, W, C, k = 128, 416, 64, 9
     op = ops.Conv(C, C, k, 1, k // 2)
@@ -312,18 +314,23 @@ def ring_roofline(dev, B, reps=20):
 
     # interleaved rounds in one process, best of three each: the clock the chip holds depends on what ran just before
     # (cdna_hip_programming.md rule 24), so a single A-then-B pass ranks whichever ran second higher
-    ms_f = ms_d = ms_old = 1e9
+    ms_f = ms_d = ms_old = ms_r4 = 1e9
+    st10 = op.fwd(x, w, stats=True, tile_cfg=10)[1]
     for _ in range(3):
         ms_old = min(ms_old, timed(lambda: op.fwd(x, w, stats=True, out=y, stats_out=st, tile_cfg=9)))
+        ms_r4 = min(ms_r4, timed(lambda: op.fwd(x, w, stats=True, out=y, stats_out=st10, tile_cfg=10)))
         ms_f = min(ms_f, timed(lambda: op.fwd(x, w, stats=True, out=y, stats_out=st)))
         ms_d = min(ms_d, timed(lambda: op.dgrad(x, wt, (H, W), addsrc=add)))
     flop = 2.0 * B * H * W * k * k * C * C
     a = flop / (ms_f * 1e-3) / 1e12
-    return {"kernel": "conv_ring_bf16<64, 9>: 9x9 s1 64->64 + BN-stats epilogue, B=%d 128x416 (level 0), bf16 in / fp32 accumulate -- the "
-                      "dominant kernel of the RtoD bf16 step (configs[2]); LDS-DMA ring, persistent workgroups (DESIGN.md 2.11)" % B,
+    return {"kernel": "conv_ring2_bf16<64, 9>: 9x9 s1 64->64 + BN-stats epilogue, B=%d 128x416 (level 0), bf16 in / fp32 accumulate -- the "
+                      "dominant kernel of the RtoD bf16 step (configs[2]); LDS-DMA ring, persistent workgroups, 512 x 64 tiles "
+                      "(DESIGN.md 2.11)" % B,
             "bound": "mfma", "unit": "TFLOP/s", "achieved": round(a, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
             "frac": round(a / PEAK_BF16_MFMA_TFLOPS, 4), "gflop_per_launch": round(flop / 1e9, 1), "ms_per_launch": round(ms_f, 4),
-            "traffic": pmc_traffic("r04_conv_ring_pmc.json"),
+            "traffic": pmc_traffic("r05_conv_ring_pmc.json"),
+            "round4_kernel": {"kernel": "conv_ring_bf16<64, 9> (tile_cfg 10: 256 x 64 tiles)", "ms_per_launch": round(ms_r4, 4),
+                              "achieved": round(flop / (ms_r4 * 1e-3) / 1e12, 1)},
             "dgrad_with_residual": {"ms_per_launch": round(ms_d, 4), "achieved": round(flop / (ms_d * 1e-3) / 1e12, 1)},
             "round1_kernel": {"kernel": "conv_rowpatch_bf16<64,4,1> (tile_cfg 9)", "ms_per_launch": round(ms_old, 4),
                               "achieved": round(flop / (ms_old * 1e-3) / 1e12, 1)}}

@@ -1226,7 +1226,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         if (f.reflect && dx_up2x)
             // dx is the gradient of the LOW-resolution tensor the forward upsampled on load: fold + adjoint interpolation
             hipLaunchKernelGGL(reflect_fold_up2x_kernel, dim3(blocks((int64_t)f.B * (f.H / 2) * (f.W / 2) * (f.C / 4))), dim3(256), 0,
-                               st, (const float*)dxp, dx, ldx, addsrc, ld_add, f.B, f.H, f.W, f.C, f.pad, dx_up2x - 1);
+                               st, (const void*)dxp, (void*)dx, ldx, (const void*)addsrc, ld_add, f.B, f.H, f.W, f.C, f.pad, dx_up2x - 1, 0);
         else if (f.reflect)
             hipLaunchKernelGGL(fft_reflect_fold_kernel, dim3(blocks((int64_t)f.B * f.H * f.W * (f.C / 4))), dim3(256), 0, st,
                                (const float*)dxp, dx, ldx, addsrc, ld_add, f.B, f.H, f.W, f.C, f.pad);

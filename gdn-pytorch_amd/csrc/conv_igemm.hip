@@ -22,6 +22,7 @@
 // (issue loads for k-step i+1, run the MFMAs of k-step i, then write LDS) so
 // HBM/L2 latency hides under the 2-4k MFMA cycles of a k-step.
 #include "common.h"
+#include "up2x.h"
 
 #define MAX_TAPS 81
 #define MAX_PHASE 4
@@ -1551,7 +1552,7 @@ extern "C" int64_t gdn_conv_dgrad_bnb_slots(const gdn_conv_geom* g, int32_t tile
 
 extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t ldy, const void* wtv, void* dxv,
                               int32_t ldx, const void* addsrcv, int32_t ld_add, const void* bnb_y, int32_t ld_bnb,
-                              const float* bnb_co, int32_t bnb_relu, float* bnb_partial, void* workspace,
+                              const float* bnb_co, int32_t bnb_relu, float* bnb_partial, int32_t dx_up2x, void* workspace,
                               size_t workspace_bytes, int32_t tile_cfg, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
     const float *dy = (const float*)dyv, *wt = (const float*)wtv, *addsrc = (const float*)addsrcv;
@@ -1574,6 +1575,10 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t l
     if (bf && (scalar || (g->Cout % 64) || (ldy % 8) || (g->Cin % 4))) return GDN_ERR_UNSUPPORTED;
     P.bf16 = bf ? 1 : 0;
     if (fold && (g->Cin % 4) && bf) return GDN_ERR_UNSUPPORTED;
+    // dx_up2x (1: align_corners False, 2: True): the layer's input was the x2 bilinear upsampling of a tensor with no other
+    // consumer of the upsampled form; dx / addsrc are THAT tensor's gradient [B, H/2, W/2, Cin] -- the fold pass of a reflection
+    // layer applies the adjoint of the interpolation as it folds (up2x.h), the full-resolution gradient is never written
+    if (dx_up2x && (dx_up2x < 0 || dx_up2x > 2 || !fold || (g->Cin % 4) || (g->H & 1) || (g->W & 1) || bnb_y)) return GDN_ERR_UNSUPPORTED;
     P.ring_notail = (tile_cfg & 0x800) ? 1 : 0;
     const int cfg = pick_cfg(P, P.N, scalar, tile_cfg);
     const int ksplit = pick_ksplit(P, cfg, scalar, tile_cfg);
@@ -1599,6 +1604,13 @@ extern "C" int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dyv, int32_t l
         const int blocks = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
         hipLaunchKernelGGL(reflect_fold_scalar_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dx, addsrc,
                            ld_add, ldx, g->B, g->H, g->W, g->Cin, g->pad);
+        rc = gdn_launch_status();
+    } else if (fold && dx_up2x) {
+        const bool w8 = (g->Cin % 8) == 0 && (ldx % 8) == 0 && (!addsrc || (ld_add % 8) == 0);
+        const int64_t nb = cdiv64((int64_t)g->B * (g->H / 2) * (g->W / 2) * (g->Cin / (w8 ? 8 : 4)), 256);
+        hipLaunchKernelGGL(w8 ? reflect_fold_up2x8_kernel : reflect_fold_up2x_kernel, dim3((unsigned)(nb < 65536 * 8 ? nb : 65536 * 8)),
+                           dim3(256), 0, st, (const void*)workspace, (void*)dx, ldx, (const void*)addsrc, ld_add, g->B, g->H, g->W,
+                           g->Cin, g->pad, dx_up2x - 1, P.bf16);
         rc = gdn_launch_status();
     } else if (fold) {
         const int64_t total = (int64_t)g->B * g->H * g->W * (g->Cin / 4);

@@ -888,7 +888,7 @@ extern "C" int gdn_winoconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t
             // dx is the gradient of the LOW-resolution tensor the forward upsampled on load: fold + adjoint interpolation
             const int64_t nb = cdiv64((int64_t)f.B * (f.H / 2) * (f.W / 2) * (f.C / 4), 256);
             hipLaunchKernelGGL(reflect_fold_up2x_kernel, dim3((unsigned)(nb < 65536 * 8 ? nb : 65536 * 8)), dim3(256), 0, st,
-                               (const float*)out, dx, ldx, addsrc, ld_add, f.B, f.H, f.W, f.C, 1, dx_up2x - 1);
+                               (const void*)out, (void*)dx, ldx, (const void*)addsrc, ld_add, f.B, f.H, f.W, f.C, 1, dx_up2x - 1, 0);
         } else if (f.reflect) {
             const int64_t nb = cdiv64((int64_t)f.B * f.H * f.W * (f.C / 4), 256);
             hipLaunchKernelGGL(wino_reflect_fold_kernel, dim3((unsigned)(nb < 65536 * 8 ? nb : 65536 * 8)), dim3(256), 0, st,

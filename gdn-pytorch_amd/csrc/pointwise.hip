@@ -276,6 +276,144 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const void* __restr
     }
 }
 
+// Round 5 (row N1, bf16 forward half): out = [relu](y * scale + shift) (+ residual) and its x2 bilinear upsampling in ONE pass
+// -- a ResidualBlock's output x + bn2(conv2(.)) followed by F.interpolate (AE_model_unet.py:55-57 -> :336-359).  Reads the raw
+// convolution output and the residual, writes the block output (low resolution; `low` may be null) and the upsampled tensor; the
+// block output is not read back.  Same arithmetic and the same rounding points as bn_apply8_kernel followed by
+// upsample2x_fwd_kernel: the four neighbours are rounded to the block output's storage type before they are interpolated, so the
+// two forms agree bit for bit.  grid.y = output row (b, oy); the thread at odd (oy, ox) also stores the low-resolution value.
+__global__ __launch_bounds__(256) void bn_apply_up2x_kernel(const void* __restrict__ y, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const void* __restrict__ res,
+                                                            void* __restrict__ low, void* __restrict__ up, int B, int H, int W,
+                                                            int C, int relu, int align, int dt, int sh) {
+    const int cq = C >> 2, Ho = 2 * H, Wo = 2 * W;
+    const int row = blockIdx.y, b = row / Ho, oy = row - b * Ho;
+    float ly; int y0, y1;
+    up_src(oy, H, align, ly, y0, y1);
+    const size_t xb = (size_t)b * H * W * C;
+    auto act = [&](int yy, int xx, int c, const f32x4& s, const f32x4& t) {
+        const size_t at = xb + ((size_t)yy * W + xx) * C + c;
+        f32x4 o = ld4_any(y, at, dt & 1) * s + t;
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        if (res) o += ld4_any(res, at, dt & 2);
+        if (dt & 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = bf16_h_to_f32(f32_to_bf16_h(o[e]));
+        }
+        return o;
+    };
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < Wo * cq; j += gridDim.x * 256) {
+        const int ox = sh >= 0 ? j >> sh : j / cq;
+        const int c = (sh >= 0 ? j & (cq - 1) : j - ox * cq) * 4;
+        float lx; int x0, x1;
+        up_src(ox, W, align, lx, x0, x1);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c), t = *reinterpret_cast<const f32x4*>(shift + c);
+        const f32x4 v00 = act(y0, x0, c, s, t), v01 = act(y0, x1, c, s, t), v10 = act(y1, x0, c, s, t), v11 = act(y1, x1, c, s, t);
+        const f32x4 o = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        st4_any(up, (((size_t)b * Ho + oy) * Wo + ox) * C + c, o, dt & 8);
+        if (low && (oy & 1) && (ox & 1)) {
+            const int iy = oy >> 1, ix = ox >> 1;      // (floor(src) of an odd output index is its own source pixel, up to rounding)
+            const f32x4 a = (y0 == iy && x0 == ix) ? v00 : act(iy, ix, c, s, t);
+            st4_any(low, xb + ((size_t)iy * W + ix) * C + c, a, dt & 4);
+        }
+    }
+}
+
+// The same in tiles (C % 8 == 0, C <= 1024): a workgroup owns TXL low-resolution columns x all channels (8 per lane: 16-byte
+// accesses on bf16 tensors) and walks RC low-resolution rows, keeping the last three rows of the block output -- already rounded
+// to its storage type -- in LDS with one halo column on either side: every element of y / residual is read once per workgroup
+// that needs it (halo rows and columns are the only re-reads), the BatchNorm arithmetic runs once per element, and each lane
+// stores the 2 x 2 output pixels of its low-resolution pixel as whole 16-byte pieces of full pixel lines.  Same values as the
+// kernel above, bit for bit.
+__global__ __launch_bounds__(256) void bn_apply_up2x8_kernel(const void* __restrict__ y, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const void* __restrict__ res,
+                                                             void* __restrict__ low, void* __restrict__ up, int B, int H, int W,
+                                                             int C, int relu, int align, int dt, int TXL, int RC) {
+    extern __shared__ float a_s[];                             // [3 rows][TXL + 2 columns][C]
+    const int CG = C >> 3, tid = threadIdx.x;
+    const int cg = tid % CG, cl = tid / CG;                    // channel group, local column (>= TXL: only halo duty)
+    const int xb0 = blockIdx.x * TXL, b = blockIdx.z, r0 = blockIdx.y * RC, r1 = min(H, r0 + RC);
+    const int ix = xb0 + cl, c = cg * 8;
+    const bool mine = cl < TXL && ix < W;
+    const int rowf = (TXL + 2) * C;                            // floats per LDS row
+    const size_t xb = (size_t)b * H * W * C;
+    auto act = [&](int yy, int xx, int cc, f32x4& o0, f32x4& o1) {
+        const size_t at = xb + ((size_t)yy * W + xx) * C + cc;
+        f32x4 v0, v1;
+        ld8_any(y, at, dt & 1, v0, v1);
+        o0 = v0 * *reinterpret_cast<const f32x4*>(scale + cc) + *reinterpret_cast<const f32x4*>(shift + cc);
+        o1 = v1 * *reinterpret_cast<const f32x4*>(scale + cc + 4) + *reinterpret_cast<const f32x4*>(shift + cc + 4);
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o0[e] = fmaxf(o0[e], 0.f); o1[e] = fmaxf(o1[e], 0.f); }
+        }
+        if (res) {
+            f32x4 q0, q1;
+            ld8_any(res, at, dt & 2, q0, q1);
+            o0 += q0; o1 += q1;
+        }
+        if (dt & 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o0[e] = bf16_h_to_f32(f32_to_bf16_h(o0[e])); o1[e] = bf16_h_to_f32(f32_to_bf16_h(o1[e])); }
+        }
+    };
+    auto load_row = [&](int iy) {                              // block output row iy, columns xb0 - 1 .. xb0 + TXL -> slot iy % 3
+        if (iy < 0 || iy >= H) return;                         // (never referenced: up_src clamps)
+        float* dst = a_s + (iy % 3) * rowf;
+        f32x4 o0, o1;
+        if (mine) {
+            act(iy, ix, c, o0, o1);
+            *reinterpret_cast<f32x4*>(dst + (cl + 1) * C + c) = o0;
+            *reinterpret_cast<f32x4*>(dst + (cl + 1) * C + c + 4) = o1;
+            if (low && iy >= r0 && iy < r1) st8_any(low, xb + ((size_t)iy * W + ix) * C + c, o0, o1, dt & 4);
+        }
+        if (tid < 2 * CG) {                                    // the two halo columns
+            const int side = tid / CG, hx = side ? xb0 + TXL : xb0 - 1;
+            if (hx >= 0 && hx < W) {
+                act(iy, hx, c, o0, o1);
+                *reinterpret_cast<f32x4*>(dst + (side ? TXL + 1 : 0) * C + c) = o0;
+                *reinterpret_cast<f32x4*>(dst + (side ? TXL + 1 : 0) * C + c + 4) = o1;
+            }
+        }
+    };
+    const int Ho = 2 * H, Wo = 2 * W;
+    load_row(r0 - 1);
+    load_row(r0);
+    for (int iy = r0; iy < r1; ++iy) {
+        load_row(iy + 1);
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int oy = 2 * iy + dy;
+                float ly; int y0, y1;
+                up_src(oy, H, align, ly, y0, y1);
+                const float* ra = a_s + (y0 % 3) * rowf + c;
+                const float* rb = a_s + (y1 % 3) * rowf + c;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int ox = 2 * ix + dx;
+                    float lx; int x0, x1;
+                    up_src(ox, W, align, lx, x0, x1);
+                    const int j0 = (x0 - xb0 + 1) * C, j1 = (x1 - xb0 + 1) * C;
+                    f32x4 o[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const f32x4 v00 = *reinterpret_cast<const f32x4*>(ra + j0 + 4 * hh), v01 = *reinterpret_cast<const f32x4*>(ra + j1 + 4 * hh);
+                        const f32x4 v10 = *reinterpret_cast<const f32x4*>(rb + j0 + 4 * hh), v11 = *reinterpret_cast<const f32x4*>(rb + j1 + 4 * hh);
+                        o[hh] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+                    }
+                    st8_any(up, (((size_t)b * Ho + oy) * Wo + ox) * C + c, o[0], o[1], dt & 8);
+                }
+            }
+        }
+        __syncthreads();                                       // (the next row overwrites the slot of row iy - 1)
+    }
+}
+
 // Gather form of the adjoint (deterministic, no atomics): each input pixel sums
 // the <= 6x6 output pixels whose stencil touches it.
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const void* __restrict__ dy, void* __restrict__ dx,
@@ -615,6 +753,29 @@ extern "C" int gdn_upsample2x_fwd(const void* x, void* y, int32_t B, int32_t H, 
     return gdn_launch_status();
 }
 
+extern "C" int gdn_bn_apply_up2x(const void* y, const float* scale, const float* shift, const void* residual, void* low,
+                                 void* up, int32_t B, int32_t H, int32_t W, int32_t C, int32_t relu, int32_t align_corners,
+                                 int32_t dtypes, void* stream) {
+    (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
+    if (!y || !scale || !shift || !up || B <= 0 || H <= 0 || W <= 0 || C <= 0) return GDN_ERR_BAD_ARG;
+    if (C % 4) return GDN_ERR_UNSUPPORTED;
+    if ((int64_t)B * 2 * H > 65535) return GDN_ERR_UNSUPPORTED;      // grid.y limit
+    if ((C % 8) == 0 && C <= 1024 && B <= 65535) {
+        // tiles: TXL low-resolution columns x all channels per workgroup, RC rows per workgroup (more where the tensor is large
+        // enough to still give every CU several workgroups: a workgroup re-reads one halo row above and below its range)
+        const int TXL = 256 / (C / 8), nbx = cdiv(W, TXL);
+        int RC = 16;
+        while (RC > 2 && (int64_t)B * nbx * cdiv(H, RC) < 2048) RC >>= 1;
+        const size_t lds = (size_t)3 * (TXL + 2) * C * sizeof(float);
+        hipLaunchKernelGGL(bn_apply_up2x8_kernel, dim3(nbx, cdiv(H, RC), B), dim3(256), lds, ST(stream), y, scale, shift, residual,
+                           low, up, B, H, W, C, relu, align_corners, dtypes, TXL, RC);
+        return gdn_launch_status();
+    }
+    hipLaunchKernelGGL(bn_apply_up2x_kernel, dim3(cdiv(2 * W * (C / 4), 256), B * 2 * H), dim3(256), 0, ST(stream), y, scale,
+                       shift, residual, low, up, B, H, W, C, relu, align_corners, dtypes, pow2_shift(C / 4));
+    return gdn_launch_status();
+}
+
 extern "C" int gdn_upsample2x_bwd(const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C,
                                   int32_t align_corners, int32_t dtypes, void* stream) {
     (void)hipGetLastError();   // drop stale errors left by other HIP users of this thread
@@ -732,7 +893,7 @@ extern "C" int gdn_adam_step_dev(float* p, const float* g, float* m, float* v, i
     return gdn_launch_status();
 }
 
-extern "C" int gdn_version(void) { return 219; }
+extern "C" int gdn_version(void) { return 220; }
 
 extern "C" const char* gdn_strerror(int status) {
     switch (status) {

@@ -40,9 +40,10 @@ __device__ __forceinline__ float up2x_at(const float* __restrict__ r0, const flo
 // dx[b][iy][ix] (extent H/2 x W/2) = sum over the upsampled pixels (oy, ox) whose stencil touches (iy, ix) of
 // weight * F(oy, ox), F = the padded-domain gradient dxp [B][H+2p][W+2p][C] summed over the padded coordinates that reflect
 // onto (oy, ox)  (+ addsrc, low resolution).  H, W: the upsampled extent = the convolution's input extent.
-__global__ __launch_bounds__(256) void reflect_fold_up2x_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int ldx,
-                                                                const float* __restrict__ addsrc, int ld_add,
-                                                                int B, int H, int W, int C, int p, int align) {
+// bf16: all three tensors hold bfloat16 (the bf16 layers' data gradient, round 5: gdn_conv_dgrad dx_up2x); sums in fp32.
+__global__ __launch_bounds__(256) void reflect_fold_up2x_kernel(const void* __restrict__ dxp, void* __restrict__ dx, int ldx,
+                                                                const void* __restrict__ addsrc, int ld_add,
+                                                                int B, int H, int W, int C, int p, int align, int bf16) {
     const int Hp = H + 2 * p, Wp = W + 2 * p, c4n = C / 4, Hl = H / 2, Wl = W / 2;
     const int64_t total = (int64_t)B * Hl * Wl * c4n;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -75,13 +76,72 @@ __global__ __launch_bounds__(256) void reflect_fold_up2x_kernel(const float* __r
                 f32x4 f4 = {0.f, 0.f, 0.f, 0.f};
                 for (int a = 0; a < ny; ++a)
                     for (int e = 0; e < nx; ++e)
-                        f4 += *reinterpret_cast<const f32x4*>(dxp + ((size_t)(b * Hp + qy[a]) * Wp + qx[e]) * C + c4 * 4);
+                        f4 += ld4_any(dxp, ((size_t)(b * Hp + qy[a]) * Wp + qx[e]) * C + c4 * 4, bf16);
                 s4 += (wy * wx) * f4;
             }
         }
         const size_t op = (size_t)(b * Hl + iy) * Wl + ix;
-        if (addsrc) s4 += *reinterpret_cast<const f32x4*>(addsrc + op * ld_add + c4 * 4);
-        *reinterpret_cast<f32x4*>(dx + op * ldx + c4 * 4) = s4;
+        if (addsrc) s4 += ld4_any(addsrc, op * ld_add + c4 * 4, bf16);
+        st4_any(dx, op * ldx + c4 * 4, s4, bf16);
+    }
+}
+
+// The same with 8 channels per lane (16-byte accesses on bf16 tensors) and the interpolation weights of the 6 candidate rows /
+// columns computed once per lane instead of once per candidate pair.  C % 8 == 0, pitches multiples of 8.
+__global__ __launch_bounds__(256) void reflect_fold_up2x8_kernel(const void* __restrict__ dxp, void* __restrict__ dx, int ldx,
+                                                                 const void* __restrict__ addsrc, int ld_add,
+                                                                 int B, int H, int W, int C, int p, int align, int bf16) {
+    const int Hp = H + 2 * p, Wp = W + 2 * p, c8n = C / 8, Hl = H / 2, Wl = W / 2;
+    const int64_t total = (int64_t)B * Hl * Wl * c8n;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c8 = (int)(i % c8n);
+        int64_t t = i / c8n;
+        const int ix = (int)(t % Wl); t /= Wl;
+        const int iy = (int)(t % Hl), b = (int)(t / Hl);
+        float wy[6], wx[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float l; int a0, a1;
+            const int oy = 2 * iy - 2 + j, ox = 2 * ix - 2 + j;
+            wy[j] = wx[j] = 0.f;
+            if (oy >= 0 && oy < H) { up_src(oy, Hl, align, l, a0, a1); wy[j] = (a0 == iy ? 1.f - l : 0.f) + (a1 == iy ? l : 0.f); }
+            if (ox >= 0 && ox < W) { up_src(ox, Wl, align, l, a0, a1); wx[j] = (a0 == ix ? 1.f - l : 0.f) + (a1 == ix ? l : 0.f); }
+        }
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jy = 0; jy < 6; ++jy) {
+            if (wy[jy] == 0.f) continue;
+            const int oy = 2 * iy - 2 + jy;
+            int qy[3], ny = 0;
+            qy[ny++] = oy + p;
+            if (oy >= 1 && oy <= p) qy[ny++] = p - oy;
+            if (oy <= H - 2 && oy >= H - 1 - p) qy[ny++] = 2 * (H - 1) - oy + p;
+#pragma unroll
+            for (int jx = 0; jx < 6; ++jx) {
+                if (wx[jx] == 0.f) continue;
+                const int ox = 2 * ix - 2 + jx;
+                int qx[3], nx = 0;
+                qx[nx++] = ox + p;
+                if (ox >= 1 && ox <= p) qx[nx++] = p - ox;
+                if (ox <= W - 2 && ox >= W - 1 - p) qx[nx++] = 2 * (W - 1) - ox + p;
+                f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = {0.f, 0.f, 0.f, 0.f};
+                for (int a = 0; a < ny; ++a)
+                    for (int e = 0; e < nx; ++e) {
+                        f32x4 g0, g1;
+                        ld8_any(dxp, ((size_t)(b * Hp + qy[a]) * Wp + qx[e]) * C + c8 * 8, bf16, g0, g1);
+                        f0 += g0; f1 += g1;
+                    }
+                s0 += (wy[jy] * wx[jx]) * f0;
+                s1 += (wy[jy] * wx[jx]) * f1;
+            }
+        }
+        const size_t op = (size_t)(b * Hl + iy) * Wl + ix;
+        if (addsrc) {
+            f32x4 g0, g1;
+            ld8_any(addsrc, op * ld_add + c8 * 8, bf16, g0, g1);
+            s0 += g0; s1 += g1;
+        }
+        st8_any(dx, op * ldx + c8 * 8, s0, s1, bf16);
     }
 }
 

@@ -131,11 +131,13 @@ class ResidualBlock(_HipModule):
             nn.Conv2d(dim_out, dim_out, kernel_size, 1, padding, bias=False),
             nn.BatchNorm2d(dim_out, affine=True, track_running_stats=True))
 
-    def run(self, ctx, x):
+    def run(self, ctx, x, up_out=None):
+        """up_out (None / align_corners flag): also return the block output upsampled x2 -- (out, up) -- for the decoder's
+        F.interpolate (reference :336-359); on the bf16 path one kernel writes both."""
         m = self.main
         # a = relu(bn1(conv1 x)) has one consumer: deferred into conv2's patch loader (never written in train mode)
         a = E.conv_bn_act(ctx, x, m[0], m[1], relu=True, defer=True)
-        return E.conv_bn_act(ctx, a, m[3], m[4], relu=False, residual=x)
+        return E.conv_bn_act(ctx, a, m[3], m[4], relu=False, residual=x, up_out=up_out)
 
     def _run(self, ctx, x):
         return (self.run(ctx, x),)
@@ -267,16 +269,19 @@ class AutoEncoder_2(_EncDec):
         x4_cat = self.downconv3.run(ctx, x3)
         x4 = self.res512_down2.run(ctx, self.res512_down1.run(ctx, x4_cat))
         x6 = self.downconv4.run(ctx, x4)
-        for i in range(1, 7):
+        for i in range(1, 6):
             x6 = getattr(self, "res512_%d" % i).run(ctx, x6)
-        x7 = self.upconv0.run(ctx, E.upsample(ctx, x6))
+        # every F.interpolate(.., scale_factor=2, mode='bilinear') of the decoder (reference :336-359) takes a ResidualBlock's
+        # output: the block hands back (output, upsampled output)
+        x6, x6_up = self.res512_6.run(ctx, x6, up_out=False)
+        x7 = self.upconv0.run(ctx, x6_up)
         x8 = self.conv1x1_512.run(ctx, x7, x2=x4_cat)            # cat((x7, x4_cat), 1) fused into the 1x1
-        x8 = self.res512_up2.run(ctx, self.res512_up1.run(ctx, x8))
-        x9 = self.upconv1.run(ctx, E.upsample(ctx, x8))
-        x10 = self.res256_up1.run(ctx, self.conv1x1_256.run(ctx, x9, x2=x3_cat))
-        x11 = self.upconv2.run(ctx, E.upsample(ctx, x10))
-        x12 = self.res128_up1.run(ctx, self.conv1x1_128.run(ctx, x11, x2=x2_cat))
-        x13 = self.upconv3.run(ctx, E.upsample(ctx, x12))
+        x8, x8_up = self.res512_up2.run(ctx, self.res512_up1.run(ctx, x8), up_out=False)
+        x9 = self.upconv1.run(ctx, x8_up)
+        x10, x10_up = self.res256_up1.run(ctx, self.conv1x1_256.run(ctx, x9, x2=x3_cat), up_out=False)
+        x11 = self.upconv2.run(ctx, x10_up)
+        x12, x12_up = self.res128_up1.run(ctx, self.conv1x1_128.run(ctx, x11, x2=x2_cat), up_out=False)
+        x13 = self.upconv3.run(ctx, x12_up)
         x14 = self.res64_up1.run(ctx, self.conv1x1_64.run(ctx, x13, x2=x1_cat))
         x15 = E.conv_head_tanh(ctx, x14, self.upconv4)
         return x1, x2, x4, x6, x8, x12, x14, x15

@@ -37,7 +37,7 @@ _SIGS = {
     "gdn_conv_fwd_workspace_bytes": (_sz, [_PG, _i32]),
     "gdn_conv_fwd": (c_int32, [_PG, _P, _i32, _P, _i32, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _i32, _P, _sz, _P]),
     "gdn_conv_dgrad_workspace_bytes": (_sz, [_PG, _i32]),
-    "gdn_conv_dgrad": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _i32, _P, _i32, _P, _P, _sz, _i32, _P]),
+    "gdn_conv_dgrad": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _i32, _P, _i32, _P, _i32, _P, _sz, _i32, _P]),
     "gdn_conv_dgrad_bnb_slots": (_i64, [_PG, _i32]),
     "gdn_conv_wgrad_workspace_bytes": (_sz, [_PG, _i32]),
     "gdn_conv_wgrad": (c_int32, [_PG, _P, _i32, _i32, _P, _i32, _P, _i32, _i32, _P, _sz, _i32, _P]),
@@ -87,6 +87,7 @@ _SIGS = {
     "gdn_bn_bwd": (c_int32, [_P, _i32, _P, _i32, _P, _P, _P, _P, _P, _P, _i32, _P, _P, _i64, _i32, _i32, _P, _i64, _P, _sz, _i32, _P]),
     "gdn_bn_bwd_coeffs": (c_int32, [_P, _i32, _P, _i32, _P, _P, _P, _P, _P, _P, _P, _i64, _i32, _i32, _P, _i64, _P, _sz, _i32, _P]),
     "gdn_bn_eval_bwd": (c_int32, [_P, _i32, _P, _i32, _P, _P, _P, _i32, _i64, _i32, _i32, _i32, _P]),
+    "gdn_bn_apply_up2x": (c_int32, [_P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "gdn_upsample2x_fwd": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "gdn_upsample2x_bwd": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _i32, _i32, _P]),
     "gdn_nchw_to_nhwc": (c_int32, [_P, _P, _i32, _i32, _i32, _i32, _i32, _P]),
@@ -115,7 +116,7 @@ _STATUS_FUNCS = {n for n, (r, _) in _SIGS.items() if r is c_int32} - {"gdn_versi
 EXPORTS = tuple(_SIGS)
 # The C ABI revision these signatures (and ConvGeom's layout) describe: gdn_version() of the library must match exactly --
 # a stale build would take the arguments apart differently.
-ABI_VERSION = 219
+ABI_VERSION = 220
 
 
 class _Lib:

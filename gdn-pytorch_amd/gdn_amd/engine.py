@@ -35,6 +35,10 @@ _C1 = os.environ.get("GDN_C1", "1") != "0"
 # x2 bilinear upsampling folded into the consumer convolution's loader and its backward's fold pass (north_star "bilinear-interp
 # ... fused"; csrc/up2x.h): A/B switch
 _FUSE_UP2X = os.environ.get("GDN_FUSE_UP2X", "1") != "0"
+# bf16 form of the same fusion (round 5, row N1): LDS-DMA operands cannot be interpolated on load, so the PRODUCER writes the
+# upsampled tensor -- BatchNorm-apply (+ residual) and the interpolation are one pass (gdn_bn_apply_up2x) -- and the consumer's
+# reflection fold applies the adjoint (gdn_conv_dgrad dx_up2x): no stand-alone upsample2x kernel in either direction
+_FUSE_UP2X_BF16 = os.environ.get("GDN_FUSE_UP2X_BF16", "1") != "0"
 _GRAPH_EPOCH = 0
 
 
@@ -256,6 +260,7 @@ class Ctx:
         self.input_needs_grad = input_needs_grad
         self.reducer = None                    # distributed.GradReducer while a backward is running
         self.bn_src = {}                       # id(activation) -> BnOut of the train-mode BatchNorm that produced it
+        self.up_src = {}                       # id(upsampled tensor) -> (its low-resolution source, up2x mode): conv_bn_act(up_out=)
 
     def grads_done(self, *params):
         """Parameters whose gradient has just been written (lets the all-reduce start early)."""
@@ -503,8 +508,12 @@ def _conv_instnorm_train(ctx, x, conv, inorm, relu, op, w, reflect, need_dx):
     return a
 
 
-def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_dx=True, defer=False):
+def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_dx=True, defer=False, up_out=None):
     """[relu](BN(conv(cat(x, x2)))) (+ residual): ConvBlock / ResidualBlock halves / ConvTBlock.
+
+    up_out (None, or the align_corners flag): the caller also wants F.interpolate(output, scale_factor=2, mode='bilinear') and
+    gets (output, upsampled) back -- on the bf16 path the BatchNorm-apply pass writes both (one kernel), on the fp32 path the
+    upsampled one is the deferred Up2x of upsample().
 
     x may be a BnOut (the deferred activation of the previous layer): the transform-domain paths apply its scale / shift /
     ReLU while loading; any other path materialises it first.  defer=True (the caller guarantees a single consumer)
@@ -535,7 +544,8 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     if bn.training and isinstance(bn, torch.nn.InstanceNorm2d):
         if lazy or up is not None or x2 is not None or residual is not None or ldt != torch.float32:
             raise GdnError("train-mode InstanceNorm is implemented for the standalone fp32 ConvBlock / ConvTBlock only")
-        return _conv_instnorm_train(ctx, x, conv, bn, relu, op, w, reflect, need_dx)
+        a = _conv_instnorm_train(ctx, x, conv, bn, relu, op, w, reflect, need_dx)
+        return a if up_out is None else (a, upsample(ctx, a, bool(up_out)))
     # GDN_HINT_TRAIN: a trained layer in train mode (forward + backward + weight gradient) -- the frequency-domain path then
     # tiles for the sum of both passes (40-point tiles on the 9x9 layers); frozen / eval-mode layers keep the forward-optimal plan
     fft_train = bool(ctx.record and bn.training and conv.weight.requires_grad)
@@ -596,6 +606,7 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
         bn._gdn_stats_ver = getattr(bn, "_gdn_stats_ver", 0) + 1
     else:
         co = _eval_coeffs(bn)
+    a_up = None
     fused = (_FUSE_EVAL_BN and not bn.training and ldt == ctx.dtype and not (relu and residual is not None)
              and (residual is None or residual.dtype == ldt) and conv.out_channels > 1)
     out_info = None
@@ -619,9 +630,19 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                 and ctx.dtype == torch.float32):
             a = out_info                                  # scale / shift / ReLU happen in the consumer's loader
         else:
-            a = ops.bn_apply(y, co[0], co[1], relu, residual, out_dtype=ctx.dtype)
+            if (up_out is not None and _FUSE_UP2X_BF16 and ctx.dtype == torch.bfloat16 and y.is_contiguous()
+                    and (residual is None or residual.is_contiguous()) and y.shape[0] * 2 * y.shape[1] <= 65535):
+                a, a_up = ops.bn_apply_up2x(y, co[0], co[1], relu, residual, align_corners=bool(up_out), out_dtype=ctx.dtype)
+            else:
+                a = ops.bn_apply(y, co[0], co[1], relu, residual, out_dtype=ctx.dtype)
             if out_info is not None and ctx.record and _FUSE_TRAIN_BN:
                 ctx.bn_src[id(a)] = out_info
+    # the layer's input is an upsampled tensor whose producer kept the low-resolution source (up_out above): a reflection-padded
+    # layer's fold pass can write dL/d(source) directly
+    up_in = None
+    if (not isinstance(x, (BnOut, Up2x)) and x2 is None and reflect and not use_fft and conv.in_channels % 4 == 0
+            and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0):
+        up_in = ctx.up_src.get(id(x))
     if ctx.record:
         in_hw = (x.shape[1], x.shape[2])
         bn_training = bn.training
@@ -703,6 +724,10 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                         if slots > 0:
                             part = torch.empty((slots, 2, conv.in_channels), dtype=torch.float32, device=dy.device)
                             bnb = (xin.y, xin.co, xin.relu, part)
+                    if up_in is not None and bnb is None and id(x) not in ctx.grads:
+                        lo, mode = up_in
+                        ctx.grads[id(lo)] = (lo, op.dgrad(dy, wt, in_hw, addsrc=ctx.pop_grad_as(lo, ldt), up2x=mode))
+                        return
                     dx = op.dgrad(dy, wt, in_hw, addsrc=ctx.pop_grad_as(x, ldt), bnb=bnb)
                     ctx.grads[id(x)] = (x, dx)
                     if bnb is not None:
@@ -713,7 +738,21 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                     ctx.add_grad(x, dcat[..., :c1])
                     ctx.add_grad(x2, dcat[..., c1:])
         ctx.tape.append(bwd)
-    return a
+    if up_out is None:
+        return a
+    if a_up is None:
+        return a, upsample(ctx, a, bool(up_out))
+    ctx.claim(a)                         # (as upsample() does: the interpolation is this activation's first consumer)
+    if ctx.record:
+        align = bool(up_out)
+        ctx.up_src[id(a_up)] = (a, 2 if align else 1)
+
+        def up_bwd():                    # (after this tape entry in the forward = before the layer's own backward)
+            dup = ctx.pop_grad(a_up)     # None when the consumer's fold pass already wrote dL/da (the usual case)
+            if dup is not None:
+                ctx.add_grad(a, ops.upsample2x_bwd(_dense(dup), align))
+        ctx.tape.append(up_bwd)
+    return a, a_up
 
 
 def conv_head_tanh(ctx, x, conv):

@@ -248,10 +248,12 @@ class Conv:
         _, ref, _, _ = self.geom(B, H, W)
         return int(lib.gdn_conv_dgrad_bnb_slots(ref, tile_cfg | (CFG_BF16 if dtype == torch.bfloat16 else 0)))
 
-    def dgrad(self, dy, wt_tap, in_hw, addsrc=None, tile_cfg=0, bnb=None):
+    def dgrad(self, dy, wt_tap, in_hw, addsrc=None, tile_cfg=0, bnb=None, up2x=0):
         """dx = dgrad(dy) (+ addsrc).  wt_tap: [k*k, Cin, Cout]; in_hw: layer input (H, W).
         bnb = (y, co, relu, partial): dx is the final gradient of [relu](BN_train(y)); `partial` [dgrad_bnb_slots, 2, Cin]
-        receives that BatchNorm's backward partial sums (as wino_bwd's bnb)."""
+        receives that BatchNorm's backward partial sums (as wino_bwd's bnb).
+        up2x (1: align_corners False, 2: True): the layer's input was the x2 bilinear upsampling of a tensor t; dx (and addsrc)
+        are dL/dt [B, H/2, W/2, Cin] (reflection-padded layers: the fold pass applies the adjoint interpolation)."""
         _chk(dy, "dy", bf16_ok=True)
         _same_dtype(dy, wt_tap, addsrc)
         if dy.dtype == torch.bfloat16:
@@ -261,7 +263,9 @@ class Conv:
         _, ref, Ho, Wo = self.geom(B, H, W)
         if tuple(dy.shape[1:]) != (Ho, Wo, self.cout):
             raise GdnError("dgrad: dy shape %s does not match layer output (%d,%d,%d)" % (tuple(dy.shape), Ho, Wo, self.cout))
-        dx = torch.empty((B, H, W, self.cin), dtype=dy.dtype, device=dy.device)
+        dx = torch.empty((B, H // 2, W // 2, self.cin) if up2x else (B, H, W, self.cin), dtype=dy.dtype, device=dy.device)
+        if up2x and addsrc is not None and tuple(addsrc.shape) != tuple(dx.shape):
+            raise GdnError("dgrad(up2x): addsrc must be the low-resolution gradient %s" % (tuple(dx.shape),))
         nb = int(lib.gdn_conv_dgrad_workspace_bytes(ref, tile_cfg))
         ws = workspace(nb, dy.device, "dgrad") if nb else None
         by, bco, brelu, bpart = bnb if bnb is not None else (None, None, False, None)
@@ -269,7 +273,7 @@ class Conv:
             raise GdnError("dgrad: the BatchNorm input of the fused backward reduction must have the gradient's dtype")
         lib.gdn_conv_dgrad(ref, _p(dy), _ld(dy), _p(wt_tap), _p(dx), _ld(dx), _p(addsrc),
                            0 if addsrc is None else _ld(addsrc), _p(by), 0 if by is None else _ld(by), _p(bco),
-                           1 if brelu else 0, _p(bpart), _p(ws), nb, tile_cfg, stream())
+                           1 if brelu else 0, _p(bpart), int(up2x), _p(ws), nb, tile_cfg, stream())
         return dx
 
     # ---- FFT-domain path (csrc/conv_fft.hip): stride-1 zero-padded fp32 layers with 64..256 channels ----
@@ -677,6 +681,21 @@ def upsample2x(x, align_corners=False):
     y = torch.empty((B, 2 * H, 2 * W, C), dtype=x.dtype, device=x.device)
     lib.gdn_upsample2x_fwd(_p(x), _p(y), B, H, W, C, 1 if align_corners else 0, _mask(x, y), stream())
     return y
+
+
+def bn_apply_up2x(y, scale, shift, relu, residual, align_corners=False, out_dtype=None, need_low=True):
+    """(low, up): low = [relu](y * scale + shift) (+ residual) and up = its x2 bilinear upsampling, one pass (gdn_bn_apply_up2x);
+    low is None when need_low is False."""
+    B, H, W, C = y.shape
+    if not y.is_contiguous() or (residual is not None and not residual.is_contiguous()):
+        raise GdnError("bn_apply_up2x needs dense NHWC tensors")
+    odt = out_dtype or y.dtype
+    low = torch.empty((B, H, W, C), dtype=odt, device=y.device) if need_low else None
+    up = torch.empty((B, 2 * H, 2 * W, C), dtype=odt, device=y.device)
+    dt = _mask(y, residual, up, up)              # (low is stored in up's type, also when it is not written)
+    lib.gdn_bn_apply_up2x(_p(y), _p(scale), _p(shift), _p(residual), _p(low), _p(up), B, H, W, C, 1 if relu else 0,
+                          1 if align_corners else 0, dt, stream())
+    return low, up
 
 
 def upsample2x_bwd(dy, align_corners=False):

@@ -40,7 +40,7 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
-/* Revision of this header (argument lists, struct layouts).  219: gdn_conv_wgrad_bf16 cfg 4 (wgrad_ring_bf16); gdn_fftconv_cgemm* measurement hooks; plan overrides in gdn_conv_geom.hints; gdn_gemm_x3_nt_packed / gdn_gemm_x3_ring_workspace_bytes removed (the measured-and-not-wired kernel now lives under tests/diag/).  218: gdn_gemm_x3_tn_splits.  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+/* Revision of this header (argument lists, struct layouts).  220: gdn_conv_dgrad dx_up2x; gdn_bn_apply_up2x; bf16 tile id 12 (conv_ring2_bf16).  219: gdn_conv_wgrad_bf16 cfg 4 (wgrad_ring_bf16); gdn_fftconv_cgemm* measurement hooks; plan overrides in gdn_conv_geom.hints; gdn_gemm_x3_nt_packed / gdn_gemm_x3_ring_workspace_bytes removed (the measured-and-not-wired kernel now lives under tests/diag/).  218: gdn_gemm_x3_tn_splits.  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
  * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
@@ -150,13 +150,18 @@ size_t gdn_conv_dgrad_workspace_bytes(const gdn_conv_geom* g, int32_t tile_cfg);
  * train-mode BatchNorm (+ReLU) and this call comes from its first consumer -- and bnb_partial [slots][2][Cin] receives that
  * BatchNorm's backward partial sums (sum dz, sum dz * xhat per slot; bnb_co = [scale, shift, mean, invstd][Cin]) computed from
  * the values as they are stored, so gdn_bn_bwd can skip its reduce pass.  slots = gdn_conv_dgrad_bnb_slots(g, tile_cfg);
- * 0 = not available for this layer (today: the bf16 stride-1 layers of the LDS-DMA ring kernel, zero padding). */
+ * 0 = not available for this layer (today: the bf16 stride-1 layers of the LDS-DMA ring kernel, zero padding).
+ * dx_up2x (0 none, 1 align_corners False, 2 True): the layer's input was F.interpolate(t, scale_factor=2, mode='bilinear') and
+ * nothing else reads the upsampled tensor (AE_model_unet.py:336-359: every upconvN); dx and addsrc are then dL/dt,
+ * [B, H/2, W/2, Cin] -- the fold pass of a reflection-padded layer applies the adjoint of the interpolation while it folds, so
+ * the full-resolution gradient is neither written nor read back.  Reflection-padded layers with Cin % 4 == 0 and even H, W
+ * only (GDN_ERR_UNSUPPORTED otherwise); fp32 and bf16. */
 int64_t gdn_conv_dgrad_bnb_slots(const gdn_conv_geom* g, int32_t tile_cfg);
 int gdn_conv_dgrad(const gdn_conv_geom* g, const void* dy, int32_t ldy,
                    const void* wt, void* dx, int32_t ldx,
                    const void* addsrc, int32_t ld_add,
                    const void* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu, float* bnb_partial,
-                   void* workspace, size_t workspace_bytes, int32_t tile_cfg, void* stream);
+                   int32_t dx_up2x, void* workspace, size_t workspace_bytes, int32_t tile_cfg, void* stream);
 
 /* Weight gradient (same call sites).  x is the layer input ([B,H,W], channel
  * slice [0,Cx) of width ldx), dy the output gradient.  Writes
@@ -388,6 +393,14 @@ int gdn_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 int gdn_bn_apply(const void* y, int32_t ldy, const float* scale, const float* shift,
                  const void* residual, int32_t ld_res, void* out, int32_t ld_out,
                  int64_t npix, int32_t C, int32_t relu, int32_t dtypes, void* stream);
+/* low = [relu](y*scale[c] + shift[c]) (+ residual), up = F.interpolate(low, scale_factor=2, mode='bilinear', align_corners) in ONE
+ * pass over dense NHWC tensors [B,H,W,C] -> [B,2H,2W,C]: a ResidualBlock's output followed by the decoder's upsampling
+ * (AE_model_unet.py:55-57 -> :336-359, north_star "bilinear-interp + residual-add fused").  low may be NULL (the block output has
+ * no other reader).  Bit-identical to gdn_bn_apply followed by gdn_upsample2x_fwd: the interpolated values are rounded to low's
+ * storage type first.  dtypes: bit0 y, bit1 residual, bit2 low, bit3 up (1 = bfloat16).  C % 4 == 0, B * 2H <= 65535. */
+int gdn_bn_apply_up2x(const void* y, const float* scale, const float* shift, const void* residual, void* low, void* up,
+                      int32_t B, int32_t H, int32_t W, int32_t C, int32_t relu, int32_t align_corners, int32_t dtypes,
+                      void* stream);
 /* Backward of out = [relu](BN_train(y)):
  *   pass 1 (reduce): per-channel sum(dz), sum(dz*xhat) with dz = dout*[z>0];
  *   pass 2 (apply) : dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)),

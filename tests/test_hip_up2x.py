@@ -171,3 +171,121 @@ def test_rtod_network_fused_equals_standalone_upsample(gpu, monkeypatch):
     d_noise = [max(v) for v in zip(*[sorted(d, reverse=True) for d in d_noise])]
     for k, (a, b) in enumerate(zip(sorted(d_fused, reverse=True), d_noise)):
         assert a <= 5 * b + 2e-5, "%d-th largest gradient distance: fused %.2e vs 1e-6-noise yardstick %.2e" % (k, a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 5 (row N1, bf16 forward half): LDS-DMA operands cannot be interpolated on load, so on the bf16 path the PRODUCER's
+# BatchNorm-apply pass writes the upsampled tensor (gdn_bn_apply_up2x) and the consumer's reflection fold applies the adjoint
+# (gdn_conv_dgrad dx_up2x).
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("align", [False, True], ids=["ac0", "ac1"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_bn_apply_up2x_is_bn_apply_then_upsample(gpu, dtype, align):
+    """One pass == gdn_bn_apply followed by gdn_upsample2x_fwd, BIT FOR BIT (the interpolated neighbours are rounded to the
+    block output's storage type first): every combination of ReLU / residual, with and without the low-resolution output,
+    shapes with a single row / column and channel counts that are not a power of two."""
+    from gdn_amd import ops
+    g = torch.Generator().manual_seed(7)
+    for (B, H, W, C) in [(2, 5, 7, 64), (1, 8, 13, 128), (3, 1, 4, 8), (1, 6, 1, 24), (2, 16, 52, 512)]:
+        y = torch.randn(B, H, W, C, generator=g).to(gpu).to(dtype)
+        res = torch.randn(B, H, W, C, generator=g).to(gpu).to(dtype)
+        sc = (torch.rand(C, generator=g) + 0.5).to(gpu)
+        sh = (torch.randn(C, generator=g) * 0.3).to(gpu)
+        for relu in (False, True):
+            for r in (None, res):
+                low0 = ops.bn_apply(y, sc, sh, relu, r, out_dtype=dtype)
+                up0 = ops.upsample2x(low0, align)
+                low1, up1 = ops.bn_apply_up2x(y, sc, sh, relu, r, align_corners=align, out_dtype=dtype)
+                what = "%s relu=%s res=%s" % ((B, H, W, C), relu, r is not None)
+                assert torch.equal(low0, low1), what + ": low-resolution output differs"
+                assert torch.equal(up0, up1), what + ": upsampled output differs"
+                none, up2 = ops.bn_apply_up2x(y, sc, sh, relu, r, align_corners=align, out_dtype=dtype, need_low=False)
+                assert none is None and torch.equal(up0, up2), what + ": without the low-resolution output"
+    # a bf16 block output from an fp32 raw tensor (mixed storage types take the same path)
+    y = torch.randn(1, 4, 6, 64, generator=g).to(gpu)
+    sc, sh = torch.ones(64, device=gpu), torch.zeros(64, device=gpu)
+    low0 = ops.bn_apply(y, sc, sh, True, None, out_dtype=torch.bfloat16)
+    low1, up1 = ops.bn_apply_up2x(y, sc, sh, True, None, align_corners=align, out_dtype=torch.bfloat16)
+    assert torch.equal(low0, low1) and torch.equal(ops.upsample2x(low0, align), up1)
+
+
+@pytest.mark.parametrize("align", [False, True], ids=["ac0", "ac1"])
+@pytest.mark.parametrize("case", [(128, 64, 7, 2, 12, 20), (256, 128, 5, 1, 16, 26), (512, 256, 3, 1, 8, 14), (64, 64, 9, 1, 16, 32)],
+                         ids=lambda c: "c%d_%d_k%d" % c[:3])
+def test_dgrad_fold_applies_upsample_adjoint(gpu, case, align):
+    """gdn_conv_dgrad(dx_up2x) of a reflection-padded layer == data gradient, fold, gdn_upsample2x_bwd, + addsrc.  fp32: against
+    torch autograd through interpolate -> ReflectionPad2d -> conv2d on the CPU (1e-3 relative) and against the two-pass HIP
+    form to rounding; bf16 (the direct / ring kernels' storage type): against the two-pass form, whose two extra roundings
+    (full-resolution gradient, low-resolution gradient before the add) bound the difference: 2^-6 of the largest value."""
+    from gdn_amd import ops
+    ci, co, k, B, H, W = case                    # H, W: the UPSAMPLED extent = the layer's input
+    g = torch.Generator().manual_seed(11 + k)
+    xl = torch.randn(B, ci, H // 2, W // 2, generator=g).requires_grad_(True)
+    w = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    gy = torch.randn(B, co, H, W, generator=g)
+    add = torch.randn(B, H // 2, W // 2, ci, generator=g)
+    _ref(xl, w, k, True, align).backward(gy)
+    ref = xl.grad + nchw(add)
+    op = ops.Conv(ci, co, k, 1, k // 2, reflect=True)
+    mode = 2 if align else 1
+    for dt in (torch.float32, torch.bfloat16):
+        gyd = nhwc(gy).to(gpu).to(dt)
+        wt = ops.transpose_taps(tapmajor(w, False).to(gpu)).to(dt)
+        addd = add.to(gpu).to(dt)
+        fused = op.dgrad(gyd, wt, (H, W), addsrc=addd, up2x=mode)
+        assert tuple(fused.shape) == (B, H // 2, W // 2, ci) and fused.dtype == dt
+        two = ops.add(ops.upsample2x_bwd(op.dgrad(gyd, wt, (H, W)), align), addd)
+        if dt == torch.float32:
+            close(nchw(fused), ref, what="fp32 fold + adjoint vs torch")
+            close(fused, two, rtol=1e-5, atol_scale=1e-6, what="fp32 fold + adjoint vs two passes")
+        else:
+            assert (fused.float() - two.float()).abs().max() <= 2 ** -6 * two.float().abs().max()
+            close(nchw(fused.float()), ref, rtol=2e-2, atol_scale=2e-2, what="bf16 fold + adjoint vs torch")
+        none = op.dgrad(gyd, wt, (H, W), up2x=mode)                  # without addsrc
+        two0 = ops.upsample2x_bwd(op.dgrad(gyd, wt, (H, W)), align)
+        assert (none.float() - two0.float()).abs().max() <= (2 ** -6 if dt == torch.bfloat16 else 1e-5) * two0.float().abs().max()
+
+
+def test_dgrad_up2x_argument_checks(gpu):
+    from gdn_amd import ops
+    from gdn_amd._lib import GdnError
+    wt = torch.randn(49, 64, 64, device=gpu)
+    with pytest.raises(GdnError):            # the adjoint rides the fold pass of a reflection layer only
+        ops.Conv(64, 64, 7, 1, 3).dgrad(torch.randn(1, 16, 16, 64, device=gpu), wt, (16, 16), up2x=1)
+    with pytest.raises(GdnError):            # odd extent: not the output of a x2 upsampling
+        ops.Conv(64, 64, 7, 1, 3, reflect=True).dgrad(torch.randn(1, 15, 16, 64, device=gpu), wt, (15, 16), up2x=1)
+    with pytest.raises(GdnError):            # addsrc must be the low-resolution gradient
+        ops.Conv(64, 64, 7, 1, 3, reflect=True).dgrad(torch.randn(1, 16, 16, 64, device=gpu), wt, (16, 16),
+                                                      addsrc=torch.randn(1, 16, 16, 64, device=gpu), up2x=1)
+
+
+def test_rtod_bf16_network_runs_no_standalone_upsample(gpu, monkeypatch):
+    """R in bf16, forward + backward: with the fusion on neither upsample2x nor its adjoint is launched as a kernel of its own
+    (4 + 4 calls with it off); the forward is bit-identical (same arithmetic, same rounding points), the parameter gradients
+    differ by the two bf16 roundings per decoder stage the fused backward no longer makes."""
+    import gdn_amd.engine as E
+    import gdn_amd.AE_model_unet as M
+    from gdn_amd import ops
+    calls = {"fwd": 0, "bwd": 0}
+    real_f, real_b = ops.upsample2x, ops.upsample2x_bwd
+    monkeypatch.setattr(ops, "upsample2x", lambda x, a=False: (calls.__setitem__("fwd", calls["fwd"] + 1), real_f(x, a))[1])
+    monkeypatch.setattr(ops, "upsample2x_bwd", lambda x, a=False: (calls.__setitem__("bwd", calls["bwd"] + 1), real_b(x, a))[1])
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(3)).to(gpu)
+
+    def run(fused):
+        monkeypatch.setattr(E, "_FUSE_UP2X_BF16", fused)
+        calls["fwd"] = calls["bwd"] = 0
+        torch.manual_seed(0)
+        net = M.AutoEncoder_2(height=64, width=96).to(gpu).train().compute_dtype("bf16")
+        feats = net(x, istrain=True)
+        (feats[-1].square().mean() + 1e-3 * feats[2].float().square().mean()).backward()
+        assert (calls["fwd"], calls["bwd"]) == ((0, 0) if fused else (4, 4))
+        r = {n: p.grad.detach().double().clone() for n, p in net.named_parameters() if p.grad is not None}
+        return r, [f.detach().clone() for f in feats]
+    (g_ref, f_ref), (g_fused, f_fused) = run(False), run(True)
+    for i, (a, b) in enumerate(zip(f_fused, f_ref)):
+        assert torch.equal(a, b), "feature %d: the fused forward is not bit-identical" % i
+    assert g_ref.keys() == g_fused.keys() and len(g_ref) > 100
+    typical = sorted(float(v.norm()) for v in g_ref.values())[len(g_ref) // 2]
+    d = sorted(float((g_fused[n] - b).norm()) / (float(b.norm()) + 5e-2 * typical) for n, b in g_ref.items())
+    assert d[len(d) // 2] <= 5e-2 and d[-1] <= 0.5, "gradient distance fused vs stand-alone: median %.3f max %.3f" % (d[len(d) // 2], d[-1])

@@ -32,7 +32,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(files[-1])):
-        if "conv_ring_bf16" not in r["Kernel_Name"]:
+        if "conv_ring2_bf16" not in r["Kernel_Name"]:
             continue
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         if c == "SQ" and r["Counter_Name"] == "SQ_WAVES":
@@ -40,7 +40,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2"):
     for cn, v in agg.items():
         res[cn] = sum(v) / len(v)
 fe, wr = res.get("FETCH_SIZE", 0), res.get("WRITE_SIZE", 0)
-row = {"kernel": "conv_ring_bf16<64, 9, 0>  9x9 s1 64->64 + BN-stats, B=20 128x416, bf16", "FETCH_SIZE_KB": round(fe, 1), "WRITE_SIZE_KB": round(wr, 1),
+row = {"kernel": "conv_ring2_bf16<64, 9, 0>  9x9 s1 64->64 + BN-stats, B=20 128x416, bf16", "FETCH_SIZE_KB": round(fe, 1), "WRITE_SIZE_KB": round(wr, 1),
        "traffic_bytes_per_launch": int((2 * fe + wr) * 1024),
        "algorithmic_bytes_per_launch": 20 * 128 * 416 * 64 * 2 * 2 + 81 * 64 * 64 * 2,
        "mean_duration_us_profiled": round(sum(dur) / max(len(dur), 1), 1)}

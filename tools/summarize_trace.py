@@ -27,7 +27,7 @@ for (name, grid), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
 # ---- persistent kernels: their grid is the CU count whatever the layer, so (kernel, grid) averages every
 # layer and batch size that runs on one symbol.  A training step launches its kernels in a fixed order: the i-th launch of a
 # symbol between two adam kernels is the same layer call in every step.  Per (symbol, ordinal): mean / min / max over the steps.
-PERSISTENT = re.compile(r"conv_ring_bf16|wgrad_ring_bf16|cgemm_bins_kernel")
+PERSISTENT = re.compile(r"conv_ring2?_bf16|wgrad_ring_bf16|cgemm_bins_kernel")
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 steps, cur = [], []
 for r in rows:

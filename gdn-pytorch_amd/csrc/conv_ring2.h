@@ -1,19 +1,26 @@
-// conv_ring2_bf16: conv_ring_bf16 (conv_ring.h) with every weight tile shared by TWICE the pixels (round 5).
+// conv_ring2_bf16: the LDS-DMA ring kernel (conv_ring.h) with ONE barrier per (filter row, slab) stage (round 5).
 // (included by conv_igemm.hip after conv_ring.h)
 //
-// conv_ring_bf16 is LDS-DMA-bound: per (filter row, 64-channel slab) stage it brings 40 KB of patch and 72 KB of weight tiles
-// (9x9) into the CU for 2.4 us of MFMA work, 46 GB/s against the ~25 GB/s a CU's DMA sustains; round 4's probe shows it
-// (dropping EITHER operand's traffic gives the whole 20 %).  The weight bytes per MFMA halve if a workgroup's tile is 512
-// instead of 256 pixels -- but two 80 KB double-buffered patches do not fit LDS beside the weight ring.  Hence:
-//   * a stage is (filter row, 32-CHANNEL slab): LDS rows are 64 bytes, the patch of 512 pixels with its halos is 40 KB again
-//     (640 positions), double-buffered; weight tiles are BN x 32 channels = 4 / 8 KB, ring of 8 slots;
-//   * the 8 waves are 8 pixel groups of 64 (no split of the reduction between waves, no exchange in the epilogue): every wave
-//     reads all BN columns of the weight tile -- 8 (BN = 64) or 16 (BN = 128) MFMAs per tap step and wave;
+// conv_ring_bf16 synchronises its eight waves at every tap step -- 8 MFMAs per wave between two raw barriers, with two waves
+// per SIMD and nobody else on the CU: 45-55 % of the matrix pipe's cycles inside the tap loop go to barrier skew and counted
+// vmcnt waits (r04b_ring_probe.txt; NOT to LDS-DMA bytes: a third less traffic bought 3 %).  wgrad_ring_bf16 (wgrad_ring.h),
+// which synchronises once per stage, keeps the pipe 67 % busy.  This kernel gives the forward / data-gradient the same shape:
+//   * a stage is (filter row, 32-CHANNEL slab): LDS rows are 64 bytes; the patch of a 512-pixel tile with its halos is 40 KB
+//     (640 positions) and the KW weight tiles of the stage are KW x 4 KB (BN = 64) -- small enough to hold TWO whole stages
+//     (patch + every weight tile: 2 x 76 KB for a 9-tap row) in LDS.  While stage s computes, every wave fires its ten pieces
+//     of stage s + 1 into the other pair, one or two per tap step under the MFMAs; the boundary (vmcnt(0) lgkmcnt(0), barrier)
+//     sits inside the last k-substep in front of its MFMAs, and the first fragment reads of the next stage land under them.
+//     72 MFMAs per wave run between two barriers.
+//   * 512-pixel tiles: the 8 waves are 8 pixel groups of 64 (no split of the reduction between waves, no exchange in the
+//     epilogue), every weight tile serves twice the pixels of conv_ring_bf16's, and the ~7 us a tile spends outside its tap loop
+//     are paid half as often;
 //   * 64-byte rows: the four 16-byte chunks of a row are XOR-permuted by (row >> 2) & 3, so the 16 rows a ds_read_b128 lane
-//     group touches -- any 16 of 28 consecutive ones, or the hardware's {0-3, 12-15, 20-27} groups -- fall on 16 different
-//     16-byte bank slots; an LDS-DMA piece is 16 rows; the permutation is applied to the per-lane SOURCE address and on the read;
-//   * everything else -- persistent workgroups, tables, one barrier per tap step with counted vmcnt, the next tile's prologue
-//     before the epilogue, the K-split tail, the epilogue fusions -- is conv_ring_bf16's.
+//     group touches fall on 16 different 16-byte bank slots; an LDS-DMA piece is 16 rows; the permutation is applied to the
+//     per-lane SOURCE address and on the read;
+//   * everything else -- persistent workgroups, tables, the next tile's prologue before the epilogue, the K-split tail, the
+//     epilogue fusions -- is conv_ring_bf16's.
+// One-stage-ahead prefetch needs a stage longer than the DMA latency: 9 / 7-tap rows (2.2 / 1.7 us of MFMA work per stage); the
+// 5- and 3-tap layers stay on conv_ring_bf16's four-step-ahead ring.  B = 20, 9x9 64 -> 64: 1249 vs 1155 TFLOP/s.
 #pragma once
 
 #define RG2_BM 512
@@ -27,27 +34,24 @@ template <int BN, int KW, int DPO = 0, bool BNB = false>
 __global__ __launch_bounds__(512, 2) void conv_ring2_bf16(const IgemmParams p) {
 #if RG_DEVICE_BODY
     constexpr int BM = RG2_BM;
-    constexpr int NSLOT = 8, TILE_B = BN * 64;               // weight tile: BN rows of 32 channels
-    constexpr int DPA = NSLOT - 2 < KW - 1 ? NSLOT - 2 : KW - 1;
-    constexpr int DPD = DPA < 4 ? DPA : 4;
-    constexpr int DP = DPO ? (DPO < DPA ? DPO : DPA) : DPD;  // prefetch distance in tap steps (>= 1); DPO: measurement override
-    constexpr int BV = 1;                                    // B pieces per wave and step (BN = 64: waves 4 .. 7 load into a dummy KB,
-                                                             // so that every wave counts the same loads)
+    constexpr int TILE_B = BN * 64;                          // weight tile: BN rows of 32 channels
+    constexpr int PT = BN / 16;                              // LDS-DMA pieces per weight tile (16 rows x 64 bytes each)
+    constexpr int NBW = (KW * PT + 7) / 8;                   // weight pieces per wave and stage (all KW tiles of the stage)
     constexpr int NG = 2;                                    // 16-channel k-substeps per step
     constexpr int NJ = BN / 32;                              // column tiles per wave
-    using S = RingSched<KW, DP>;
-    static_assert(DP >= 1 && S::last >= 0, "schedule");
-    // LDS map: [A buffer 0 | weight ring | A buffer 1 | two table sets].  The next tile's prologue lands in A buffer 0 and ring
-    // slots 0 .. DP; what is behind them (64 KB: the last ring slots and A buffer 1) is the epilogue's scratch meanwhile.
-    constexpr int A0 = 0, B0 = RG2_ABYTES, A1 = B0 + NSLOT * TILE_B, TAB0 = A1 + RG2_ABYTES;
-    constexpr int SC0 = B0 + (DP + 1) * TILE_B;              // epilogue scratch: [SC0, TAB0)
+    static_assert(PT == 4 || PT == 8, "a wave's pieces all cover the same rows of their tiles");
+    // LDS map: [A buffer 0 | weight set 0 | A buffer 1 | weight set 1 | two table sets | coefficients].  A stage reads one
+    // (A buffer, weight set) pair while the LDS-DMA of the next stage fills the other.  The next tile's prologue lands in pair
+    // 0; pair 1 is the epilogue's scratch meanwhile.
+    constexpr int A0 = 0, B0 = RG2_ABYTES, A1 = B0 + KW * TILE_B, B1 = A1 + RG2_ABYTES, TAB0 = B1 + KW * TILE_B;
+    constexpr int SC0 = A1;                                  // epilogue scratch: [SC0, TAB0)
     constexpr int TABN = BM + RG_KMAX * RG2_NRMAX + RG2_NRMAX + 1 + RG2_NRMAX + 3;     // ints per table set (648)
-    constexpr int TABSET = 2624;
-    static_assert(TAB0 - SC0 >= 35 * 1024 && TABN * 4 <= TABSET, "LDS map");
+    constexpr int TABSET = TABN * 4;
+    static_assert(TAB0 - SC0 >= 35 * 1024, "LDS map");
     // ONE shared object: the compiler must see a single LDS array beside the LDS-DMA instructions
     constexpr int COEF0 = TAB0 + 2 * TABSET + 64;            // [4][BN] floats: the BatchNorm coefficients of a data gradient's bnb mode
-    constexpr int DUMMY0 = COEF0 + 4 * 128 * 4;              // 1 KB nobody reads
-    __shared__ __attribute__((aligned(16))) unsigned char sm[DUMMY0 + 1024];
+    static_assert(COEF0 + 4 * 128 * 4 <= 160 * 1024, "LDS size");
+    __shared__ __attribute__((aligned(16))) unsigned char sm[COEF0 + 4 * 128 * 4];
     int* const wirow = reinterpret_cast<int*>(sm + TAB0 + 2 * TABSET);    // [RG_KMAX] weight index of the first tap of each filter row
     auto tab = [&](int b) { return reinterpret_cast<int*>(sm + TAB0 + b * TABSET); };
     // a table set: row_out[512] output pixel index or -1 | rowoff[RG_KMAX][RG2_NRMAX] byte offset of input row or -1 |
@@ -144,10 +148,10 @@ __global__ __launch_bounds__(512, 2) void conv_ring2_bf16(const IgemmParams p) {
 
     // ---- per-tile state ----
     const unsigned OOB = 0xFFFFFF00u;
-    constexpr int NA = RG_AV, NB = BV;
+    constexpr int NA = RG_AV, NB = 1;
     unsigned pk[NA];             // patch piece e of this wave = piece e * 8 + wave of the stage's 40 (16 positions x 4 chunks): per-lane
                                  // column offset, with the image-row index j of the position in its low 4 bits (the offset is a multiple of 16)
-    unsigned boff[NB];           // weight-tile piece of this wave = rows [16 wave, 16 wave + 16) of the tile (16 rows x 4 chunks)
+    unsigned boff[NB];           // this wave's weight pieces are rows [16 (wave % PT), + 16) of their tiles (16 rows x 4 chunks)
     unsigned a_vo[NA];           // per-lane source offsets of the patch pieces of one stage
     __amdgpu_buffer_rsrc_t rs_x;
     // (p.kc carries measurement knobs for this kernel: bit 1 / bit 2 give the weight / activation descriptor zero records, so
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void conv_ring2_bf16(const IgemmParams p) {
         }
 #pragma unroll
         for (int e = 0; e < NB; ++e) {
-            const int n = wave * 16 + (lane >> 2);
+            const int n = (wave & (PT - 1)) * 16 + (lane >> 2);
             const unsigned lc = (unsigned)((lane & 3) ^ ((n >> 2) & 3));
             boff[e] = (n < BN && (n0 + n) < p.N) ? (unsigned)((n0 + n) * p.Cred) * 2u + lc * 16u : OOB;
         }
@@ -197,20 +201,22 @@ __global__ __launch_bounds__(512, 2) void conv_ring2_bf16(const IgemmParams p) {
     auto dma_a = [&](int par, int cc, int e) {               // piece e of the patch whose offsets are in a_vo -> A buffer `par`
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (rg_lds_ptr)(sm + (par ? A1 : A0) + (e * 8 + wave) * 1024), 16, a_vo[e], cc * 64, 0, 0);
     };
-    auto dma_b = [&](int v, int soff) {                      // this wave's pieces of the weight tile at scalar offset soff -> ring slot v % NSLOT
-        const int slot = v & (NSLOT - 1);
-        const int dst = (BN == 64 && wave >= 4) ? DUMMY0 : B0 + slot * TILE_B + wave * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (rg_lds_ptr)(sm + dst), 16, boff[0], soff, 0, 0);
+    // piece e of this wave of the KW weight tiles of the stage whose first tap lies at scalar offset soff -> weight set `par`:
+    // piece e * 8 + wave of the KW * PT (tile kx = piece / PT at soff + kx * tap2).  A piece past the last one re-loads the wave's
+    // previous piece (same bytes to the same place), so that every wave issues the same number of loads.
+    auto dma_bw = [&](int par, int soff, int e) {
+        int pi = e * 8 + wave;
+        if (pi >= KW * PT) pi -= 8;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (rg_lds_ptr)(sm + (par ? B1 : B0) + pi * 1024), 16, boff[0],
+                                                 soff + (pi / PT) * tap2, 0, 0);
     };
-    // The weight tile of tap step v = stage * KW + kx lies at scalar offset soff(stage) + kx * tap2: with KW unrolled, the
-    // tile that step (stage, kx) prefetches -- step v + 1 + DP -- is tap (kx + 1 + DP) % KW of this stage or of the next one
-    // (DP < KW), so two scalars per stage replace all per-step bookkeeping.  Past the last step the "next" stage is the last
-    // stage again: harmless reloads into free slots keep the number of loads per step -- what the counted waits rely on -- fixed.
+    // The weights of tap kx of a stage lie at stage_soff + kx * tap2; past the last stage the "next" stage is the last stage
+    // again: harmless reloads into the idle pair keep the instruction stream uniform.
     auto stage_soff = [&](int ky_, int cc_) { return __builtin_amdgcn_readfirstlane(wirow[ky_]) * tap2 + cc_ * 64; };
     int ky_n = 0, cc_n = 0, soff_c = 0, soff_n = 0;
     // (measured and not kept: every workgroup starting at another filter row, so that the workgroups of an XCD read different
     //  weight tiles at any moment: 1049 vs 1100 TFLOP/s -- sharing the lines helps)
-    auto issue_prologue = [&](int b, int s0, int ns) {       // first stage's patch and the weight tiles of steps 0 .. DP of the item in table set b
+    auto issue_prologue = [&](int b, int s0, int ns) {       // first stage's patch and weight tiles of the item in table set b -> pair 0
         const int ky0 = s0 / nchunks, cc0 = s0 - ky0 * nchunks;
         ky_n = ky0; cc_n = cc0;
         if (ns > 1) { if (++cc_n == nchunks) { cc_n = 0; ++ky_n; } }
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void conv_ring2_bf16(const IgemmParams p) {
 #pragma unroll
         for (int e = 0; e < NA; ++e) dma_a(0, cc0, e);
 #pragma unroll
-        for (int v = 0; v <= DP; ++v) dma_b(v, (v < KW ? soff_c : soff_n) + (v % KW) * tap2);
+        for (int e = 0; e < NBW; ++e) dma_bw(0, soff_c, e);
     };
 
     // ---- fragment addressing ----
@@ -234,10 +240,10 @@ __global__ __launch_bounds__(512, 2) void conv_ring2_bf16(const IgemmParams p) {
     unsigned apos[2];                                // A: pixel r of the tile sits at patch position r + j(r) * (KW - 1) (+ the tap's shift)
     f32x16 acc[2][NJ];
     bf16x8 fa[2][2], fb[2][NJ];                      // [register set][row tile / column tile]
-    auto load_frags = [&](int set, int par, int kx, int slot, int g) {     // fragments of (A buffer par, tap kx, ring slot, k-substep g)
+    auto load_frags = [&](int set, int par, int kx, int g) {     // fragments of (pair par, tap kx, k-substep g)
         const unsigned sh = (unsigned)(dx_up ? kx : KW - 1 - kx);
         const unsigned abase = (unsigned)(par ? A1 : A0);
-        const unsigned bbase = (unsigned)(B0 + slot * TILE_B);
+        const unsigned bbase = (unsigned)((par ? B1 : B0) + kx * TILE_B);
         const unsigned gx = (unsigned)g << 5;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -288,59 +294,59 @@ __global__ __launch_bounds__(512, 2) void conv_ring2_bf16(const IgemmParams p) {
         if (has_next) setup_tables(tb ^ 1, mt_n * BM);              // (the other set: ordered by the loop's barriers before anyone reads it)
         rg_wait_vm<0>();                                            // the prologue pieces (and the previous epilogue's stores)
         __builtin_amdgcn_s_barrier();
-        if (ns > 0) load_frags(0, 0, 0, 0, 0);
+        if (ns > 0) load_frags(0, 0, 0, 0);
 
-        for (int stage = 0; stage < ns; ++stage) {         // (stage: local index -- buffer parity and ring slots start at 0 for every item)
+        // ---- stage walk: ONE barrier per stage.  During stage s every wave fires its pieces of stage s + 1 (patch and all KW
+        // weight tiles) into the other pair, one or two per tap step under the MFMAs; the boundary -- vmcnt(0) lgkmcnt(0), barrier --
+        // sits inside the last k-substep, in front of its MFMAs, whose operands are in registers by then: behind the barrier the
+        // first fragments of the next stage are requested and land under those MFMAs.  Between two boundaries a wave runs
+        // 2 KW NJ MFMAs (72 for a 9-tap row) with no synchronisation at all.
+        for (int stage = 0; stage < ns; ++stage) {         // (stage: local index -- the pair parity starts at 0 for every item)
             const int par = stage & 1;
-            const int ubase = stage * KW;
-            a_offsets(tb, ky_n);                               // (ky_n, cc_n): the NEXT stage; the last stage reloads itself into the idle buffer
+            a_offsets(tb, ky_n);                               // (ky_n, cc_n): the NEXT stage; the last stage reloads itself into the idle pair
+            const bool more = stage + 1 < ns;
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx) {
-                // pieces issued DP or more steps ago have landed (this thread's); the barrier makes everyone's visible and says
-                // that every wave has finished the LDS reads of step u-1
-                switch (kx) {
-                    case 0: rg_wait_vm<S::wait_n(0, BV)>(); break;
-                    case 1: rg_wait_vm<S::wait_n(1, BV)>(); break;
-                    case 2: rg_wait_vm<S::wait_n(2, BV)>(); break;
-                    case 3: rg_wait_vm<S::wait_n(3 % KW, BV)>(); break;
-                    case 4: rg_wait_vm<S::wait_n(4 % KW, BV)>(); break;
-                    case 5: rg_wait_vm<S::wait_n(5 % KW, BV)>(); break;
-                    case 6: rg_wait_vm<S::wait_n(6 % KW, BV)>(); break;
-                    case 7: rg_wait_vm<S::wait_n(7 % KW, BV)>(); break;
-                    default: rg_wait_vm<S::wait_n(8 % KW, BV)>(); break;
-                }
-                __builtin_amdgcn_s_barrier();
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const int cur = g & 1;
-                    // read-ahead: the next k-substep's fragments -- of the NEXT step under this step's last MFMAs
-                    if (g + 1 < NG) load_frags(cur ^ 1, par, kx, (ubase + kx) & (NSLOT - 1), g + 1);
-                    else if (stage + 1 < ns || kx + 1 < KW)
-                        load_frags(cur ^ 1, kx + 1 < KW ? par : par ^ 1, kx + 1 < KW ? kx + 1 : 0, (ubase + kx + 1) & (NSLOT - 1), 0);
-                    // (measured and not kept: the same operands through v_mfma_f32_16x16x32_bf16 -- 1080 vs 1092-1098 TFLOP/s)
+                    if (g + 1 < NG) load_frags(cur ^ 1, par, kx, g + 1);
+                    else if (kx + 1 < KW) load_frags(cur ^ 1, par, kx + 1, 0);
+                    else {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) {
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next stage has landed; this wave's reads of this one too
+                            __builtin_amdgcn_s_barrier();                              // ... everyone's
+                            load_frags(cur ^ 1, par ^ 1, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < NJ; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
                     if (g == 0) {
-                        // this step's LDS-DMA issue sits UNDER the MFMAs (whose operands the read-ahead already delivered):
-                        // straight after the barrier the matrix pipe would idle while every wave issues its pieces
-                        const int vb = kx + 1 + DP;                // compile-time after unrolling
-                        dma_b(ubase + vb, (vb < KW ? soff_c : soff_n) + (vb % KW) * tap2);
+                        // this step's share of the next stage's LDS-DMA, under the MFMAs: patch piece e at step e (KW - 1) / NA,
+                        // weight piece e at step e (KW - 1) / NBW -- nothing in the last step, whose boundary waits for them
 #pragma unroll
                         for (int e = 0; e < NA; ++e)
-                            if (e >= S::a_first(kx) && e < S::a_first(kx) + S::a_cnt(kx)) dma_a(par ^ 1, cc_n, e);
+                            if (e * (KW - 1) / NA == kx) dma_a(par ^ 1, cc_n, e);
+#pragma unroll
+                        for (int e = 0; e < NBW; ++e)
+                            if (e * (KW - 1) / NBW == kx) dma_bw(par ^ 1, soff_n, e);
                     }
                     // (conv_ring_bf16's schedule: one MFMA, one fragment read of the NEXT k-substep, a couple of vector / scalar
                     //  instructions and at most one LDS-DMA per group)
+                    if (g + 1 < NG || kx + 1 < KW) {
 #pragma unroll
-                    for (int i = 0; i < 2 * NJ; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        for (int i = 0; i < 2 * NJ; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }

@@ -315,9 +315,10 @@ def ring_roofline(dev, B, reps=20):
     # interleaved rounds in one process, best of three each: the clock the chip holds depends on what ran just before
     # (cdna_hip_programming.md rule 24), so a single A-then-B pass ranks whichever ran second higher
     ms_f = ms_d = ms_old = ms_r4 = 1e9
-    st10 = op.fwd(x, w, stats=True, tile_cfg=10)[1]
+    st10 = op.fwd(x, w, stats=True, tile_cfg=10)[1]            # (one partial-statistics slot per tile: the count follows the tile)
+    st9 = op.fwd(x, w, stats=True, tile_cfg=9)[1]
     for _ in range(3):
-        ms_old = min(ms_old, timed(lambda: op.fwd(x, w, stats=True, out=y, stats_out=st, tile_cfg=9)))
+        ms_old = min(ms_old, timed(lambda: op.fwd(x, w, stats=True, out=y, stats_out=st9, tile_cfg=9)))
         ms_r4 = min(ms_r4, timed(lambda: op.fwd(x, w, stats=True, out=y, stats_out=st10, tile_cfg=10)))
         ms_f = min(ms_f, timed(lambda: op.fwd(x, w, stats=True, out=y, stats_out=st)))
         ms_d = min(ms_d, timed(lambda: op.dgrad(x, wt, (H, W), addsrc=add)))

@@ -176,6 +176,7 @@ class Conv:
         self.reflect, self.transposed = bool(reflect and pad > 0), transposed
         self._geom = {}
         self._fwd_ws = {}
+        self._slots = {}
 
     def geom(self, B, H, W, hints=0, x3=None, f4=None):
         """x3 / f4: None = the current switch; a saved state's backward passes what its forward used."""
@@ -224,9 +225,18 @@ class Conv:
         st = None
         if stats:
             st = stats_out
-            if st is None:
+            slots = self._slots.get((B, H, W, tile_cfg))
+            if slots is None:
                 slots = int(lib.gdn_conv_stats_slots(ref, tile_cfg))
+                self._slots[(B, H, W, tile_cfg)] = slots
+            if st is None:
                 st = torch.empty((slots, 2, self.cout), dtype=torch.float32, device=x.device)
+            elif (st.dtype != torch.float32 or not st.is_contiguous() or st.dim() != 3 or st.shape[0] != slots
+                  or tuple(st.shape[1:]) != (2, self.cout)):
+                # the kernel writes one slot per tile of the configuration it picks: a buffer sized for another tile_cfg is
+                # overrun (or leaves slots unwritten that the finalize pass then sums)
+                raise GdnError("conv fwd: stats_out must be a dense float32 [%d, 2, %d] for this geometry and tile_cfg, got %s"
+                               % (slots, self.cout, tuple(st.shape)))
         nb = self._fwd_ws.get((B, H, W, tile_cfg))
         if nb is None:
             nb = int(lib.gdn_conv_fwd_workspace_bytes(ref, tile_cfg))

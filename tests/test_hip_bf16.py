@@ -197,6 +197,18 @@ def test_conv_bf16_rejects_unsupported(gpu):
     op = ops.Conv(64, 64, 3, 1, 1)
     with pytest.raises(GdnError):      # mixed dtypes
         op.fwd(torch.zeros(1, 8, 8, 64, device=gpu).bfloat16(), torch.zeros(9, 64, 64, device=gpu))
+    # a caller-owned partial-statistics buffer must have the slot count of the tile configuration that runs (one slot per tile:
+    # 512-pixel tiles of tile id 12 write half as many as the 256-pixel ones -- a wrong size is refused, not overrun)
+    op = ops.Conv(64, 64, 9, 1, 4)
+    x, w = torch.zeros(2, 32, 64, 64, device=gpu).bfloat16(), torch.zeros(81, 64, 64, device=gpu).bfloat16()
+    st12 = op.fwd(x, w, stats=True, tile_cfg=12)[1]
+    st10 = op.fwd(x, w, stats=True, tile_cfg=10)[1]
+    assert st10.shape[0] == 2 * st12.shape[0]
+    with pytest.raises(GdnError):
+        op.fwd(x, w, stats=True, stats_out=st12, tile_cfg=10)
+    with pytest.raises(GdnError):
+        op.fwd(x, w, stats=True, stats_out=st10, tile_cfg=12)
+    op.fwd(x, w, stats=True, stats_out=st10, tile_cfg=10)
 
 
 # ----------------------------------------------------------------------------------------------

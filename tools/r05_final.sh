@@ -1,7 +1,8 @@
 #!/bin/bash
 # GPU box: the round's final records (profiles/r05f_*): whole-step MFMA utilisation, step traces of three configurations with the
 # no-MFMA16-beside-FFT check, smoke, default bench line.   usage: GDN_COMMIT=<hash> bash tools/r05_final.sh
-cd /root/repo
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd $R
 bash tools/pmc_step.sh > gpurun_out/pmc_step.log 2>&1
 bash tools/prof_step.sh r05f_dtod_fp32 > /dev/null 2>&1
 bash tools/prof_step.sh r05f_rtod_bf16 --mode RtoD --dtype bf16 > /dev/null 2>&1

@@ -393,8 +393,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) { return f32_to_bf16_h(f); }
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
+// (four waves per SIMD: the 128 x 128 form then fits 128 registers without a spill instead of 88 + 64 accumulation registers at
+//  three waves -- this single-image, two-barrier pipeline lives on occupancy: +2 % over the strided / transposed / 1x1 layers,
+//  while a second LDS image at half the workgroups per CU cost 20 %, profiles/README.md)
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_igemm_bf16(const IgemmParams p) {
+__global__ __launch_bounds__(256, 4) void conv_igemm_bf16(const IgemmParams p) {
     constexpr int KC = 64, LDS_LD = 36, RPP = 32;        // 64 bf16 = 128 B per row, 144-B pitch
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");

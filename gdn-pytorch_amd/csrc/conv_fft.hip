@@ -1002,8 +1002,14 @@ bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
 }
 
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
-// persistent grid of cgemm_bins_kernel: four workgroups per CU (a multiple of 8: a workgroup stays on one XCD's bins)
-inline int cgemm_grid(int nunits) { const int g = 4 * gdn_num_cus(); return nunits < g ? (nunits + 7) / 8 * 8 : g; }
+// persistent grid of cgemm_bins_kernel: four workgroups per CU, ROUNDED DOWN to a multiple of 8 (at least 8) -- the kernel's
+// mixed-radix walk takes its stride digits from gridDim.x >> 3 (a workgroup stays on one XCD's bins), so a grid that is not a
+// multiple of 8 (a part with an odd CU count) would skip or repeat units
+inline int cgemm_grid(int nunits) {
+    int g = 4 * gdn_num_cus() / 8 * 8;
+    if (g < 8) g = 8;
+    return nunits < g ? (nunits + 7) / 8 * 8 : g;
+}
 
 // splits of the weight-gradient reduction: enough workgroups for ~4 per CU, chunks of at least 64 tiles
 inline int tn_splits(const FftGeom& f) {

@@ -893,7 +893,49 @@ extern "C" int gdn_adam_step_dev(float* p, const float* g, float* m, float* v, i
     return gdn_launch_status();
 }
 
-extern "C" int gdn_version(void) { return 220; }
+// ---- shader-clock probe (measurement aid; include/gdn_hip.h) -----------------------------------------------------------------
+// One wave: reads the shader cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime), sleeps until the flag
+// word is set by clock_probe_set_kernel on the measured stream (or max_ticks have passed), reads both again.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ buf, unsigned long long max_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1 = r0;
+    while (__hip_atomic_load(buf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull && r1 - r0 < max_ticks) {
+        __builtin_amdgcn_s_sleep(64);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    buf[1] = c1 - c0;
+    buf[2] = r1 - r0;
+    buf[3] = __hip_atomic_load(buf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // 1: ended by the flag, 0: by the tick limit
+}
+__global__ void clock_probe_set_kernel(unsigned long long* buf, unsigned long long v) {
+    __hip_atomic_store(buf, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v == 0ull) { buf[1] = 0ull; buf[2] = 0ull; buf[3] = 0ull; }
+}
+
+extern "C" int gdn_clock_probe_arm(uint64_t* buf, void* stream) {
+    (void)hipGetLastError();
+    if (!buf) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(clock_probe_set_kernel, dim3(1), dim3(1), 0, ST(stream), (unsigned long long*)buf, 0ull);
+    return gdn_launch_status();
+}
+extern "C" int gdn_clock_probe_watch(uint64_t* buf, uint64_t max_ticks, void* side_stream) {
+    (void)hipGetLastError();
+    if (!buf || max_ticks == 0 || max_ticks > 1000000000ull) return GDN_ERR_BAD_ARG;      // at most 10 s
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, ST(side_stream), (unsigned long long*)buf,
+                       (unsigned long long)max_ticks);
+    return gdn_launch_status();
+}
+extern "C" int gdn_clock_probe_stop(uint64_t* buf, void* stream) {
+    (void)hipGetLastError();
+    if (!buf) return GDN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(clock_probe_set_kernel, dim3(1), dim3(1), 0, ST(stream), (unsigned long long*)buf, 1ull);
+    return gdn_launch_status();
+}
+
+extern "C" int gdn_version(void) { return 221; }
 
 extern "C" const char* gdn_strerror(int status) {
     switch (status) {

@@ -201,9 +201,6 @@ def _init_conv_weights(module):
             m.weight.data.uniform_(-stdv, stdv)
             if m.bias is not None:
                 m.bias.data.uniform_(-stdv, stdv)
-        elif isinstance(m, nn.Linear):
-            m.weight.data.normal_(0, 0.01)
-            m.bias.data.zero_()
 
 
 _RES = (  # (name, channels, kernel, pad) in the reference's constructor order

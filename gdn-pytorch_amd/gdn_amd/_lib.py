@@ -6,7 +6,7 @@ fails, the product path raises.
 import ctypes
 import os
 import pathlib
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("GDN_HIP_LIB", _PKG.parent / "lib" / "libgdn_hip.so"))
@@ -110,13 +110,16 @@ _SIGS = {
     "gdn_depth_metrics": (c_int32, [_P, _P, _P, _i32, _i32, _i32, _i32, _P, _P, _sz, _P]),
     "gdn_adam_step": (c_int32, [_P, _P, _P, _P, _i64, _f, _f, _f, _f, _f, _i32, _f, _P]),
     "gdn_adam_step_dev": (c_int32, [_P, _P, _P, _P, _i64, _P, _P, _P]),
+    "gdn_clock_probe_arm": (c_int32, [_P, _P]),
+    "gdn_clock_probe_watch": (c_int32, [_P, c_uint64, _P]),
+    "gdn_clock_probe_stop": (c_int32, [_P, _P]),
 }
 _STATUS_FUNCS = {n for n, (r, _) in _SIGS.items() if r is c_int32} - {"gdn_version", "gdn_device_info"}
 
 EXPORTS = tuple(_SIGS)
 # The C ABI revision these signatures (and ConvGeom's layout) describe: gdn_version() of the library must match exactly --
 # a stale build would take the arguments apart differently.
-ABI_VERSION = 220
+ABI_VERSION = 221
 
 
 class _Lib:

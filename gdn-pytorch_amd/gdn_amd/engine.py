@@ -631,7 +631,8 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
             a = out_info                                  # scale / shift / ReLU happen in the consumer's loader
         else:
             if (up_out is not None and _FUSE_UP2X_BF16 and ctx.dtype == torch.bfloat16 and y.is_contiguous()
-                    and (residual is None or residual.is_contiguous()) and y.shape[0] * 2 * y.shape[1] <= 65535):
+                    and (residual is None or residual.is_contiguous()) and y.shape[0] * 2 * y.shape[1] <= 65535
+                    and y.shape[3] % 4 == 0):         # (the fused kernel's channel-vector width; other shapes take the two-pass form)
                 a, a_up = ops.bn_apply_up2x(y, co[0], co[1], relu, residual, align_corners=bool(up_out), out_dtype=ctx.dtype)
             else:
                 a = ops.bn_apply(y, co[0], co[1], relu, residual, out_dtype=ctx.dtype)

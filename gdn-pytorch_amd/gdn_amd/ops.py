@@ -54,9 +54,15 @@ def plan_override_hints():
     h = 0
     e = os.environ
     if e.get("GDN_PLAN_BATCH"):
-        h |= (int(e["GDN_PLAN_BATCH"]) & 0xff) << 8
-    if e.get("GDN_RING_CUS") and int(e["GDN_RING_CUS"]) >= 8:
-        h |= ((int(e["GDN_RING_CUS"]) // 8) & 0xff) << 16
+        n = int(e["GDN_PLAN_BATCH"])
+        if not 1 <= n <= 255:           # an 8-bit field: masking would silently plan for another batch
+            raise GdnError("GDN_PLAN_BATCH=%d is outside 1..255" % n)
+        h |= n << 8
+    if e.get("GDN_RING_CUS"):
+        n = int(e["GDN_RING_CUS"])
+        if not 8 <= n <= 2040 or n % 8:
+            raise GdnError("GDN_RING_CUS=%d must be a multiple of 8 in 8..2040" % n)
+        h |= (n // 8) << 16
     if e.get("GDN_FFT_NP") in ("32", "40"):
         h |= HINT_FFT_NP32 if e["GDN_FFT_NP"] == "32" else HINT_FFT_NP40
     return h
@@ -166,6 +172,44 @@ def side_stream(device):
     return st
 
 
+class ShaderClock:
+    """Measurement aid: the shader clock the chip holds while the launches inside the `with` block run on the current stream
+    (gdn_clock_probe_*: one sleeping wave on a second stream reads s_memtime / s_memrealtime at both ends of the window).
+
+        with ops.ShaderClock(dev) as clk:
+            for _ in range(reps): launch()
+        torch.cuda.synchronize(); clk.ghz()      # None if the watcher could not overlap the window"""
+
+    def __init__(self, device, max_s=5.0):
+        self.buf = torch.zeros(4, dtype=torch.int64, device=device)
+        self.side = torch.cuda.Stream(device=device)
+        self.max_ticks = int(min(max_s, 10.0) * 1e8)
+
+    def __enter__(self):
+        main = torch.cuda.current_stream()
+        lib.gdn_clock_probe_arm(self.buf.data_ptr(), main.cuda_stream)
+        self.side.wait_stream(main)
+        lib.gdn_clock_probe_watch(self.buf.data_ptr(), self.max_ticks, self.side.cuda_stream)
+        return self
+
+    def __exit__(self, *exc):
+        main = torch.cuda.current_stream()
+        lib.gdn_clock_probe_stop(self.buf.data_ptr(), main.cuda_stream)
+        main.wait_stream(self.side)
+        return False
+
+    def read(self):
+        """(shader cycles, 100 MHz ticks, ended_by_flag) of the window; call after a synchronize."""
+        _, cyc, ticks, ended = [int(v) for v in self.buf.cpu().tolist()]
+        return cyc, ticks, bool(ended)
+
+    def ghz(self, min_ticks=1000):
+        cyc, ticks, ended = self.read()
+        if not ended or ticks < min_ticks or cyc <= 0:
+            return None
+        return cyc / ticks * 0.1
+
+
 class Conv:
     """Geometry + launch helper for one Conv2d / ConvTranspose2d layer.
 
@@ -217,6 +261,7 @@ class Conv:
             tile_cfg |= CFG_BF16
         B, H, W, C1 = x.shape
         _, ref, Ho, Wo = self.geom(B, H, W)
+        ph = plan_override_hints()       # part of every cache key below: an override changes the plan, hence slot count and workspace
         c2 = 0 if x2 is None else x2.shape[3]
         if C1 + c2 != self.cin:
             raise GdnError("conv expects %d input channels, got %d" % (self.cin, C1 + c2))
@@ -225,10 +270,10 @@ class Conv:
         st = None
         if stats:
             st = stats_out
-            slots = self._slots.get((B, H, W, tile_cfg))
+            slots = self._slots.get((B, H, W, tile_cfg, ph))
             if slots is None:
                 slots = int(lib.gdn_conv_stats_slots(ref, tile_cfg))
-                self._slots[(B, H, W, tile_cfg)] = slots
+                self._slots[(B, H, W, tile_cfg, ph)] = slots
             if st is None:
                 st = torch.empty((slots, 2, self.cout), dtype=torch.float32, device=x.device)
             elif (st.dtype != torch.float32 or not st.is_contiguous() or st.dim() != 3 or st.shape[0] != slots
@@ -237,10 +282,10 @@ class Conv:
                 # overrun (or leaves slots unwritten that the finalize pass then sums)
                 raise GdnError("conv fwd: stats_out must be a dense float32 [%d, 2, %d] for this geometry and tile_cfg, got %s"
                                % (slots, self.cout, tuple(st.shape)))
-        nb = self._fwd_ws.get((B, H, W, tile_cfg))
+        nb = self._fwd_ws.get((B, H, W, tile_cfg, ph))
         if nb is None:
             nb = int(lib.gdn_conv_fwd_workspace_bytes(ref, tile_cfg))
-            self._fwd_ws[(B, H, W, tile_cfg)] = nb
+            self._fwd_ws[(B, H, W, tile_cfg, ph)] = nb
         ws = workspace(nb, x.device, "splitk") if nb else None
         try:
             lib.gdn_conv_fwd(ref, _p(x), _ld(x), _p(x2), 0 if x2 is None else _ld(x2), C1, _p(w_tap), _p(y), _ld(y),

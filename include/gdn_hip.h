@@ -40,7 +40,7 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
-/* Revision of this header (argument lists, struct layouts).  220: gdn_conv_dgrad dx_up2x; gdn_bn_apply_up2x; bf16 tile id 12 (conv_ring2_bf16).  219: gdn_conv_wgrad_bf16 cfg 4 (wgrad_ring_bf16); gdn_fftconv_cgemm* measurement hooks; plan overrides in gdn_conv_geom.hints; gdn_gemm_x3_nt_packed / gdn_gemm_x3_ring_workspace_bytes removed (the measured-and-not-wired kernel now lives under tests/diag/).  218: gdn_gemm_x3_tn_splits.  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+/* Revision of this header (argument lists, struct layouts).  221: gdn_clock_probe_*.  220: gdn_conv_dgrad dx_up2x; gdn_bn_apply_up2x; bf16 tile id 12 (conv_ring2_bf16).  219: gdn_conv_wgrad_bf16 cfg 4 (wgrad_ring_bf16); gdn_fftconv_cgemm* measurement hooks; plan overrides in gdn_conv_geom.hints; gdn_gemm_x3_nt_packed / gdn_gemm_x3_ring_workspace_bytes removed (the measured-and-not-wired kernel now lives under tests/diag/).  218: gdn_gemm_x3_tn_splits.  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
  * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
@@ -539,6 +539,21 @@ int gdn_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
  * initialised to {1.0, 1.0, 0, 0, 0} and advanced by the call itself. */
 int gdn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
                       const float* hyper, void* state, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Measurement aid (no reference counterpart): the shader clock the chip holds WHILE a window of launches runs, so a
+ * roofline fraction can be read against the clock of the box it was measured on (bench.py `clock_ghz`, `frac_at_clock`).
+ *   buf    device memory, uint64[4]: {flag, shader cycles (s_memtime), 100 MHz ticks (s_memrealtime), ended_by_flag}
+ *   gdn_clock_probe_arm(buf, stream)            clears buf, stream-ordered BEFORE the measured launches;
+ *   gdn_clock_probe_watch(buf, max_ticks, side) one wave on a SECOND stream of the caller's (which must wait for the arm):
+ *                                               reads both counters, sleeps until the flag is set or max_ticks (<= 1e9 =
+ *                                               10 s) have passed, reads them again: clock = cycles / ticks x 100 MHz;
+ *   gdn_clock_probe_stop(buf, stream)           sets the flag, stream-ordered AFTER the measured launches.
+ * One sleeping wave: no LDS, 16 registers -- it fits beside any kernel of this library.
+ * ---------------------------------------------------------------------- */
+int gdn_clock_probe_arm(uint64_t* buf, void* stream);
+int gdn_clock_probe_watch(uint64_t* buf, uint64_t max_ticks, void* side_stream);
+int gdn_clock_probe_stop(uint64_t* buf, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,6 @@
-"""Worker of tests/test_hip_model.py::test_data_parallel_two_ranks (spawned, one process per rank, both on cuda:0 with
-the gloo backend: RCCL refuses two ranks on one device, gloo moves the same buckets through the host)."""
+"""Worker of tests/test_hip_model.py::test_data_parallel_two_ranks (spawned, one process per rank).  On a box with one GPU both
+ranks sit on cuda:0 with the gloo backend (RCCL refuses two ranks on one device, gloo moves the same buckets through the host);
+with two or more GPUs visible it is the deployment layout: one rank per device, RCCL ("nccl"), the bf16 x 3 GEMMs left on."""
 import os
 import sys
 
@@ -12,17 +13,18 @@ def run(rank, world, port, steps, out_dir, overlap, global_berhu=False):
     for p in (root, os.path.join(root, "gdn-pytorch_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0",
-                      WORLD_SIZE=str(world), GDN_OVERLAP_ALLREDUCE="1" if overlap else "0")
+    multi = torch.cuda.device_count() >= world           # (counting devices does not initialise the GPU)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank) if multi else "0",
+                      WORLD_SIZE=str(world), GDN_OVERLAP_ALLREDUCE="1" if overlap else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     import gdn_amd.AE_model_unet as M
     from gdn_amd import distributed as D
     from gdn_amd import ops
     from gdn_amd import utils as U
     from gdn_amd.optim import Adam
     from oracle import gdn_oracle as O
-    D.init(backend="gloo")
+    D.init(backend="nccl" if multi else "gloo")
     U.GLOBAL_BERHU = bool(global_berhu)
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", rank if multi else 0)
     torch.cuda.set_device(dev)
     torch.manual_seed(0 if rank == 0 else 123)          # rank 1 starts from different weights: the broadcast must fix it
     model = M.AutoEncoder_DtoD(input_dim=1, height=32, width=64).to(dev).train()
@@ -51,7 +53,7 @@ def run(rank, world, port, steps, out_dir, overlap, global_berhu=False):
     torch.cuda.synchronize()
     torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "losses": losses, "trace": trace,
                 "reducer": getattr(model, "_gdn_reducer", None) is not None,
-                "x3": "1" if ops.x3_enabled() else "0", "shared": D.SHARED_GPU_RANKS},
+                "x3": "1" if ops.x3_enabled() else "0", "shared": D.SHARED_GPU_RANKS, "backend": str(torch.distributed.get_backend())},
                os.path.join(out_dir, "rank%d.pt" % rank))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

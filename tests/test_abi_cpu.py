@@ -179,3 +179,25 @@ def test_loader_rejects_a_library_of_another_abi_revision(built_lib, monkeypatch
     monkeypatch.setattr(L, "ABI_VERSION", L.ABI_VERSION + 1)
     with pytest.raises(L.GdnError, match="revision"):
         fresh.gdn_version()
+
+
+def test_plan_override_hints_refuse_out_of_range(monkeypatch):
+    """GDN_PLAN_BATCH / GDN_RING_CUS are 8-bit fields of gdn_conv_geom.hints; a value that does not fit must be an
+    error, not a silently different plan (256 -> no override, 300 -> 44)."""
+    import pytest
+    from gdn_amd import ops
+    for k in ("GDN_PLAN_BATCH", "GDN_RING_CUS", "GDN_FFT_NP"):
+        monkeypatch.delenv(k, raising=False)
+    assert ops.plan_override_hints() == 0
+    monkeypatch.setenv("GDN_PLAN_BATCH", "64")
+    monkeypatch.setenv("GDN_RING_CUS", "16")
+    assert ops.plan_override_hints() == (64 << 8) | (2 << 16)
+    for bad in ("0", "256", "300"):
+        monkeypatch.setenv("GDN_PLAN_BATCH", bad)
+        with pytest.raises(ops.GdnError):
+            ops.plan_override_hints()
+    monkeypatch.setenv("GDN_PLAN_BATCH", "255")
+    for bad in ("4", "12", "2048", "4096"):
+        monkeypatch.setenv("GDN_RING_CUS", bad)
+        with pytest.raises(ops.GdnError):
+            ops.plan_override_hints()

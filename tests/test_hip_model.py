@@ -309,7 +309,8 @@ def test_guide_fast_path_identical(gpu):
 
 @pytest.mark.parametrize("overlap,global_berhu", [(True, False), (False, False), (True, True)])
 def test_data_parallel_two_ranks(gpu, tmp_path, monkeypatch, overlap, global_berhu):
-    """Two real processes (one per rank, gloo, both on cuda:0) train 3 steps on their own shards with
+    """Two real processes (one per rank; with >= 2 GPUs visible: one per device over RCCL, x3 on -- otherwise gloo, both on
+    cuda:0) train 3 steps on their own shards with
     broadcast_parameters + sync_gradients (+ the overlapped GradReducer) + the fused Adam's 1/world scale.
     A single process that runs both shards with the same weights, sums the two gradient arenas and applies the
     same Adam must end with BITWISE identical parameters; BatchNorm running statistics stay rank-local (8(e)).
@@ -325,10 +326,14 @@ def test_data_parallel_two_ranks(gpu, tmp_path, monkeypatch, overlap, global_ber
     mp.spawn(dp_worker.run, args=(2, port, steps, str(tmp_path), overlap, global_berhu), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert r0["reducer"] == overlap
-    # the two ranks share this box's one GPU: distributed.init saw it and took the bf16 x 3 GEMMs out (a
-    # neighbour process's barrier-paced bf16 matrix bursts perturb FFT-type kernels on this hardware); same switch here
-    assert r0["shared"] == 2 and r0["x3"] == "0" and r1["x3"] == "0"
-    monkeypatch.setattr(ops, "_x3", False)              # ops.set_x3(False), undone after the test
+    if torch.cuda.device_count() >= 2:
+        # the deployment layout: one rank per device, RCCL; a two-rank SUM is order-free, so the bitwise check below holds
+        assert r0["backend"] == "nccl" and r0["shared"] == 1 and r0["x3"] == "1" and r1["x3"] == "1"
+    else:
+        # the two ranks share this box's one GPU: distributed.init saw it and took the bf16 x 3 GEMMs out (a
+        # neighbour process's barrier-paced bf16 matrix bursts perturb FFT-type kernels on this hardware); same switch here
+        assert r0["backend"] == "gloo" and r0["shared"] == 2 and r0["x3"] == "0" and r1["x3"] == "0"
+        monkeypatch.setattr(ops, "_x3", False)              # ops.set_x3(False), undone after the test
     # single-process emulation: replica A plays rank 0, replica B rank 1 (own BN buffers, shared weights)
     torch.manual_seed(0)
     A = M.AutoEncoder_DtoD(input_dim=1, height=32, width=64).to(gpu).train()
@@ -502,11 +507,15 @@ def test_train_step_b20_vs_oracle(gpu):
             assert float((a - b).norm() / b.norm()) < 1e-3, "post-Adam " + k
 
 
-@pytest.mark.parametrize("seed", [0, 3])
-def test_forward_b20_depth_map_vs_oracle_two_seeds(gpu, seed):
-    """The forward half of the benchmarked configuration on two independent draws (weights AND batch), so the depth-map
-    margin is not one sample deep: max|err| <= 1e-3 (the north-star bar) and rms <= 6e-5 against the CPU oracle's
-    train-mode forward at B = 20, 128x416 (~5 s of oracle time per seed)."""
+_B20_SEED_ERRS = {}
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4])
+def test_forward_b20_depth_map_vs_oracle_five_seeds(gpu, seed):
+    """The forward half of the benchmarked configuration on five independent draws (weights AND batch), so the depth-map
+    margin is not one sample deep: max|err| <= 1e-3 (the north-star bar, absolute on the map's (-1, 1) range) and rms <= 6e-5
+    against the CPU oracle's train-mode forward at B = 20, 128x416 (~5 s of oracle time per seed).  The last seed prints the
+    distribution of the five maxima; test_forward_vs_fp64_yardstick shows whose rounding they are."""
     import gdn_amd.AE_model_unet as M
     B = 20
     depth, _, _ = O.synthetic_batch(B, 128, 416, seed=seed)
@@ -522,8 +531,49 @@ def test_forward_b20_depth_map_vs_oracle_two_seeds(gpu, seed):
     d = out.detach().cpu().double() - ref.double()
     rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
     print("B=20 forward seed %d: depth map max err %.3e rms %.3e" % (seed, mx, rms))
+    _B20_SEED_ERRS[seed] = (mx, rms)
+    if len(_B20_SEED_ERRS) == 5:
+        mxs, rmss = sorted(v[0] for v in _B20_SEED_ERRS.values()), sorted(v[1] for v in _B20_SEED_ERRS.values())
+        print("B=20 forward, 5 seeds: max|err| min %.3e median %.3e max %.3e (bar 1e-3); rms min %.3e median %.3e max %.3e (bar 6e-5)"
+              % (mxs[0], mxs[2], mxs[4], rmss[0], rmss[2], rmss[4]))
     assert mx <= 1e-3, "seed %d: depth map max error %.3e > 1e-3 (rms %.3e)" % (seed, mx, rms)
     assert rms <= 6e-5, "seed %d: depth map rms error %.3e > 6e-5 (max %.3e)" % (seed, rms, mx)
+
+
+@pytest.mark.parametrize("model_name,seed", [("AutoEncoder_DtoD", 0), ("AutoEncoder_DtoD", 1), ("AutoEncoder_2", 0), ("AutoEncoder_2", 1)])
+def test_forward_vs_fp64_yardstick(gpu, model_name, seed):
+    """Whose rounding is the HIP-vs-oracle difference?  The oracle evaluated in float64 (same weights and batch, cast up) is the
+    exact train-mode forward to ~1e-15; both fp32 evaluations -- the reference's arithmetic (the fp32 oracle = torch CPU running
+    the reference's graph, AE_model_unet.py:529-576 / :312-368) and the HIP path -- are judged against it:
+        rms(HIP - fp64) <= 1.1 x rms(oracle_fp32 - fp64),     max|HIP - fp64| <= 1.5 x max|oracle_fp32 - fp64| + 1e-4.
+    I.e. the HIP path is as close to the true value as the reference's own fp32 evaluation (the transform-domain layers sum 64-128
+    products per bin where the direct form sums 5184 per output), and the thin margin of the 1e-3 bar between the two fp32 results is
+    the reference's own rounding as much as ours.  B = 4, 128x416, the trained-layer plan (a tape is recorded)."""
+    import gdn_amd.AE_model_unet as M
+    B, H, W = 4, 128, 416
+    dt = model_name == "AutoEncoder_DtoD"
+    depth, rgb, _ = O.synthetic_batch(B, H, W, seed=100 + seed)
+    xin = depth if dt else rgb
+    sd = O.init_state_dict(model_name, seed=seed)
+    fwd = O.forward_dtod if dt else O.forward_r
+    torch.set_num_threads(max(1, min(len(__import__("os").sched_getaffinity(0)), 32)))
+    with torch.no_grad():
+        ref32 = fwd({k: v.clone() for k, v in sd.items()}, xin, istrain=False, training=True).double()
+        ref64 = fwd({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}, xin.double(),
+                    istrain=False, training=True)
+    assert ref64.dtype == torch.float64
+    model = M.AutoEncoder_DtoD(input_dim=1) if dt else M.AutoEncoder_2(input_dim=3)
+    model.load_state_dict(sd)
+    model = model.to(gpu).train()
+    out = model(xin.to(gpu).requires_grad_(True), istrain=False).detach().cpu().double()      # (records a tape: trained-layer plan)
+    rms = lambda t: float(t.pow(2).mean().sqrt())
+    e_hip, e_ref, e_pair = out - ref64, ref32 - ref64, out - ref32
+    print("%s seed %d: HIP-fp64 rms %.3e max %.3e | oracle_fp32-fp64 rms %.3e max %.3e | HIP-oracle_fp32 rms %.3e max %.3e"
+          % (model_name, seed, rms(e_hip), float(e_hip.abs().max()), rms(e_ref), float(e_ref.abs().max()), rms(e_pair),
+             float(e_pair.abs().max())))
+    assert rms(e_ref) > 0 and rms(e_hip) <= 1.1 * rms(e_ref), "HIP is further from fp64 (%.3e) than the reference's fp32 (%.3e)" % (
+        rms(e_hip), rms(e_ref))
+    assert float(e_hip.abs().max()) <= 1.5 * float(e_ref.abs().max()) + 1e-4
 
 
 def test_rtod_train_step_b20_vs_oracle(gpu):

@@ -548,6 +548,121 @@ def test_bench_gpus_2_self_launch_trains_two_ranks(gpu, mode, dtype):
     assert dp2["overlap"] is False and dp2["buckets_in_flight_before_backward_returned"] == 0 and abs(dp2["bytes_reduced"] - dp["bytes_reduced"]) < 0.01 * dp["bytes_reduced"]
 
 
+def test_shader_clock_probe(gpu):
+    """gdn_clock_probe_*: one sleeping wave on a second stream brackets a window of launches on the current stream and returns
+    shader cycles / 100 MHz ticks: a plausible engine clock (0.3-2.6 GHz on MI355X), the window at least as long as the event
+    time of the launches, and a window whose stop never comes ends by the tick limit (reported, no hang)."""
+    from gdn_amd import ops
+    x = torch.randn(8, 128, 416, 64, device=gpu)
+    sc, sh = torch.ones(64, device=gpu), torch.zeros(64, device=gpu)
+    y = torch.empty_like(x)
+    for _ in range(3):
+        ops.bn_apply(x, sc, sh, True, None, out=y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    clk = ops.ShaderClock(gpu)
+    with clk:
+        e0.record()
+        for _ in range(50):
+            ops.bn_apply(x, sc, sh, True, None, out=y)
+        e1.record()
+    torch.cuda.synchronize()
+    cyc, ticks, ended = clk.read()
+    ghz = clk.ghz()
+    print("clock probe: %d cycles / %d ticks -> %.3f GHz over %.3f ms of launches" % (cyc, ticks, ghz or -1, e0.elapsed_time(e1)))
+    assert ended and ghz is not None and 0.3 < ghz < 2.6
+    assert ticks * 1e-5 >= 0.9 * e0.elapsed_time(e1)                 # 100 MHz ticks -> ms
+    # no stop: the watcher gives up at its tick limit (20 ms here) and says so
+    clk2 = ops.ShaderClock(gpu, max_s=0.02)
+    ops.lib.gdn_clock_probe_arm(clk2.buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    clk2.side.wait_stream(torch.cuda.current_stream())
+    ops.lib.gdn_clock_probe_watch(clk2.buf.data_ptr(), clk2.max_ticks, clk2.side.cuda_stream)
+    torch.cuda.synchronize()
+    cyc, ticks, ended = clk2.read()
+    assert not ended and 2_000_000 <= ticks < 4_000_000 and clk2.ghz() is None
+
+
+def _no_error_keys(o, path=""):
+    """Every 'error' / '*_error' key anywhere in a bench record (there must be none)."""
+    bad = []
+    if isinstance(o, dict):
+        for k, v in o.items():
+            if k == "error" or k.endswith("_error"):
+                bad.append(path + "/" + k)
+            bad += _no_error_keys(v, path + "/" + k)
+    elif isinstance(o, list):
+        for i, v in enumerate(o):
+            bad += _no_error_keys(v, "%s[%d]" % (path, i))
+    return bad
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_gpus_2_default_flags_rooflines_on(gpu, launcher):
+    """The command the driver's scaling run takes: `bench.py --gpus 2` WITHOUT --no-roofline.  After the
+    closing barrier the other rank leaves the process group; rank 0 must not run another training step (it holds the gradient
+    all-reduce -- under RCCL a collective issued alone never returns, under gloo it raises): one JSON line, no 'error' anywhere
+    in it, the breakdown marked as an N = 1 property, a live `roofline`, and the tail after the timed region short.  1-GPU box:
+    gloo hooks, both ranks on cuda:0; >= 2 GPUs: RCCL, one rank per device."""
+    import json
+    import os
+    import pathlib
+    import subprocess
+    import sys
+    import time
+    root = pathlib.Path(__file__).resolve().parent.parent
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    multi = torch.cuda.device_count() >= 2
+    env = base if multi else dict(base, GDN_SINGLE_DEVICE="1", GDN_DIST_BACKEND="gloo")
+    tail = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2"]
+    if launcher == "self":
+        cmd = [sys.executable, str(root / "bench.py"), *tail]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29523", str(root / "bench.py"), *tail]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(root))
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert sum(ln.startswith("{") for ln in lines) == 1
+    rec = json.loads(lines[-1] if launcher == "self" else [ln for ln in lines if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["dist_backend"] == ("nccl" if multi else "gloo") and rec["value"] > 0
+    assert _no_error_keys(rec) == [], _no_error_keys(rec)
+    assert "skipped" in rec["step_kernel_breakdown"] and "cpu_baseline" not in rec and "other_configs" not in rec
+    rf = rec["roofline"]
+    assert rf["bound"] == "mfma" and rf["achieved"] > 0 and 0 < rf["frac"] < 1 and "cgemm_bins_kernel" in rf["kernel"]
+    assert rec["tail_s"] < 60.0 and wall < 600.0, (rec["tail_s"], wall)
+    assert "parity_bar" in rec["config"]
+
+
+def test_bench_forced_rccl_one_rank_rooflines_on(gpu):
+    """A forced 1-rank RCCL group (GDN_FORCE_DIST=1: the same reducer / stream-ordering path as N > 1) with the rooflines ON:
+    at world size 1 the profiler pass over two more steps runs (its all-reduce is this rank's own), and the record carries the
+    family shares over ALL symbols plus the step's largest symbol; no 'error' anywhere."""
+    import json
+    import os
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = dict(os.environ, GDN_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29527", RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-cpu-baseline", "--no-other-configs"],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    rec = json.loads(lines[-1])
+    assert rec["n_gpus"] == 1 and rec["dist_backend"] == "nccl" and rec["value"] > 0
+    assert _no_error_keys(rec) == [], _no_error_keys(rec)
+    brk = rec["step_kernel_breakdown"]
+    assert brk["symbols"] > len(brk["top"]) and brk["top_symbol"] == brk["top"][0]["symbol"]
+    assert abs(sum(brk["families"].values()) - 1.0) < 1e-2 and "cgemm" in brk["families"]
+    for k in ("roofline", "roofline_direct3x3", "roofline_fftconv"):
+        assert rec[k]["achieved"] > 0, k
+    assert "largest single symbol" in rec["roofline"]["chosen_by"]
+
+
 def _diag_child(script, args, timeout=600):
     """Run tests/diag/<script> child <args> in a fresh process; returns its `R <hash> <losses>` line."""
     import pathlib

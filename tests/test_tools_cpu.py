@@ -46,3 +46,31 @@ def test_family_classifier_names_the_x3_gemms():
     assert family("void cgemm_bins_kernel<false>").startswith("fft") and family("void conv_wgrad_f32_kernel<7,64>") == "direct wgrad"
     assert family("void bn_bwd_apply8_kernel").startswith("batchnorm") and family("adam_kernel") == "adam"
     assert is_ours("void upsample2x_fwd_kernel") and not is_ours("void at::native::vectorized_elementwise_kernel")
+
+
+def test_summarize_trace_drops_the_first_step_outlier(tmp_path):
+    """tools/summarize_trace.py: per-(kernel, grid) means are over steady-state steps: a 20 ms first-step
+    launch of a 0.2 ms kernel must not show up in its mean."""
+    rows, t = [], 0
+    for step in range(4):
+        d = 20_000_000 if step == 0 else 200_000
+        rows.append(("void conv_igemm_bf16(IgemmParams)", 0, t, t + d)); t += d
+        rows.append(("void adam_kernel(float*)", 0, t, t + 1000)); t += 1000
+    f = _trace(tmp_path, rows)
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "summarize_trace.py"), str(f)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "steady-state steps only: 3 of 4 steps" in r.stdout
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("conv_igemm_bf16") or " conv_igemm_bf16" in ln][0]
+    assert " 3 " in line and "200.0" in line, line
+
+
+def test_bench_kernel_family_table():
+    """bench.py's family table for step_kernel_breakdown: every symbol counts (not only the top rows), the two GEMM
+    families are separate from the transforms that share their prefix."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    f = bench.kernel_family
+    assert f("cgemm_bins_kernel") == "cgemm" and f("cgemm_tn_bins_kernel") == "cgemm" and f("gemm_x3_nt8_kernel") == "gemm_x3"
+    assert f("fft2d_fwd_kernel") == f("ifft_rows_overlap_kernel") == f("fft_wgrad_taps_kernel") == "fft_transforms"
+    assert f("wino_gemm_kernel") == "wino_gemm_f32" and f("wino4_input_kernel") == "winograd_transforms"
+    assert f("bn_bwd_apply_kernel") == "batchnorm" and f("conv_ring2_bf16") == "bf16_ring" and f("berhu_kernel") == "other"

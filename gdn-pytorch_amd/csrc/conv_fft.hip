@@ -39,10 +39,50 @@ static_assert(FFT_BINS_OF(32) % 8 == 0 && FFT_BINS_OF(16) % 8 == 0 && FFT_BINS_O
 // not fold it back into multiplies.
 #define GDN_KEEP(v) asm volatile("" : "+v"(v))
 
+// Round-6 A/B switches (tools/ab_variant.sh ... -DGDN_x=n; measured in profiles/r06_fft_ab.txt):
+#ifndef GDN_ICOLS_ORDER
+#define GDN_ICOLS_ORDER 1    // ifft_cols grid: 0: blockIdx.x = tile group, y = kx;  1: blockIdx.x = kx (fastest), y = tile group
+#endif
+#ifndef GDN_ROWS_REMAP
+#define GDN_ROWS_REMAP 2     // ifft_rows_overlap: 0 = 4 tiles x 64-channel chunk, 1 = (256 / C) tiles x all channels, 2 = 1 only for C = 256
+#endif
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
 
 namespace {
+
+// Raw buffer access for the transform kernels (round 6).  Walking a global pointer through an `asm volatile` pin (GDN_KEEP) made
+// the compiler forget the address space: every strided access became a FLAT instruction with two vector instructions of 64-bit
+// address arithmetic in front of it.  Here the part of an address that is uniform over the workgroup (tile, bin row, column) lives
+// in the descriptor's base -- scalar arithmetic -- and the per-lane part is a 32-bit byte offset that is a constant of the thread.
+// The descriptor spans 4 GiB from its base; what is in range is decided by the caller (a per-lane offset >= 2^31 reads as zero).
+// Values that are uniform over the workgroup but were computed on the vector unit (an integer division of blockIdx) live in vector
+// registers: a descriptor built from them makes the compiler emit a "waterfall" loop around every access.  GDN_UNI moves them to
+// scalar registers once, where they are defined.
+#define GDN_UNI(v) __builtin_amdgcn_readfirstlane(v)
+template <class T>
+__device__ __forceinline__ T* fft_uni_ptr(T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = GDN_UNI((unsigned)v), hi = GDN_UNI((unsigned)(v >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fft_rs(const void* base, unsigned bytes = 0xffffffffu) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x2 fft_ld2(const void* base, unsigned voff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(fft_rs(base), voff, 0, 0));
+}
+__device__ __forceinline__ void fft_st2(void* base, unsigned voff, float a, float b) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, f32x2{a, b}), fft_rs(base), voff, 0, 0);
+}
+__device__ __forceinline__ float fft_ld1(const void* base, unsigned voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fft_rs(base), voff, 0, 0));
+}
+__device__ __forceinline__ void fft_st1(void* base, unsigned voff, float a) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a), fft_rs(base), voff, 0, 0);
+}
+constexpr unsigned FFT_VOFF_ZERO = 0x80000000u;      // a per-lane offset no descriptor reaches: the load returns 0, the store is dropped
 
 // cos/sin(2*pi*j/32), j = 0..31
 __device__ __constant__ float kCos32[32] = {
@@ -196,6 +236,9 @@ template <int NP>
 __device__ __forceinline__ float tw_cos_r(int idx) { return NP == 40 ? kCos40[idx] : kCos32[idx * (32 / (NP == 40 ? 32 : NP))]; }
 template <int NP>
 __device__ __forceinline__ float tw_sin_r(int idx) { return NP == 40 ? kSin40[idx] : kSin32[idx * (32 / (NP == 40 ? 32 : NP))]; }
+
+// pitch (complex elements) of one tile of the column-inverse intermediate S[t][u][kx][c]
+__host__ __device__ inline size_t fft_s_pitch(int np, int C) { return (size_t)np * (np / 2 + 1) * C; }
 
 struct FftGeom {
     int np, bins;                // tile size (32 / 16), kept bins = np * (np/2 + 1)
@@ -394,30 +437,42 @@ __global__ __launch_bounds__(256, 4) void cgemm_bins_kernel(const float* __restr
 }
 
 // icols: thread = (tile, kx, channel n): inverse FFT32 along ky, rows u < nrows kept.
-// grid: x = (tile / 4) * (C / 64) + channel chunk, y = kx; block = 4 tiles x 64 channels
+// grid: x = tile group, y = kx; block = (256 / C) WHOLE tiles x all C channels (C = 64 << cq_shift <= 256): a block's loads are one
+// contiguous 2 KB run per ky and its stores C x 8 B runs (round 6; before: 4 tiles x one 64-channel chunk, i.e. 512-byte pieces
+// of 1-2 KB rows on the 128- / 256-channel layers -- PMC profiles/r06_fft_pmc.json: 1.8 TB/s, 70 % of the wave time waiting)
+#ifndef GDN_ICOLS40_WAVES
+#define GDN_ICOLS40_WAVES 2
+#endif
+
 template <int NP>
-__global__ __launch_bounds__(256, NP == 40 ? 2 : 1) void ifft_cols_kernel(const float2* __restrict__ Yf, float2* __restrict__ S, int C, int M, int nrows,
+__global__ __launch_bounds__(256, NP == 40 ? GDN_ICOLS40_WAVES : 1) void ifft_cols_kernel(const float2* __restrict__ Yf, float2* __restrict__ S, int C, int M, int nrows,
                                                         int cq_shift) {
     constexpr int NK = FFT_NK_OF(NP);
-    const int t = (blockIdx.x >> cq_shift) * 4 + (threadIdx.x >> 6);
+    const int csh = 6 + cq_shift;                                   // log2(C)
+    const int bx = GDN_ICOLS_ORDER ? blockIdx.y : blockIdx.x, kx = GDN_ICOLS_ORDER ? blockIdx.x : blockIdx.y;
+    const int t = bx * (256 >> csh) + (threadIdx.x >> csh);
     if (t >= M) return;
-    const int c = (blockIdx.x & ((1 << cq_shift) - 1)) * 64 + (threadIdx.x & 63), kx = blockIdx.y;
+    const int c = threadIdx.x & (C - 1);
     float re[NP], im[NP];
-    const float2* src = Yf + ((size_t)kx * M + t) * C + c;
+    // the block's (256 / C) tiles x C channels are one contiguous 2 KB run per bin: per-lane offset = 8 x thread, the bin row is scalar
+    const int t0 = bx * (256 >> csh);
+    const float2* src = fft_uni_ptr(Yf + ((size_t)kx * M + t0) * C);
     const size_t sk = (size_t)NK * M * C;
+    const unsigned vi = threadIdx.x * 8u;
 #pragma unroll
     for (int ky = 0; ky < NP; ++ky) {
-        const float2 v = *src;
-        re[ky] = v.x; im[ky] = v.y;
-        src += sk; GDN_KEEP(src);
+        const f32x2 v = fft_ld2(src, vi);
+        re[ky] = v[0]; im[ky] = v[1];
+        src += sk;
     }
     fftn<NP, 1>(re, im);
-    float2* dst = S + (((size_t)t * NP) * NK + kx) * C + c;
+    float2* dst = fft_uni_ptr(S + (size_t)t0 * fft_s_pitch(NP, C) +  (size_t)kx * C);
+    const unsigned vo = (unsigned)(((size_t)(threadIdx.x >> csh) * fft_s_pitch(NP, C) + c) * 8);
     const int su = NK * C;
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
-        if (u < nrows) *dst = make_float2(re[u], im[u]);
-        dst += su; GDN_KEEP(dst);
+        if (u < nrows) fft_st2(dst, vo, re[u], im[u]);
+        dst += su;
     }
 }
 
@@ -617,13 +672,16 @@ __global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __
                                                                 int parity, int Ho, int Wo, int off, int cq_shift) {
     // output image Ho x Wo; patch row j of tile row ty lands on output row ty*T - off + j  (off = pad for a zero-padded
     // layer: dx itself; off = 0 for a reflection-padded one: the padded-domain gradient, folded afterwards)
-    // grid: x = (tile-of-this-parity / 4) * (C / 64) + channel chunk, y = output row, z = image; block = 4 tiles x 64 channels
+    // grid: x = group of tiles of this parity, y = output row, z = image; block = (256 / C) tiles x all C channels (whole 8 x C
+    // byte rows of S in, whole 4 x C byte pixels of dx out: round 6, see ifft_cols_kernel)
     constexpr int NK = FFT_NK_OF(NP);
     const int C = g.C, T = g.T;
     const int ntx = (g.tiles_x + 1 - parity) / 2;         // tiles of this parity per row
-    const int txl = (blockIdx.x >> cq_shift) * 4 + (threadIdx.x >> 6);
+    const bool remap = GDN_ROWS_REMAP == 1 || (GDN_ROWS_REMAP == 2 && cq_shift == 2);
+    const int csh = remap ? 6 + cq_shift : 6;             // log2(channels per workgroup)
+    const int txl = (remap ? blockIdx.x : (blockIdx.x >> cq_shift)) * (256 >> csh) + (threadIdx.x >> csh);
     if (txl >= ntx) return;
-    const int c = (blockIdx.x & ((1 << cq_shift) - 1)) * 64 + (threadIdx.x & 63);
+    const int c = (remap ? 0 : (blockIdx.x & ((1 << cq_shift) - 1)) * 64) + (threadIdx.x & ((1 << csh) - 1));
     const int tx = txl * 2 + parity, iy = blockIdx.y, b = blockIdx.z;
     const int q = iy + off;
     const int ty_a = q / T, j_a = q - ty_a * T;
@@ -632,15 +690,17 @@ __global__ __launch_bounds__(256) void ifft_rows_overlap_kernel(const float2* __
     for (int kx = 0; kx < NK; ++kx) { re[kx] = 0.f; im[kx] = 0.f; }
     if (ty_a < g.tiles_y) {
         const int t = (b * g.tiles_y + ty_a) * g.tiles_x + tx;
-        const float2* src = S + (((size_t)t * NP + j_a) * NK) * C + c;
+        const float2* src = S + (size_t)t * fft_s_pitch(NP, C) + ((size_t)j_a * NK) * C + c;
+        const int skx = C;
 #pragma unroll
-        for (int kx = 0; kx < NK; ++kx) { const float2 v = *src; re[kx] = v.x; im[kx] = v.y; src += C; GDN_KEEP(src); }
+        for (int kx = 0; kx < NK; ++kx) { const float2 v = *src; re[kx] = v.x; im[kx] = v.y; src += skx; GDN_KEEP(src); }
     }
     if (ty_a >= 1 && j_a + T < NP) {
         const int t = (b * g.tiles_y + ty_a - 1) * g.tiles_x + tx;
-        const float2* src = S + (((size_t)t * NP + j_a + T) * NK) * C + c;
+        const float2* src = S + (size_t)t * fft_s_pitch(NP, C) + ((size_t)(j_a + T) * NK) * C + c;
+        const int skx = C;
 #pragma unroll
-        for (int kx = 0; kx < NK; ++kx) { const float2 v = *src; re[kx] += v.x; im[kx] += v.y; src += C; GDN_KEEP(src); }
+        for (int kx = 0; kx < NK; ++kx) { const float2 v = *src; re[kx] += v.x; im[kx] += v.y; src += skx; GDN_KEEP(src); }
     }
 #pragma unroll
     for (int kx = NK; kx < NP; ++kx) { re[kx] = re[NP - kx]; im[kx] = -im[NP - kx]; }
@@ -709,9 +769,40 @@ __global__ __launch_bounds__(256) void fft_reflect_fold_kernel(const float* __re
 }
 
 // ---- single-pass 2-D transforms: one workgroup = one tile x 16 channels, rows and columns meet in LDS (68 KB) ----
-// channels per workgroup: 16, or 8 for the 40-point tiles (40 x 21 x 8 complex = 53.8 KB: three workgroups per CU)
-#define FFT_CG_OF(NP) ((NP) == 40 ? 16 : 16)
+// channels per workgroup: 16 (8 for the 40-point tiles -- 53.8 KB of LDS, two workgroups per CU at 152 registers -- measured again in
+// round 6 with the scalar loader: forward transform 265 vs 237 us, inverse 357 vs 253: the 32- / 64-byte runs cost more than the
+// overlap of two workgroups returns; profiles/r06_fft_ab.txt)
+#define FFT_CG_OF(NP) 16
 #define FFT_LDS_ELEMS_OF(NP) ((NP) * FFT_NK_OF(NP) * FFT_CG_OF(NP))
+
+// One patch row of the forward transform's plain loader: NP raw buffer loads through `img` (image b, channel group: uniform), the
+// lane's row as a constant byte offset (FFT_VOFF_ZERO for a row that reads as zero), the column as the scalar offset.
+//   FAST: no border column in this tile -- the column is ix0 + bb, columns >= nvalid (zero padding of a dy tile) read 0;
+//   else: bounds test, reflection (|ix|, 2W - 2 - ix) and the zero-byte descriptor of an outside column, all scalar.
+//   AFF : [relu](x * scale + shift) on load (the producer's train-mode BatchNorm); padding stays zero -- isl / itl are already
+//         zeroed for a zero row, the shift of a zero column by a scalar select.
+template <int NP, bool FAST, bool AFF>
+__device__ __forceinline__ void fft_load_row(float (&re)[NP], float (&im)[NP], const float* img, unsigned img_bytes, unsigned vrow,
+                                             int ldx, int ix0, int nvalid, int lim, int W, float isl, float itl, float lo) {
+    const unsigned ldx4 = (unsigned)ldx * 4u;
+#pragma unroll
+    for (int bb = 0; bb < NP; ++bb) {
+        const int ix = ix0 + bb;
+        bool colok;
+        unsigned so;
+        if (FAST) {
+            colok = bb < nvalid;
+            so = (unsigned)ix * ldx4;
+        } else {
+            colok = bb < nvalid && ix >= -lim && ix < W + lim;
+            const int ai = ix < 0 ? -ix : ix;
+            so = (unsigned)(ai < W ? ai : 2 * W - 2 - ai) * ldx4;                       // mirrored column (border patches only)
+        }
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fft_rs(img, colok ? img_bytes : 0u), vrow, so, 0));
+        re[bb] = AFF ? fmaxf(v * isl + (colok ? itl : 0.f), lo) : v;
+        im[bb] = 0.f;
+    }
+}
 
 // forward: patch (halo = 1: rows/cols start at -pad, full 32; halo = 0: the T x T tile, zero padded) -> Xf[bin][tile][C]
 // two waves per SIMD: at four (128 VGPRs) the two 32-point transforms spill 44 dwords per lane and the kernel is 15 % slower
@@ -735,10 +826,10 @@ __global__ __launch_bounds__(NP * FFT_CG_OF(NP), NP == 16 ? 4 : 2) void fft2d_fw
     // groups of one tile back to back, so the half cache lines the groups share and the halo rows / columns neighbouring
     // tiles share are served by that XCD's L2 instead of being fetched once per XCD
     const int ngrp = g.C / CG, tpx = (g.M + 7) / 8;
-    const int tid = threadIdx.x, c = tid & (CG - 1), cg = ((blockIdx.x >> 3) % ngrp) * CG;
-    const int t = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3) / ngrp;
+    const int tid = threadIdx.x, c = tid & (CG - 1), cg = GDN_UNI(((blockIdx.x >> 3) % ngrp) * CG);
+    const int t = GDN_UNI((blockIdx.x & 7) * tpx + (blockIdx.x >> 3) / ngrp);
     if (t >= g.M) return;
-    const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
+    const int tx = GDN_UNI(t % g.tiles_x), ty = GDN_UNI((t / g.tiles_x) % g.tiles_y), b = GDN_UNI(t / (g.tiles_x * g.tiles_y));
     float re[NP], im[NP];
     {
         const int a = tid >> CGS;
@@ -751,7 +842,7 @@ __global__ __launch_bounds__(NP * FFT_CG_OF(NP), NP == 16 ? 4 : 2) void fft2d_fw
         const bool row_ok = iy >= -lim && iy < g.H + lim && a < nvalid;
         const int iyr = iy < 0 ? -iy : (iy >= g.H ? 2 * g.H - 2 - iy : iy);
         // wave-uniform image base + 32-bit per-lane offsets (one image is far below 2^31 elements): half the address registers
-        const float* img = x + (size_t)b * g.H * g.W * ldx + cg;
+        const float* img = fft_uni_ptr(x + (size_t)b * g.H * g.W * ldx + cg);
         const int row_off = (row_ok ? iyr : 0) * g.W * ldx + c;
         int off_x = ix0 * ldx;                             // running ix * ldx (interior columns: no multiply per element)
         const float is = in_scale ? in_scale[cg + c] : 1.f, it = in_scale ? in_shift[cg + c] : 0.f;
@@ -786,50 +877,60 @@ __global__ __launch_bounds__(NP * FFT_CG_OF(NP), NP == 16 ? 4 : 2) void fft2d_fw
                 im[bb] = 0.f;
             }
         } else if (!bnb_y) {
-#pragma unroll
-            for (int bb = 0; bb < NP; ++bb) {
-                const int ix = ix0 + bb;
-                const bool ok = row_ok && bb < nvalid && ix >= -lim && ix < g.W + lim;
-                const bool inside = ix >= 0 && ix < g.W;
-                const int ixr = ix < 0 ? -ix : 2 * g.W - 2 - ix;         // mirrored column (border patches only)
-                float v = ok ? img[row_off + (inside ? off_x : ixr * ldx)] : 0.f;
-                if (in_scale) v = ok ? fmaxf(v * is + it, lo) : 0.f;
-                re[bb] = v;
-                im[bb] = 0.f;
-                off_x += ldx; GDN_KEEP(off_x);
+            // Round 6: raw buffer loads, no branch and no predicate per element.  The ROW is a constant of the thread: a row that must
+            // read as zero gets a per-lane offset no descriptor reaches (the hardware returns 0).  The COLUMN is uniform over the
+            // workgroup: its bounds test, reflection and byte offset are scalar arithmetic on the descriptor's base; a column outside
+            // the border reads a clamped address and is zeroed by a scalar select.  (Before: a divergent branch, 22 scalar and 7
+            // vector instructions around every load -- 1200 of the 1900 instructions a wave spent in this phase.)
+            // A column outside the border is read through a descriptor of zero bytes (it loads 0 without touching memory).  A tile
+            // with no border column (11 of the 13 tiles of a 416-pixel row) takes the loop whose column is a running scalar offset.
+            const unsigned vrow = row_ok ? (unsigned)row_off * 4u : FFT_VOFF_ZERO;
+            const unsigned img_bytes = (unsigned)g.H * g.W * ldx * 4u - (unsigned)cg * 4u;
+            const float isl = row_ok ? is : 0.f, itl = row_ok ? it : 0.f;      // (the coefficients of a zero ROW are zeroed per lane)
+            const bool fastx = ix0 >= 0 && ix0 + nvalid <= g.W;                // uniform
+            if (fastx) {
+                if (in_scale) fft_load_row<NP, true, true>(re, im, img, img_bytes, vrow, ldx, ix0, nvalid, lim, g.W, isl, itl, lo);
+                else fft_load_row<NP, true, false>(re, im, img, img_bytes, vrow, ldx, ix0, nvalid, lim, g.W, isl, itl, lo);
+            } else {
+                if (in_scale) fft_load_row<NP, false, true>(re, im, img, img_bytes, vrow, ldx, ix0, nvalid, lim, g.W, isl, itl, lo);
+                else fft_load_row<NP, false, false>(re, im, img, img_bytes, vrow, ldx, ix0, nvalid, lim, g.W, isl, itl, lo);
             }
         } else {
-            // dy = scale * (dz - k1 - xhat * k2) from (dout, y): zero border (no reflection in this mode)
+            // dy = scale * (dz - k1 - xhat * k2) from (dout, y): zero border (no reflection in this mode).
+            // Round 6: raw buffer loads like the plain loader -- the lane's row is a constant offset (a zero row reads 0 and its
+            // scale is zeroed per lane), the column is uniform (scalar offset; an outside column reads through a zero-byte
+            // descriptor and is re-selected to 0 by a scalar mask).  Two halves: NP loads in flight, NP / 2 extra registers.
             const int ch = cg + c;
             const float bs = bnb_co[ch], bt = bnb_co[g.C + ch], bmu = bnb_co[2 * g.C + ch], bis = bnb_co[3 * g.C + ch];
             const float k1 = bnb_kk[ch], k2 = bnb_kk[g.C + ch];
-            const float* yimg = bnb_y + (size_t)b * g.H * g.W * ld_bnb + cg;
-            const int yrow = (row_ok ? iy : 0) * g.W * ld_bnb + c;
-            int off_y = ix0 * ld_bnb;
-            // two passes: every load first (addresses clamped to the row, so none is conditional and all NP x 2 are in
-            // flight together), then the arithmetic.  With the loads inside `if (ok)` the compiler waited for each pair before
-            // issuing the next: 32 dependent round trips per workgroup, 527 us for this transform against 253 us for the
-            // forward's (profiles/r02 step trace).
-            constexpr int HB = NP / 2;                       // (in two halves: NP loads in flight, NP / 2 extra registers)
+            const float bsl = row_ok ? bs : 0.f;
+            const float* yimg = fft_uni_ptr(bnb_y + (size_t)b * g.H * g.W * ld_bnb + cg);
+            const unsigned vrow_d = row_ok ? (unsigned)row_off * 4u : FFT_VOFF_ZERO;
+            const unsigned vrow_y = row_ok ? (unsigned)(iy * g.W * ld_bnb + c) * 4u : FFT_VOFF_ZERO;
+            const unsigned bytes_d = (unsigned)g.H * g.W * ldx * 4u - (unsigned)cg * 4u;
+            const unsigned bytes_y = (unsigned)g.H * g.W * ld_bnb * 4u - (unsigned)cg * 4u;
+            const unsigned ldx4 = (unsigned)ldx * 4u, ldy4 = (unsigned)ld_bnb * 4u;
+            constexpr int HB = NP / 2;
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
                 float dv[HB];
 #pragma unroll
                 for (int b2 = 0; b2 < HB; ++b2) {
                     const int bb = hb * HB + b2, ix = ix0 + bb;
-                    const bool in = bb < nvalid && ix >= 0 && ix < g.W;
-                    dv[b2] = img[row_off + (in ? off_x : 0)];
-                    im[bb] = yimg[yrow + (in ? off_y : 0)];          // (im[] holds y until the transform input is formed)
-                    off_x += ldx; GDN_KEEP(off_x);
-                    off_y += ld_bnb; GDN_KEEP(off_y);
+                    const bool colok = bb < nvalid && ix >= 0 && ix < g.W;              // uniform
+                    dv[b2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fft_rs(img, colok ? bytes_d : 0u), vrow_d,
+                                                                                            (unsigned)ix * ldx4, 0));
+                    im[bb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fft_rs(yimg, colok ? bytes_y : 0u), vrow_y,
+                                                                                            (unsigned)ix * ldy4, 0));   // (im[] holds y for now)
                 }
 #pragma unroll
                 for (int b2 = 0; b2 < HB; ++b2) {
                     const int bb = hb * HB + b2, ix = ix0 + bb;
-                    const bool ok = row_ok && bb < nvalid && ix >= 0 && ix < g.W;
+                    const bool colok = bb < nvalid && ix >= 0 && ix < g.W;
                     const float d = dv[b2], yv = im[bb];
                     const float dz = (in_relu && !(yv * bs + bt > 0.f)) ? 0.f : d;
-                    re[bb] = ok ? bs * (dz - k1 - ((yv - bmu) * bis) * k2) : 0.f;
+                    const float val = bsl * (dz - k1 - ((yv - bmu) * bis) * k2);
+                    re[bb] = colok ? val : 0.f;
                     im[bb] = 0.f;
                 }
             }
@@ -845,10 +946,13 @@ __global__ __launch_bounds__(NP * FFT_CG_OF(NP), NP == 16 ? 4 : 2) void fft2d_fw
 #pragma unroll
         for (int a = 0; a < NP; ++a) { const float2 v = lds[(a * NK + kx) * CG + c]; re[a] = v.x; im[a] = v.y; }
         fftn<NP, -1>(re, im);
-        float2* dst = Xf + ((size_t)kx * g.M + t) * g.C + cg + c;
+        // bin (ky, kx) of this tile and channel group: the tile / channel-group / ky part of the address is uniform (descriptor
+        // base), the lane's kx and channel are a constant 32-bit offset
+        float2* dst = fft_uni_ptr(Xf + (size_t)t * g.C + cg);
         const size_t sk = (size_t)NK * g.M * g.C;
+        const unsigned vo = (unsigned)(((size_t)kx * g.M * g.C + c) * 8);
 #pragma unroll
-        for (int ky = 0; ky < NP; ++ky) { *dst = make_float2(re[ky], im[ky]); dst += sk; GDN_KEEP(dst); }
+        for (int ky = 0; ky < NP; ++ky) { fft_st2(dst, vo, re[ky], im[ky]); dst += sk; }
     }
 }
 
@@ -894,10 +998,10 @@ __global__ __launch_bounds__(NP * FFT_CG_OF(NP), NP == 16 ? 8 : NP == 32 ? 4 : 2
     constexpr int CG = FFT_CG_OF(NP), CGS = CG == 8 ? 3 : 4;
     __shared__ float2 lds[FFT_LDS_ELEMS_OF(NP)];
     const int ngrp = g.N / CG, tpx = (g.M + 7) / 8;          // XCD-aware order as in fft2d_fwd_kernel
-    const int tid = threadIdx.x, c = tid & (CG - 1), cg = ((blockIdx.x >> 3) % ngrp) * CG, T = g.T;
-    const int t = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3) / ngrp;
+    const int tid = threadIdx.x, c = tid & (CG - 1), cg = GDN_UNI(((blockIdx.x >> 3) % ngrp) * CG), T = g.T;
+    const int t = GDN_UNI((blockIdx.x & 7) * tpx + (blockIdx.x >> 3) / ngrp);
     if (t >= g.M) return;
-    const int tx = t % g.tiles_x, ty = (t / g.tiles_x) % g.tiles_y, b = t / (g.tiles_x * g.tiles_y);
+    const int tx = GDN_UNI(t % g.tiles_x), ty = GDN_UNI((t / g.tiles_x) % g.tiles_y), b = GDN_UNI(t / (g.tiles_x * g.tiles_y));
     float re[NP], im[NP];
     ifft2d_cols_to_lds<NP>(Yf, lds, g.N, g.M, t, cg, re, im);
     const int u = tid >> CGS, oy = ty * T + u;
@@ -905,6 +1009,7 @@ __global__ __launch_bounds__(NP * FFT_CG_OF(NP), NP == 16 ? 8 : NP == 32 ? 4 : 2
     if (u < T && oy < g.H) {
         ifft_row_from_lds<NP>(lds, u, c, re, im);
         const int ox0 = tx * T;
+        // (pointer walks here: the buffer-descriptor form of these loads / stores measured 4 % slower, profiles/r06_fft_ab.txt)
         float* dst = y + ((size_t)(b * g.H + oy) * g.W + ox0) * ldy + cg + c;
         const float* ad = addsrc ? addsrc + ((size_t)(b * g.H + oy) * g.W + ox0) * ld_add + cg + c : nullptr;
         if (!ep_scale && act == 0 && !ad) {
@@ -1002,6 +1107,10 @@ bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
 }
 
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+inline dim3 icols_grid(const FftGeom& f, int cq_shift) {
+    const int groups = cdiv(f.M, 4 >> cq_shift), nk = f.np / 2 + 1;
+    return GDN_ICOLS_ORDER ? dim3(nk, groups) : dim3(groups, nk);
+}
 // persistent grid of cgemm_bins_kernel: four workgroups per CU, ROUNDED DOWN to a multiple of 8 (at least 8) -- the kernel's
 // mixed-radix walk takes its stride digits from gridDim.x >> 3 (a workgroup stays on one XCD's bins), so a grid that is not a
 // multiple of 8 (a part with an odd CU count) would skip or repeat units
@@ -1134,7 +1243,7 @@ extern "C" size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     if (f.flip) return 0;                  // stride-1 ConvTranspose2d: forward (inference) only
     const size_t cm = f.C > f.N ? f.C : f.N;
     const size_t padded = f.reflect ? al256((size_t)f.B * (f.H + 2 * f.pad) * (f.W + 2 * f.pad) * f.C * 4) : 0;
-    return al256((size_t)f.M * f.bins * cm * 8) + al256((size_t)f.M * f.bins * f.N * 8) +
+    return al256((size_t)f.M * fft_s_pitch(f.np, (int)cm) * 8) + al256((size_t)f.M * f.bins * f.N * 8) +
            al256((size_t)f.M * f.bins * f.C * 8) + wf_region_bytes(f) + padded;
 }
 
@@ -1149,6 +1258,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     if (dyb_y && (!dyb_co || !dyb_kk)) return GDN_ERR_BAD_ARG;
     if (!dy || (!dx && !dw) || (dx && !w && !xf) || (dw && !xf)) return GDN_ERR_BAD_ARG;
     if (dx && f.reflect && ((ldx % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
+    if (dx && f.C != 64 && f.C != 128 && f.C != 256) return GDN_ERR_UNSUPPORTED;      // (the inverse kernels index channels by shifts)
     if (dx_up2x < 0 || dx_up2x > 2 || (dx_up2x && ((g->H & 1) || (g->W & 1)))) return GDN_ERR_BAD_ARG;
     if (dx && dx_up2x && !f.reflect) return GDN_ERR_UNSUPPORTED;   // (the fold pass of a reflection layer carries the adjoint)
     if (!workspace || workspace_bytes < gdn_fftconv_bwd_workspace_bytes(g)) return GDN_ERR_WORKSPACE;
@@ -1156,7 +1266,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
     hipStream_t st = (hipStream_t)stream;
     const size_t cm = f.C > f.N ? f.C : f.N;
     char* p = (char*)workspace;
-    float2* R = (float2*)p; p += al256((size_t)f.M * f.bins * cm * 8);
+    float2* R = (float2*)p; p += al256((size_t)f.M * fft_s_pitch(f.np, (int)cm) * 8);
     float2* Df = (float2*)p; p += al256((size_t)f.M * f.bins * f.N * 8);
     float2* Ef = (float2*)p; p += al256((size_t)f.M * f.bins * f.C * 8);
     float* Wf = (float*)p; p += wf_region_bytes(f);   // weight-gradient products P (per split), or the weight spectrum when the forward saved none
@@ -1203,19 +1313,20 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         int cq_shift = 0;
         while ((64 << cq_shift) < f.C) ++cq_shift;           // C / 64 is 1, 2 or 4
         if (f.np == 16)
-            hipLaunchKernelGGL(ifft_cols_kernel<16>, dim3(cdiv(f.M, 4) << cq_shift, FFT_NK_OF(16)), dim3(256), 0, st, (const float2*)Ef, R,
+            hipLaunchKernelGGL(ifft_cols_kernel<16>, icols_grid(f, cq_shift), dim3(256), 0, st, (const float2*)Ef, R,
                                f.C, f.M, 16, cq_shift);
         else if (f.np == 40)
-            hipLaunchKernelGGL(ifft_cols_kernel<40>, dim3(cdiv(f.M, 4) << cq_shift, FFT_NK_OF(40)), dim3(256), 0, st, (const float2*)Ef, R,
+            hipLaunchKernelGGL(ifft_cols_kernel<40>, icols_grid(f, cq_shift), dim3(256), 0, st, (const float2*)Ef, R,
                                f.C, f.M, 40, cq_shift);
         else
-            hipLaunchKernelGGL(ifft_cols_kernel<32>, dim3(cdiv(f.M, 4) << cq_shift, FFT_NK_OF(32)), dim3(256), 0, st, (const float2*)Ef, R,
+            hipLaunchKernelGGL(ifft_cols_kernel<32>, icols_grid(f, cq_shift), dim3(256), 0, st, (const float2*)Ef, R,
                                f.C, f.M, 32, cq_shift);
         const int Ho = f.reflect ? f.H + 2 * f.pad : f.H, Wo = f.reflect ? f.W + 2 * f.pad : f.W;
         for (int parity = 0; parity < 2; ++parity) {
             const int ntx = (f.tiles_x + 1 - parity) / 2;
             if (ntx == 0) continue;
-            const dim3 gr(cdiv(ntx, 4) << cq_shift, Ho, f.B);
+            const bool remap = GDN_ROWS_REMAP == 1 || (GDN_ROWS_REMAP == 2 && cq_shift == 2);
+            const dim3 gr(remap ? cdiv(ntx, 4 >> cq_shift) : cdiv(ntx, 4) << cq_shift, Ho, f.B);
             float* o = f.reflect ? dxp : dx;
             const int ldo = f.reflect ? f.C : ldx, off = f.reflect ? 0 : f.pad;
             const float* ad = f.reflect ? (const float*)nullptr : addsrc;

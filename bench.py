@@ -463,7 +463,7 @@ def node_cores():
 
 def cpu_baseline(batch=20):
     """The oracle's DtoD training step on the host cores at the benchmarked batch (B = 20, the node's core count
-    stated).  Which thread count the step is timed at is MEASURED, cheaply: a batch-2 train-mode forward of the oracle at 32, 64,
+    stated).  Which thread count the step is timed at is MEASURED, cheaply: a batch-2 train-mode forward of the oracle at 16, 32, 64,
     the physical core count and every usable CPU (each bounded; torch's CPU convolutions stop scaling well before a whole
     128-core node -- r06a: 201.7 s per step at 256 threads against 11.3 s at 32), then one untimed warm-up step and one timed step
     at the fastest count.  About 40 s of host time."""
@@ -471,7 +471,7 @@ def cpu_baseline(batch=20):
     logical, physical, usable = node_cores()
     sd = O.init_state_dict("AutoEncoder_DtoD", seed=0)
     probe_x = O.synthetic_batch(2, 128, 416, seed=1)[0]
-    cands = sorted({max(1, min(usable, n)) for n in (32, 64, physical or usable, usable)})
+    cands = sorted({max(1, min(usable, n)) for n in (16, 32, 64, physical or usable, usable)})
     probe = []
     best_n, best_t = cands[0], None
     for n in cands:

@@ -896,11 +896,15 @@ extern "C" int gdn_adam_step_dev(float* p, const float* g, float* m, float* v, i
 // ---- shader-clock probe (measurement aid; include/gdn_hip.h) -----------------------------------------------------------------
 // One wave: reads the shader cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime), sleeps until the flag
 // word is set by clock_probe_set_kernel on the measured stream (or max_ticks have passed), reads both again.
+// buf must be HOST-PINNED memory mapped into the device (hipHostMalloc / a pinned torch tensor): the setter and the watcher
+// usually run on different XCDs, whose L2s are not coherent with each other for ordinary device memory inside a kernel -- an
+// agent-scope load kept hitting the watcher's own stale line (the r06 full-suite run: the watcher ran into its tick limit) and
+// polling with L2 invalidates would disturb the kernels being measured.  Host memory is uncached: every poll reads the flag.
 __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ buf, unsigned long long max_ticks) {
     if (threadIdx.x != 0) return;
     const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long r1 = r0;
-    while (__hip_atomic_load(buf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull && r1 - r0 < max_ticks) {
+    while (__hip_atomic_load(buf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0ull && r1 - r0 < max_ticks) {
         __builtin_amdgcn_s_sleep(64);
         r1 = __builtin_amdgcn_s_memrealtime();
     }
@@ -908,10 +912,10 @@ __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __r
     r1 = __builtin_amdgcn_s_memrealtime();
     buf[1] = c1 - c0;
     buf[2] = r1 - r0;
-    buf[3] = __hip_atomic_load(buf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // 1: ended by the flag, 0: by the tick limit
+    buf[3] = __hip_atomic_load(buf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // 1: ended by the flag, 0: by the tick limit
 }
 __global__ void clock_probe_set_kernel(unsigned long long* buf, unsigned long long v) {
-    __hip_atomic_store(buf, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(buf, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (v == 0ull) { buf[1] = 0ull; buf[2] = 0ull; buf[3] = 0ull; }
 }
 

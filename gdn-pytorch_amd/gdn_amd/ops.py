@@ -180,8 +180,9 @@ class ShaderClock:
             for _ in range(reps): launch()
         torch.cuda.synchronize(); clk.ghz()      # None if the watcher could not overlap the window"""
 
-    def __init__(self, device, max_s=5.0):
-        self.buf = torch.zeros(4, dtype=torch.int64, device=device)
+    def __init__(self, device, max_s=2.0):
+        # host-pinned, device-mapped: the flag is polled across XCDs whose L2s are not coherent for device memory (gdn_hip.h)
+        self.buf = torch.zeros(4, dtype=torch.int64).pin_memory()
         self.side = torch.cuda.Stream(device=device)
         self.max_ticks = int(min(max_s, 10.0) * 1e8)
 
@@ -200,7 +201,7 @@ class ShaderClock:
 
     def read(self):
         """(shader cycles, 100 MHz ticks, ended_by_flag) of the window; call after a synchronize."""
-        _, cyc, ticks, ended = [int(v) for v in self.buf.cpu().tolist()]
+        _, cyc, ticks, ended = [int(v) for v in self.buf.tolist()]
         return cyc, ticks, bool(ended)
 
     def ghz(self, min_ticks=1000):

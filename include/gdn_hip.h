@@ -543,7 +543,9 @@ int gdn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
 /* ------------------------------------------------------------------------
  * Measurement aid (no reference counterpart): the shader clock the chip holds WHILE a window of launches runs, so a
  * roofline fraction can be read against the clock of the box it was measured on (bench.py `clock_ghz`, `frac_at_clock`).
- *   buf    device memory, uint64[4]: {flag, shader cycles (s_memtime), 100 MHz ticks (s_memrealtime), ended_by_flag}
+ *   buf    HOST-PINNED memory mapped into the device (hipHostMalloc; not device memory: the setter and the watcher run on
+ *          different XCDs, whose L2s are not coherent inside a kernel), uint64[4]:
+ *          {flag, shader cycles (s_memtime), 100 MHz ticks (s_memrealtime), ended_by_flag}
  *   gdn_clock_probe_arm(buf, stream)            clears buf, stream-ordered BEFORE the measured launches;
  *   gdn_clock_probe_watch(buf, max_ticks, side) one wave on a SECOND stream of the caller's (which must wait for the arm):
  *                                               reads both counters, sleeps until the flag is set or max_ticks (<= 1e9 =

@@ -463,15 +463,15 @@ def node_cores():
 
 def cpu_baseline(batch=20):
     """The oracle's DtoD training step on the host cores at the benchmarked batch (B = 20, the node's core count
-    stated).  Which thread count the step is timed at is MEASURED, cheaply: a batch-2 train-mode forward of the oracle at 16, 32, 64,
+    stated).  Which thread count the step is timed at is MEASURED, cheaply: a batch-4 train-mode forward of the oracle at 32, 64,
     the physical core count and every usable CPU (each bounded; torch's CPU convolutions stop scaling well before a whole
     128-core node -- r06a: 201.7 s per step at 256 threads against 11.3 s at 32), then one untimed warm-up step and one timed step
     at the fastest count.  About 40 s of host time."""
     from oracle import gdn_oracle as O
     logical, physical, usable = node_cores()
     sd = O.init_state_dict("AutoEncoder_DtoD", seed=0)
-    probe_x = O.synthetic_batch(2, 128, 416, seed=1)[0]
-    cands = sorted({max(1, min(usable, n)) for n in (16, 32, 64, physical or usable, usable)})
+    probe_x = O.synthetic_batch(4, 128, 416, seed=1)[0]
+    cands = sorted({max(1, min(usable, n)) for n in (32, 64, physical or usable, usable)})
     probe = []
     best_n, best_t = cands[0], None
     for n in cands:
@@ -484,7 +484,7 @@ def cpu_baseline(batch=20):
                 ts.append(time.time() - t0)
                 if ts[-1] > 6.0:                     # already far slower than any useful setting: do not repeat it
                     break
-        probe.append({"threads": n, "batch2_forward_s": round(min(ts), 3)})
+        probe.append({"threads": n, "batch4_forward_s": round(min(ts), 3)})
         if best_t is None or min(ts) < best_t:
             best_n, best_t = n, min(ts)
         if min(ts) > 3.0 * best_t:                   # larger counts only get worse from here
@@ -501,7 +501,7 @@ def cpu_baseline(batch=20):
             "node_cores": {"logical": logical, "physical": physical, "usable_by_this_process": usable},
             "thread_probe": probe,
             "sample": "1 timed DtoD train step (fwd+loss+bwd+Adam, %.1f s) of the CPU oracle at batch %d, 128x416 fp32, after one "
-                      "untimed warm-up step (%.1f s), at the thread count a batch-2 forward probe found fastest on this node "
+                      "untimed warm-up step (%.1f s), at the thread count a batch-4 forward probe found fastest on this node "
                       "(thread_probe); the same workload as the GPU step" % (dt, batch, t1 - t0)}
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: the frequency-domain layers of the headline step on their TRAINING plans (GDN_HINT_TRAIN: 40-point tiles for 9x9 / 7x7),
 forward (+ BN partials, spectra kept) and backward (dgrad + wgrad), a few launches each -- the driver of tools/pmc_fft_r06.sh.
-usage: fft_train_kernels.py [reps]"""
+usage: fft_train_kernels.py [reps] [batch]"""
 import pathlib, sys, time
 ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "gdn-pytorch_amd"))
@@ -9,7 +9,8 @@ import torch
 from gdn_amd import ops
 dev = torch.device("cuda:0")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-for (C, k, H, W, B) in [(64, 9, 128, 416, 20), (128, 7, 64, 208, 20), (256, 5, 32, 104, 20)]:
+BB = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+for (C, k, H, W, B) in [(64, 9, 128, 416, BB), (128, 7, 64, 208, BB), (256, 5, 32, 104, BB)]:
     op = ops.Conv(C, C, k, 1, k // 2)
     x = torch.randn(B, H, W, C, device=dev)
     w = torch.randn(k * k, C, C, device=dev) * 0.02

@@ -178,25 +178,61 @@ class ShaderClock:
 
         with ops.ShaderClock(dev) as clk:
             for _ in range(reps): launch()
-        torch.cuda.synchronize(); clk.ghz()      # None if the watcher could not overlap the window"""
+        torch.cuda.synchronize(); clk.ghz()      # None if no stream was found that runs beside the current one
+
+    The watcher only works on a stream whose hardware queue is not the current stream's: HIP deals its streams onto a handful
+    of hardware queues, and a watcher that shares the queue of the stream it watches sits IN FRONT of the launches it is
+    meant to bracket (the r06 full-suite runs: the watcher ran into its tick limit after earlier tests had created a few
+    dozen streams).  So the side stream is chosen by trial -- a 1 ms watcher that must see a stop issued right behind it --
+    among a high-priority stream and up to eight fresh ones, once per (device, current stream)."""
+
+    _side = {}            # (device index, current stream handle) -> torch.cuda.Stream or None
 
     def __init__(self, device, max_s=2.0):
         # host-pinned, device-mapped: the flag is polled across XCDs whose L2s are not coherent for device memory (gdn_hip.h)
         self.buf = torch.zeros(4, dtype=torch.int64).pin_memory()
-        self.side = torch.cuda.Stream(device=device)
         self.max_ticks = int(min(max_s, 10.0) * 1e8)
+        self.device = torch.device(device)
+        self.side = self._find_side()
+
+    def _trial(self, side, ticks):
+        main = torch.cuda.current_stream(self.device)
+        self.buf.zero_()
+        lib.gdn_clock_probe_arm(self.buf.data_ptr(), main.cuda_stream)
+        side.wait_stream(main)
+        lib.gdn_clock_probe_watch(self.buf.data_ptr(), ticks, side.cuda_stream)
+        lib.gdn_clock_probe_stop(self.buf.data_ptr(), main.cuda_stream)
+        main.wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        return bool(self.buf[3].item())
+
+    def _find_side(self):
+        main = torch.cuda.current_stream(self.device)
+        key = (self.device.index or 0, main.cuda_stream)
+        if key not in ShaderClock._side:
+            found = None
+            for i in range(9):
+                cand = torch.cuda.Stream(device=self.device, priority=-1 if i == 0 else 0)
+                if self._trial(cand, 100000):            # 1 ms: ended by the flag only if it ran beside the stop
+                    found = cand
+                    break
+            ShaderClock._side[key] = found
+        return ShaderClock._side[key]
 
     def __enter__(self):
-        main = torch.cuda.current_stream()
-        lib.gdn_clock_probe_arm(self.buf.data_ptr(), main.cuda_stream)
-        self.side.wait_stream(main)
-        lib.gdn_clock_probe_watch(self.buf.data_ptr(), self.max_ticks, self.side.cuda_stream)
+        self.buf.zero_()
+        if self.side is not None:
+            main = torch.cuda.current_stream(self.device)
+            lib.gdn_clock_probe_arm(self.buf.data_ptr(), main.cuda_stream)
+            self.side.wait_stream(main)
+            lib.gdn_clock_probe_watch(self.buf.data_ptr(), self.max_ticks, self.side.cuda_stream)
         return self
 
     def __exit__(self, *exc):
-        main = torch.cuda.current_stream()
-        lib.gdn_clock_probe_stop(self.buf.data_ptr(), main.cuda_stream)
-        main.wait_stream(self.side)
+        if self.side is not None:
+            main = torch.cuda.current_stream(self.device)
+            lib.gdn_clock_probe_stop(self.buf.data_ptr(), main.cuda_stream)
+            main.wait_stream(self.side)
         return False
 
     def read(self):

@@ -551,7 +551,9 @@ def test_bench_gpus_2_self_launch_trains_two_ranks(gpu, mode, dtype):
 def test_shader_clock_probe(gpu):
     """gdn_clock_probe_*: one sleeping wave on a second stream brackets a window of launches on the current stream and returns
     shader cycles / 100 MHz ticks: a plausible engine clock (0.3-2.6 GHz on MI355X), the window at least as long as the event
-    time of the launches, and a window whose stop never comes ends by the tick limit (reported, no hang)."""
+    time of the launches; the side stream is one that really runs beside the current stream (chosen by trial: late in a long
+    pytest process a fresh stream may share the current stream's hardware queue, and a watcher there blocks what it should
+    bracket); a window whose stop never comes ends by the tick limit (reported, no hang)."""
     from gdn_amd import ops
     x = torch.randn(8, 128, 416, 64, device=gpu)
     sc, sh = torch.ones(64, device=gpu), torch.zeros(64, device=gpu)
@@ -559,8 +561,10 @@ def test_shader_clock_probe(gpu):
     for _ in range(3):
         ops.bn_apply(x, sc, sh, True, None, out=y)
     torch.cuda.synchronize()
+    junk = [torch.cuda.Stream() for _ in range(13)]          # (push the round-robin of hardware queues along)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     clk = ops.ShaderClock(gpu)
+    assert clk.side is not None, "no stream runs beside the current one"
     with clk:
         e0.record()
         for _ in range(50):
@@ -574,12 +578,14 @@ def test_shader_clock_probe(gpu):
     assert ticks * 1e-5 >= 0.9 * e0.elapsed_time(e1)                 # 100 MHz ticks -> ms
     # no stop: the watcher gives up at its tick limit (20 ms here) and says so
     clk2 = ops.ShaderClock(gpu, max_s=0.02)
+    clk2.buf.zero_()
     ops.lib.gdn_clock_probe_arm(clk2.buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
     clk2.side.wait_stream(torch.cuda.current_stream())
     ops.lib.gdn_clock_probe_watch(clk2.buf.data_ptr(), clk2.max_ticks, clk2.side.cuda_stream)
     torch.cuda.synchronize()
     cyc, ticks, ended = clk2.read()
     assert not ended and 2_000_000 <= ticks < 4_000_000 and clk2.ghz() is None
+    del junk
 
 
 def _no_error_keys(o, path=""):

@@ -1241,6 +1241,8 @@ extern "C" size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
     FftGeom f;
     if (!fft_geom(g, f)) return 0;
     if (f.flip) return 0;                  // stride-1 ConvTranspose2d: forward (inference) only
+    if (f.C != 64 && f.C != 128 && f.C != 256) return 0;   // the inverse kernels of the data gradient index channels by shifts: a
+                                                           // caller asking "is the backward supported" (ops.fft_ok) takes another path
     const size_t cm = f.C > f.N ? f.C : f.N;
     const size_t padded = f.reflect ? al256((size_t)f.B * (f.H + 2 * f.pad) * (f.W + 2 * f.pad) * f.C * 4) : 0;
     return al256((size_t)f.M * fft_s_pitch(f.np, (int)cm) * 8) + al256((size_t)f.M * f.bins * f.N * 8) +

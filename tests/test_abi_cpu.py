@@ -77,6 +77,11 @@ def test_host_queries_without_gpu(built_lib):
     assert lib.gdn_conv_dgrad_bnb_slots(ctypes.byref(ConvGeom(20, 16, 52, 512, 512, 3, 1, 1, 0, 0)), 0x10000) > 0   # bf16 ring layer
     assert lib.gdn_conv_dgrad_bnb_slots(ctypes.byref(g), 0) == 0                                                    # fp32
     assert lib.gdn_conv_dgrad_bnb_slots(ctypes.byref(ConvGeom(2, 16, 24, 64, 128, 4, 2, 1, 0, 0)), 0x10000) == 0   # stride 2
+    # frequency-domain backward: the data gradient's inverse kernels index channels by shifts (64 / 128 / 256 input channels);
+    # any other multiple of 64 is forward-only and the workspace query says so (ops.fft_ok then picks another path)
+    f64, f192 = ConvGeom(2, 32, 64, 64, 64, 5, 1, 2, 0, 0), ConvGeom(2, 32, 64, 192, 192, 5, 1, 2, 0, 0)
+    assert lib.gdn_fftconv_spectrum_bytes(ctypes.byref(f64)) > 0 and lib.gdn_fftconv_bwd_workspace_bytes(ctypes.byref(f64)) > 0
+    assert lib.gdn_fftconv_spectrum_bytes(ctypes.byref(f192)) > 0 and lib.gdn_fftconv_bwd_workspace_bytes(ctypes.byref(f192)) == 0
 
 
 def test_models_match_oracle_init_and_keys():

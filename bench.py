@@ -209,7 +209,8 @@ def fftconv_roofline(dev, B, reps=10):
                 "note": "the same layer as the training step runs it (GDN_HINT_TRAIN: 4 x 13 tiles of 32 valid outputs, 26 % fewer "
                         "spectrum bytes and GEMM rows): fewer bytes in less time -- the byte rate falls, the layer gets faster",
                 "fwd_ms": round(tf, 4), "fwd_bytes": tby_f, "fwd_achieved": round(tby_f / tf / 1e6, 1),
-                "bwd_ms": round(tb, 4), "bwd_bytes": tby_b, "bwd_achieved": round(tby_b / tb / 1e6, 1)}}
+                "bwd_ms": round(tb, 4), "bwd_bytes": tby_b, "bwd_achieved": round(tby_b / tb / 1e6, 1),
+                "fwd_traffic": fft_train_fwd_traffic()}}
 
 
 def cgemm_roofline(dev, B, reps=20):
@@ -459,6 +460,21 @@ def node_cores():
     except OSError:
         pass
     return logical, physical, usable
+
+
+def fft_train_fwd_traffic():
+    """L2 -> fabric bytes of the three forward kernels of the 9x9 64->64 layer on its training plan (fft2d_fwd<40>, cgemm_bins<false>,
+    ifft2d_valid<40>; B = 20) from the committed PMC passes (profiles/r06_fft_pmc.json; FETCH_SIZE doubled per the gfx950
+    correction + WRITE_SIZE); None if absent."""
+    try:
+        d = json.loads((ROOT / "profiles" / "r06_fft_pmc.json").read_text())["kernels"]
+        tot = 0.0
+        for k, v in d.items():
+            if k.startswith(("fft2d_fwd_kernel<40>", "ifft2d_valid_kernel<40>", "cgemm_bins_kernel<false>")):
+                tot += v["fetch_bytes"] + v["write_bytes"]
+        return int(tot) or None
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def cpu_baseline(batch=20):

@@ -43,6 +43,9 @@ static_assert(FFT_BINS_OF(32) % 8 == 0 && FFT_BINS_OF(16) % 8 == 0 && FFT_BINS_O
 #ifndef GDN_ICOLS_ORDER
 #define GDN_ICOLS_ORDER 1    // ifft_cols grid: 0: blockIdx.x = tile group, y = kx;  1: blockIdx.x = kx (fastest), y = tile group
 #endif
+#ifndef GDN_FFT_DGRAD_PATCH
+#define GDN_FFT_DGRAD_PATCH 1  // data gradient's inverse: 1 = single-pass inverse into a patch buffer + gather (overlap-add), 0 = ifft_cols + two
+#endif                         //                           ordered ifft_rows_overlap launches through the intermediate S (rounds 1-5)
 #ifndef GDN_ROWS_REMAP
 #define GDN_ROWS_REMAP 2     // ifft_rows_overlap: 0 = 4 tiles x 64-channel chunk, 1 = (256 / C) tiles x all channels, 2 = 1 only for C = 256
 #endif
@@ -239,6 +242,14 @@ __device__ __forceinline__ float tw_sin_r(int idx) { return NP == 40 ? kSin40[id
 
 // pitch (complex elements) of one tile of the column-inverse intermediate S[t][u][kx][c]
 __host__ __device__ inline size_t fft_s_pitch(int np, int C) { return (size_t)np * (np / 2 + 1) * C; }
+
+// Layout of the data gradient's patch buffer, in floats: a patch row of np pixels x C channels is followed by 64 floats (256 bytes)
+// of padding and a tile of np rows by 64 more.  Dense, every stride is a power of two times np (16 KB rows, 512 KB tiles on the
+// 7x7 / 128-channel layers) and all workgroups of the chip, which walk their columns in step, write into the same few memory
+// channels: ifft2d_patch<32> ran at 1.5 TB/s (351 us against 94 us of ifft2d_valid<32> for 1.5 x the bytes).  With the padding
+// both strides are odd multiples of 256 bytes.  Fits the region the intermediate S occupies (32 (np + 1) <= np C).
+__host__ __device__ inline size_t fft_patch_row(int np, int C) { return (size_t)np * C + 64; }
+__host__ __device__ inline size_t fft_patch_tile(int np, int C) { return (size_t)np * fft_patch_row(np, C) + 64; }
 
 struct FftGeom {
     int np, bins;                // tile size (32 / 16), kept bins = np * (np/2 + 1)
@@ -1071,6 +1082,72 @@ __global__ __launch_bounds__(NP * FFT_CG_OF(NP), NP == 16 ? 8 : NP == 32 ? 4 : 2
     }
 }
 
+// ---- data gradient, round 6: single-pass inverse into a PATCH buffer + gather ------------------------------------------------
+// The two-kernel inverse (ifft_cols -> S -> ifft_rows_overlap x 2) moves the 447 MB intermediate S out and back in, and its column
+// pass runs at 1.8-2.6 TB/s (profiles/r06_fft_pmc.json).  Inside a training step the backward is HBM-throughput-bound (running the
+// weight-gradient chain beside the data-gradient chain returns 0.3 ms of its 6.8: the memory is saturated either way), so bytes are
+// what count.  Here the tile's whole NP x NP patch of dx contributions is produced in one pass (inverse columns -> LDS -> Hermitian
+// inverse rows, like ifft2d_valid) and written to patch[tile][u][v][C] -- no two tiles write the same address, so ONE launch and no
+// read-modify-write -- and a streaming gather sums the <= 4 patches that cover an output pixel in a fixed order (+ addsrc).
+// Bytes per 9x9 layer at B = 20: 447 (E) + 426 (patch) written once and read once + 272 (addsrc) + 272 (dx) = 1.84 GB against ~2.5.
+template <int NP>
+__global__ __launch_bounds__(NP * FFT_CG_OF(NP), NP == 16 ? 8 : NP == 32 ? 4 : 2) void ifft2d_patch_kernel(const float2* __restrict__ Ef, float* __restrict__ patch,
+                                                                                                              FftGeom g, int Ho, int Wo, int off) {
+    constexpr int CG = FFT_CG_OF(NP), CGS = CG == 8 ? 3 : 4;
+    __shared__ float2 lds[FFT_LDS_ELEMS_OF(NP)];
+    const int ngrp = g.C / CG, tpx = (g.M + 7) / 8;          // XCD-aware order as in fft2d_fwd_kernel
+    const int tid = threadIdx.x, c = tid & (CG - 1), cg = GDN_UNI(((blockIdx.x >> 3) % ngrp) * CG);
+    const int t = GDN_UNI((blockIdx.x & 7) * tpx + (blockIdx.x >> 3) / ngrp);
+    if (t >= g.M) return;
+    const int tx = GDN_UNI(t % g.tiles_x), ty = GDN_UNI((t / g.tiles_x) % g.tiles_y);
+    float re[NP], im[NP];
+    ifft2d_cols_to_lds<NP>(Ef, lds, g.C, g.M, t, cg, re, im);
+    const int u = tid >> CGS, iy = ty * g.T - off + u;
+    if (iy < 0 || iy >= Ho) return;                          // (after the barrier inside ifft2d_cols_to_lds: no later one)
+    ifft_row_from_lds<NP>(lds, u, c, re, im);
+    const int ix0 = tx * g.T - off;
+    float* dst = patch + (size_t)t * fft_patch_tile(NP, g.C) + (size_t)u * fft_patch_row(NP, g.C) + cg + c;
+#pragma unroll
+    for (int v = 0; v < NP; ++v) {
+        if (ix0 + v >= 0 && ix0 + v < Wo) *dst = re[v] * (1.0f / (NP * NP));      // (uniform bound: a scalar branch)
+        dst += g.C; GDN_KEEP(dst);
+    }
+}
+
+// dx[b][y][x][c] = (patch of the tile whose rows / columns start at or before the pixel) + (the previous tile's, where its k - 1
+// trailing rows / columns reach the pixel), rows first, in that fixed order, + addsrc.  grid: x = pixels-of-a-row x C / 4, y = row,
+// z = image; a thread owns four channels of one pixel.
+__global__ __launch_bounds__(256) void fft_overlap_gather_kernel(const float* __restrict__ patch, float* __restrict__ dx, int lddx,
+                                                                 const float* __restrict__ addsrc, int ld_add, FftGeom g, int np,
+                                                                 int Ho, int Wo, int off, int c4_shift) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int x = i >> c4_shift, c4 = i & ((1 << c4_shift) - 1);
+    if (x >= Wo) return;
+    const int y = blockIdx.y, b = blockIdx.z, T = g.T, C = g.C;
+    const int qy = y + off, qx = x + off;
+    const int tya = qy / T, ja = qy - tya * T, txa = qx / T, ia = qx - txa * T;
+    // candidate rows: (tile row, patch row); candidate columns likewise
+    const bool ya = tya < g.tiles_y, yb = tya >= 1 && ja + T < np;
+    const bool xa = txa < g.tiles_x, xb = txa >= 1 && ia + T < np;
+    const size_t ttile = fft_patch_tile(np, C), trow = fft_patch_row(np, C);      // floats per tile / per patch row (padded)
+    const float* base = patch + (size_t)b * g.tiles_y * g.tiles_x * ttile + (size_t)c4 * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    auto at = [&](int ty, int j, int tx, int ii) {
+        return *reinterpret_cast<const f32x4*>(base + ((size_t)ty * g.tiles_x + tx) * ttile + (size_t)j * trow + (size_t)ii * C);
+    };
+    if (ya) {
+        if (xa) s += at(tya, ja, txa, ia);
+        if (xb) s += at(tya, ja, txa - 1, ia + T);
+    }
+    if (yb) {
+        if (xa) s += at(tya - 1, ja + T, txa, ia);
+        if (xb) s += at(tya - 1, ja + T, txa - 1, ia + T);
+    }
+    const size_t px = ((size_t)b * Ho + y) * Wo + x;
+    if (addsrc) s += *reinterpret_cast<const f32x4*>(addsrc + px * ld_add + c4 * 4);
+    *reinterpret_cast<f32x4*>(dx + px * lddx + c4 * 4) = s;
+}
+
 bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
     if (!g || g->stride != 1 || g->k < 3 || g->k > 9 || (g->k & 1) == 0) return false;
     if (g->pad != g->k / 2 || (g->transposed && g->pad_mode != 0)) return false;
@@ -1311,6 +1388,22 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         const int nu = cdiv(f.M, 64) * (f.C / 64) * f.bins;
         hipLaunchKernelGGL(cgemm_bins_kernel<true>, dim3(cgemm_grid(nu)), dim3(256), 0, st,
                            (const float*)Df, Wsaved ? Wsaved : (const float*)Wf, (float*)Ef, f.M, f.C, f.N, nu);
+        const int Ho = f.reflect ? f.H + 2 * f.pad : f.H, Wo = f.reflect ? f.W + 2 * f.pad : f.W;
+        float* o = f.reflect ? dxp : dx;
+        const int ldo = f.reflect ? f.C : ldx, off = f.reflect ? 0 : f.pad;
+        const float* ad = f.reflect ? (const float*)nullptr : addsrc;
+        if (GDN_FFT_DGRAD_PATCH && (ldo % 4) == 0 && (!ad || (ld_add % 4) == 0)) {
+            // single-pass inverse of every tile into its own patch (the region S used to occupy), then the gather
+            float* patch = (float*)R;
+            const dim3 gp(f.C / FFT_CG_OF(f.np) * 8 * cdiv(f.M, 8)), bp(f.np * FFT_CG_OF(f.np));
+            if (f.np == 16) hipLaunchKernelGGL(ifft2d_patch_kernel<16>, gp, bp, 0, st, (const float2*)Ef, patch, f, Ho, Wo, off);
+            else if (f.np == 40) hipLaunchKernelGGL(ifft2d_patch_kernel<40>, gp, bp, 0, st, (const float2*)Ef, patch, f, Ho, Wo, off);
+            else hipLaunchKernelGGL(ifft2d_patch_kernel<32>, gp, bp, 0, st, (const float2*)Ef, patch, f, Ho, Wo, off);
+            int c4_shift = 4;                                    // log2(C / 4): C is 64, 128 or 256
+            while ((4 << c4_shift) < f.C) ++c4_shift;
+            hipLaunchKernelGGL(fft_overlap_gather_kernel, dim3(cdiv(Wo << c4_shift, 256), Ho, f.B), dim3(256), 0, st, (const float*)patch, o, ldo,
+                               ad, ld_add, f, f.np, Ho, Wo, off, c4_shift);
+        } else {
         // inverse along ky into S, then rows: the tile rows that reach an image row are summed in the frequency domain
         int cq_shift = 0;
         while ((64 << cq_shift) < f.C) ++cq_shift;           // C / 64 is 1, 2 or 4
@@ -1323,15 +1416,11 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         else
             hipLaunchKernelGGL(ifft_cols_kernel<32>, icols_grid(f, cq_shift), dim3(256), 0, st, (const float2*)Ef, R,
                                f.C, f.M, 32, cq_shift);
-        const int Ho = f.reflect ? f.H + 2 * f.pad : f.H, Wo = f.reflect ? f.W + 2 * f.pad : f.W;
         for (int parity = 0; parity < 2; ++parity) {
             const int ntx = (f.tiles_x + 1 - parity) / 2;
             if (ntx == 0) continue;
             const bool remap = GDN_ROWS_REMAP == 1 || (GDN_ROWS_REMAP == 2 && cq_shift == 2);
             const dim3 gr(remap ? cdiv(ntx, 4 >> cq_shift) : cdiv(ntx, 4) << cq_shift, Ho, f.B);
-            float* o = f.reflect ? dxp : dx;
-            const int ldo = f.reflect ? f.C : ldx, off = f.reflect ? 0 : f.pad;
-            const float* ad = f.reflect ? (const float*)nullptr : addsrc;
             if (f.np == 16)
                 hipLaunchKernelGGL(ifft_rows_overlap_kernel<16>, gr, dim3(256), 0, st, (const float2*)R, o, ldo, ad, ld_add, f, parity, Ho,
                                    Wo, off, cq_shift);
@@ -1341,6 +1430,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
             else
                 hipLaunchKernelGGL(ifft_rows_overlap_kernel<32>, gr, dim3(256), 0, st, (const float2*)R, o, ldo, ad, ld_add, f, parity, Ho,
                                    Wo, off, cq_shift);
+        }
         }
         if (f.reflect && dx_up2x)
             // dx is the gradient of the LOW-resolution tensor the forward upsampled on load: fold + adjoint interpolation

@@ -12,7 +12,7 @@ for v in main "$@"; do
     bash $R/tools/prof_diag.sh abfft_${v}_$rep tests/diag/fft_train_kernels.py 10 > /dev/null 2>&1
     echo "=== $v (run $rep)" >> $out
     cat $R/gpurun_out/prof_diag_abfft_${v}_$rep/stdout.txt >> $out
-    grep -E "fft2d|ifft" $R/gpurun_out/prof_diag_abfft_${v}_$rep/by_kernel_and_grid.txt | awk '{printf "%-44s %-14s %5s %9s\n", $1" "$2, $3, $4, $5}' >> $out
+    grep -E "fft2d|ifft|gather" $R/gpurun_out/prof_diag_abfft_${v}_$rep/by_kernel_and_grid.txt | awk '{printf "%-44s %-14s %5s %9s\n", $1" "$2, $3, $4, $5}' >> $out
   done
 done
 cat $out

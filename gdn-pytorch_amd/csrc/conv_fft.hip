@@ -1115,37 +1115,88 @@ __global__ __launch_bounds__(NP * FFT_CG_OF(NP), NP == 16 ? 8 : NP == 32 ? 4 : 2
 }
 
 // dx[b][y][x][c] = (patch of the tile whose rows / columns start at or before the pixel) + (the previous tile's, where its k - 1
-// trailing rows / columns reach the pixel), rows first, in that fixed order, + addsrc.  grid: x = pixels-of-a-row x C / 4, y = row,
-// z = image; a thread owns four channels of one pixel.
+// trailing rows / columns reach the pixel), rows first, in that fixed order, + addsrc.  A workgroup walks image rows r = b Ho + y
+// (r = blockIdx.x, + gridDim.x, ...); a thread owns four channels (fixed) of every (256 / (C / 4))-th pixel of the row; the tile /
+// patch-column of every x is tabulated once per workgroup in LDS (no division per pixel).
+// bnb_y != NULL: dx is the final gradient of z = [relu](BN_train(bnb_y)) (this layer's input): the workgroup also emits that
+// BatchNorm's backward partial sums (sum dz, sum dz * xhat; bnb_co = {scale, shift, mean, invstd}[C]) into bnb_part[blockIdx.x][2][C]
+// -- the values are in registers here, so the stand-alone reduce pass over (dx, y) (bn_bwd_reduce: two tensor reads) becomes one
+// read of y.  Fixed order everywhere: a thread's pixels in sequence, the threads of a channel group in index order.
+constexpr int FFT_GATHER_MAX_W = 1024;       // widest output row the x table holds (wider rows: gdn_fftconv_bwd takes the two-kernel inverse)
+constexpr int FFT_GATHER_MAX_BLOCKS = 8192;  // workgroups (= BatchNorm-backward partial slots) of one gather launch
 __global__ __launch_bounds__(256) void fft_overlap_gather_kernel(const float* __restrict__ patch, float* __restrict__ dx, int lddx,
                                                                  const float* __restrict__ addsrc, int ld_add, FftGeom g, int np,
-                                                                 int Ho, int Wo, int off, int c4_shift) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int x = i >> c4_shift, c4 = i & ((1 << c4_shift) - 1);
-    if (x >= Wo) return;
-    const int y = blockIdx.y, b = blockIdx.z, T = g.T, C = g.C;
-    const int qy = y + off, qx = x + off;
-    const int tya = qy / T, ja = qy - tya * T, txa = qx / T, ia = qx - txa * T;
-    // candidate rows: (tile row, patch row); candidate columns likewise
-    const bool ya = tya < g.tiles_y, yb = tya >= 1 && ja + T < np;
-    const bool xa = txa < g.tiles_x, xb = txa >= 1 && ia + T < np;
+                                                                 int Ho, int Wo, int off, int c4_shift,
+                                                                 const float* __restrict__ bnb_y, int ld_bnb,
+                                                                 const float* __restrict__ bnb_co, int bnb_relu,
+                                                                 float* __restrict__ bnb_part) {
+    __shared__ int xinfo[FFT_GATHER_MAX_W];
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x, c4n = 1 << c4_shift, c4 = tid & (c4n - 1), xl = tid >> c4_shift, xstep = 256 >> c4_shift;
+    const int T = g.T, C = g.C;
+    for (int x = tid; x < Wo; x += 256) {
+        const int qx = x + off, txa = qx / T;
+        xinfo[x] = (txa << 8) | (qx - txa * T);              // (patch column < T <= 36, tile column < 2^23)
+    }
+    __syncthreads();
+    f32x4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmu = bsc, bis = bsc;
+    if (bnb_y) {
+        bsc = *reinterpret_cast<const f32x4*>(bnb_co + c4 * 4);
+        bsh = *reinterpret_cast<const f32x4*>(bnb_co + C + c4 * 4);
+        bmu = *reinterpret_cast<const f32x4*>(bnb_co + 2 * C + c4 * 4);
+        bis = *reinterpret_cast<const f32x4*>(bnb_co + 3 * C + c4 * 4);
+    }
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
     const size_t ttile = fft_patch_tile(np, C), trow = fft_patch_row(np, C);      // floats per tile / per patch row (padded)
-    const float* base = patch + (size_t)b * g.tiles_y * g.tiles_x * ttile + (size_t)c4 * 4;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    auto at = [&](int ty, int j, int tx, int ii) {
-        return *reinterpret_cast<const f32x4*>(base + ((size_t)ty * g.tiles_x + tx) * ttile + (size_t)j * trow + (size_t)ii * C);
-    };
-    if (ya) {
-        if (xa) s += at(tya, ja, txa, ia);
-        if (xb) s += at(tya, ja, txa - 1, ia + T);
+    const int nrows = g.B * Ho;
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const int b = r / Ho, y = r - b * Ho;
+        const int qy = y + off, tya = qy / T, ja = qy - tya * T;
+        const bool ya = tya < g.tiles_y, yb = tya >= 1 && ja + T < np;           // candidate tile rows (uniform)
+        const float* base = patch + (size_t)b * g.tiles_y * g.tiles_x * ttile + (size_t)c4 * 4;
+        const float* rowa = base + (size_t)tya * g.tiles_x * ttile + (size_t)ja * trow;
+        const float* rowb = base + (size_t)(tya - 1) * g.tiles_x * ttile + (size_t)(ja + T) * trow;
+        for (int x = xl; x < Wo; x += xstep) {
+            const int info = xinfo[x], txa = info >> 8, ia = info & 255;
+            const bool xa = txa < g.tiles_x, xb = txa >= 1 && ia + T < np;
+            const size_t oa = (size_t)txa * ttile + (size_t)ia * C, ob = (size_t)(txa - 1) * ttile + (size_t)(ia + T) * C;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if (ya) {
+                if (xa) s += *reinterpret_cast<const f32x4*>(rowa + oa);
+                if (xb) s += *reinterpret_cast<const f32x4*>(rowa + ob);
+            }
+            if (yb) {
+                if (xa) s += *reinterpret_cast<const f32x4*>(rowb + oa);
+                if (xb) s += *reinterpret_cast<const f32x4*>(rowb + ob);
+            }
+            const size_t px = (size_t)r * Wo + x;
+            if (addsrc) s += *reinterpret_cast<const f32x4*>(addsrc + px * ld_add + c4 * 4);
+            *reinterpret_cast<f32x4*>(dx + px * lddx + c4 * 4) = s;
+            if (bnb_y) {
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(bnb_y + px * ld_bnb + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dz = (bnb_relu && !(yv[e] * bsc[e] + bsh[e] > 0.f)) ? 0.f : s[e];
+                    s1[e] += dz;
+                    s2[e] += dz * ((yv[e] - bmu[e]) * bis[e]);
+                }
+            }
+        }
     }
-    if (yb) {
-        if (xa) s += at(tya - 1, ja + T, txa, ia);
-        if (xb) s += at(tya - 1, ja + T, txa - 1, ia + T);
+    if (bnb_part) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[tid * 8 + e] = s1[e]; red[tid * 8 + 4 + e] = s2[e]; }
+        __syncthreads();
+        if (tid < c4n) {
+            f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
+            for (int k = 0; k < xstep; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a1[e] += red[(k * c4n + tid) * 8 + e]; a2[e] += red[(k * c4n + tid) * 8 + 4 + e]; }
+            float* dst = bnb_part + (size_t)blockIdx.x * 2 * C + tid * 4;
+            *reinterpret_cast<f32x4*>(dst) = a1;
+            *reinterpret_cast<f32x4*>(dst + C) = a2;
+        }
     }
-    const size_t px = ((size_t)b * Ho + y) * Wo + x;
-    if (addsrc) s += *reinterpret_cast<const f32x4*>(addsrc + px * ld_add + c4 * 4);
-    *reinterpret_cast<f32x4*>(dx + px * lddx + c4 * 4) = s;
 }
 
 bool fft_geom(const gdn_conv_geom* g, FftGeom& f) {
@@ -1326,15 +1377,33 @@ extern "C" size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g) {
            al256((size_t)f.M * f.bins * f.C * 8) + wf_region_bytes(f) + padded;
 }
 
+// workgroups of the data gradient's gather pass = slots of the BatchNorm-backward partial sums it can emit (0: not available:
+// reflection-padded layers finish their gradient in the fold pass, and rows wider than the gather's x table take the old inverse)
+static int fft_gather_blocks(const FftGeom& f) {
+    if (!GDN_FFT_DGRAD_PATCH || f.reflect || f.W > FFT_GATHER_MAX_W) return 0;
+    const int64_t rows = (int64_t)f.B * f.H;
+    return (int)(rows < FFT_GATHER_MAX_BLOCKS ? rows : FFT_GATHER_MAX_BLOCKS);
+}
+extern "C" int64_t gdn_fftconv_bnb_slots(const gdn_conv_geom* g) {
+    FftGeom f;
+    if (!fft_geom(g, f) || f.flip) return 0;
+    if (f.C != 64 && f.C != 128 && f.C != 256) return 0;
+    return fft_gather_blocks(f);
+}
+
 extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w, const void* xf,
                                float* dx, int32_t ldx, const float* addsrc, int32_t ld_add, float* dw,
                                const float* dyb_y, int32_t ld_dyb, const float* dyb_co,
-                               const float* dyb_kk, int32_t dyb_relu, int32_t dx_up2x, int32_t phases, void* workspace,
+                               const float* dyb_kk, int32_t dyb_relu,
+                               const float* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu, float* bnb_partial,
+                               int32_t dx_up2x, int32_t phases, void* workspace,
                                size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
     FftGeom f;
     if (!fft_geom(g, f) || f.flip) return GDN_ERR_UNSUPPORTED;
     if (dyb_y && (!dyb_co || !dyb_kk)) return GDN_ERR_BAD_ARG;
+    if (bnb_y && (!dx || !bnb_co || !bnb_partial || (ld_bnb % 4))) return GDN_ERR_BAD_ARG;
+    if (bnb_y && (fft_gather_blocks(f) == 0 || (ldx % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
     if (!dy || (!dx && !dw) || (dx && !w && !xf) || (dw && !xf)) return GDN_ERR_BAD_ARG;
     if (dx && f.reflect && ((ldx % 4) || (addsrc && (ld_add % 4)))) return GDN_ERR_UNSUPPORTED;
     if (dx && f.C != 64 && f.C != 128 && f.C != 256) return GDN_ERR_UNSUPPORTED;      // (the inverse kernels index channels by shifts)
@@ -1392,7 +1461,7 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
         float* o = f.reflect ? dxp : dx;
         const int ldo = f.reflect ? f.C : ldx, off = f.reflect ? 0 : f.pad;
         const float* ad = f.reflect ? (const float*)nullptr : addsrc;
-        if (GDN_FFT_DGRAD_PATCH && (ldo % 4) == 0 && (!ad || (ld_add % 4) == 0)) {
+        if (GDN_FFT_DGRAD_PATCH && (ldo % 4) == 0 && (!ad || (ld_add % 4) == 0) && Wo <= FFT_GATHER_MAX_W) {
             // single-pass inverse of every tile into its own patch (the region S used to occupy), then the gather
             float* patch = (float*)R;
             const dim3 gp(f.C / FFT_CG_OF(f.np) * 8 * cdiv(f.M, 8)), bp(f.np * FFT_CG_OF(f.np));
@@ -1401,8 +1470,10 @@ extern "C" int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t 
             else hipLaunchKernelGGL(ifft2d_patch_kernel<32>, gp, bp, 0, st, (const float2*)Ef, patch, f, Ho, Wo, off);
             int c4_shift = 4;                                    // log2(C / 4): C is 64, 128 or 256
             while ((4 << c4_shift) < f.C) ++c4_shift;
-            hipLaunchKernelGGL(fft_overlap_gather_kernel, dim3(cdiv(Wo << c4_shift, 256), Ho, f.B), dim3(256), 0, st, (const float*)patch, o, ldo,
-                               ad, ld_add, f, f.np, Ho, Wo, off, c4_shift);
+            const int64_t rows = (int64_t)f.B * Ho;
+            const int gb = (int)(rows < FFT_GATHER_MAX_BLOCKS ? rows : FFT_GATHER_MAX_BLOCKS);      // (= fft_gather_blocks(f) when bnb_y)
+            hipLaunchKernelGGL(fft_overlap_gather_kernel, dim3(gb), dim3(256), 0, st, (const float*)patch, o, ldo,
+                               ad, ld_add, f, f.np, Ho, Wo, off, c4_shift, bnb_y, ld_bnb, bnb_co, bnb_relu, bnb_partial);
         } else {
         // inverse along ky into S, then rows: the tile rows that reach an image row are summed in the frequency domain
         int cq_shift = 0;

@@ -939,7 +939,7 @@ extern "C" int gdn_clock_probe_stop(uint64_t* buf, void* stream) {
     return gdn_launch_status();
 }
 
-extern "C" int gdn_version(void) { return 221; }
+extern "C" int gdn_version(void) { return 222; }
 
 extern "C" const char* gdn_strerror(int status) {
     switch (status) {

@@ -48,7 +48,9 @@ _SIGS = {
     "gdn_fftconv_stats_slots": (_i64, [_PG]),
     "gdn_fftconv_fwd": (c_int32, [_PG, _P, _i32, _P, _P, _i32, _P, _i32, _P, _P, _P, _i32, _P, _P, _i32, _i32, _P, _P, _sz, _P]),
     "gdn_fftconv_bwd_workspace_bytes": (_sz, [_PG]),
-    "gdn_fftconv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _P, _i32, _P, _i32, _P, _P, _i32, _P, _P, _i32, _i32, _i32, _P, _sz, _P]),
+    "gdn_fftconv_bwd": (c_int32, [_PG, _P, _i32, _P, _P, _P, _i32, _P, _i32, _P, _P, _i32, _P, _P, _i32, _P, _i32, _P, _i32, _P,
+                                  _i32, _i32, _P, _sz, _P]),
+    "gdn_fftconv_bnb_slots": (_i64, [_PG]),
     "gdn_fftconv_cgemm_workspace_bytes": (_sz, [_PG]),
     "gdn_fftconv_cgemm": (c_int32, [_PG, _i32, _P, _sz, _P]),
     "gdn_fftconv_cgemm_shape": (c_int32, [_PG, _P, _P, _P]),
@@ -119,7 +121,7 @@ _STATUS_FUNCS = {n for n, (r, _) in _SIGS.items() if r is c_int32} - {"gdn_versi
 EXPORTS = tuple(_SIGS)
 # The C ABI revision these signatures (and ConvGeom's layout) describe: gdn_version() of the library must match exactly --
 # a stale build would take the arguments apart differently.
-ABI_VERSION = 221
+ABI_VERSION = 222
 
 
 class _Lib:

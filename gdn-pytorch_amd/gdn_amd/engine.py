@@ -25,7 +25,7 @@ _WINOGRAD = os.environ.get("GDN_WINOGRAD", "1") != "0"
 _FUSE_TRAIN_BN = os.environ.get("GDN_FUSE_TRAIN_BN", "1") != "0"
 # per-site A/B switches of that fusion (measurement; all on by default unless a site measured slower)
 _FUSE = {k: os.environ.get("GDN_FUSE_" + k.upper(), d) != "0" for k, d in
-         (("fft_in", "1"), ("fft_dyb", "1"), ("wino_in", "1"), ("wino_bnb", "1"), ("ring_bnb", "1"))}
+         (("fft_in", "1"), ("fft_dyb", "1"), ("fft_bnb", "1"), ("wino_in", "1"), ("wino_bnb", "1"), ("ring_bnb", "1"))}
 # fp32 4x4 stride-2 pad-1 Conv2d / ConvTranspose2d layers run as Winograd F(3x3,2x2) over the polyphase images
 # (csrc/conv_wino2.hip) when both channel counts reach this value (0 disables): the transforms move ~1.8x the
 # layer's activations (measured: a gain on every such layer of G, the smallest at 64 channels, tests/diag/wino2_time.py)
@@ -566,7 +566,10 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
     # the transform-domain paths share one call shape: forward (+ saved state), backward from that state
     alt_fwd = op.fft_fwd if use_fft else op.wino_fwd if use_wino else op.wino2_fwd if use_wino2 else None
     alt_bwd = op.fft_bwd if use_fft else op.wino_bwd if use_wino else op.wino2_bwd if use_wino2 else None
-    bnb_slots = op.wino_bnb_slots if use_wino else (lambda *a: 0)      # (fft / wino2 epilogues do not emit them)
+    # slots of the producer BatchNorm's backward partials the data-gradient pass can emit (wino2 epilogues do not emit them)
+    bnb_slots = (op.wino_bnb_slots if use_wino
+                 else (lambda B_, H_, W_: op.fft_bnb_slots(B_, H_, W_, train=fft_train)) if (use_fft and not use_wino2 and _FUSE["fft_bnb"])
+                 else (lambda *a: 0))
     state_kw = "spectrum" if use_fft else "state"
     bstate_kw = "xf" if use_fft else "state"
     use_fft_only = use_fft
@@ -683,7 +686,8 @@ def conv_bn_act(ctx, x, conv, bn, relu, residual=None, x2=None, reflect=0, need_
                         raise GdnError("weight.grad is not tap-major")
                 if gv is not None or want_dx:
                     bnb = None
-                    if xin is not None and want_dx and xin.y.dtype == torch.float32 and _FUSE["wino_bnb"]:
+                    if (xin is not None and want_dx and xin.y.dtype == torch.float32
+                            and _FUSE["fft_bnb" if use_fft_only else "wino_bnb"]):
                         # x = [relu](BN_train(xin.y)) and this data gradient is its final gradient: emit the producer's
                         # BatchNorm-backward partial sums from the epilogue that writes dx
                         slots = bnb_slots(x.shape[0], x.shape[1], x.shape[2])

@@ -414,14 +414,22 @@ class Conv:
         _, ref, _, _ = self.geom(B, H, W)
         return int(lib.gdn_winoconv_bnb_slots(ref))
 
-    def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None, dyb=None, up2x=0, train=False):
+    def fft_bnb_slots(self, B, H, W, train=False):
+        """Slots of the BatchNorm-backward partial sums fft_bwd's data-gradient gather can emit (`bnb`); 0: not available."""
+        _, ref, _, _ = self.geom(B, H, W, 1 if train else 0)
+        return int(lib.gdn_fftconv_bnb_slots(ref))
+
+    def fft_bwd(self, dy, w_tap, in_hw, xf=None, dw_tap=None, need_dx=True, addsrc=None, dyb=None, up2x=0, train=False,
+                bnb=None):
         """Data gradient (returned; + addsrc) and / or weight gradient (into dw_tap, needs the forward's saved state xf:
         input + weight spectra) from one transform of dy.  w_tap is the FORWARD tap-major weight [k*k, Cout, Cin]; it is
         only read when xf is None.
         dyb = (y_raw, coeffs[4,Cout], kk[2,Cout], relu): `dy` is dout of THIS layer's train-mode BatchNorm; the dy transform
         applies scale*(dz - k1 - xhat*k2) while loading (kk from bn_bwd_coeffs).
         up2x: the forward upsampled a low-resolution x on load; dx (and addsrc) are that tensor's gradient [B,H/2,W/2,Cin]
-        (in_hw stays the convolution's input extent)."""
+        (in_hw stays the convolution's input extent).
+        bnb = (y_in, coeffs[4,Cin], relu, partial[fft_bnb_slots,2,Cin]): dx is the final gradient of this layer's input
+        [relu](BN_train(y_in)); the pass that writes dx fills `partial` with that BatchNorm's backward sums (bn_bwd `partial`)."""
         _chk(dy, "dy")
         B = dy.shape[0]
         H, W = in_hw
@@ -429,6 +437,10 @@ class Conv:
         nb = int(lib.gdn_fftconv_bwd_workspace_bytes(ref))
         if nb == 0:
             raise GdnError("fftconv: unsupported layer k=%d stride=%d" % (self.k, self.stride))
+        by, bco, brelu, bpart = bnb if (bnb is not None and need_dx) else (None, None, False, None)
+        if bpart is not None and (bpart.dtype != torch.float32 or not bpart.is_contiguous()
+                                  or tuple(bpart.shape) != (int(lib.gdn_fftconv_bnb_slots(ref)), 2, self.cin)):
+            raise GdnError("fft_bwd: bnb partial must be a dense float32 [%d, 2, %d]" % (int(lib.gdn_fftconv_bnb_slots(ref)), self.cin))
         if tuple(dy.shape[1:]) != (Ho, Wo, self.cout):
             raise GdnError("fft_bwd: dy shape %s does not match layer output" % (tuple(dy.shape),))
         dx = torch.empty((B, H // 2, W // 2, self.cin) if up2x else (B, H, W, self.cin), dtype=torch.float32,
@@ -440,6 +452,7 @@ class Conv:
             lib.gdn_fftconv_bwd(ref, _p(dy), _ld(dy), _p(w_tap), _p(xf), _p(dx),
                                 0 if dx is None else _ld(dx), _p(addsrc), 0 if addsrc is None else _ld(addsrc),
                                 _p(dw_tap), _p(yy), 0 if yy is None else _ld(yy), _p(yco), _p(ykk), 1 if yrelu else 0,
+                                _p(by), 0 if by is None else _ld(by), _p(bco), 1 if brelu else 0, _p(bpart),
                                 int(up2x), phases, _p(ws), nb, st)
         if dw_tap is not None and need_dx and _FFT_OVERLAP:
             # the two chains only share the spectrum of dy and are each latency-bound: the weight-gradient chain runs on a

@@ -40,7 +40,7 @@ typedef enum {
     GDN_ERR_LAUNCH = -4
 } gdn_status;
 
-/* Revision of this header (argument lists, struct layouts).  221: gdn_clock_probe_*.  220: gdn_conv_dgrad dx_up2x; gdn_bn_apply_up2x; bf16 tile id 12 (conv_ring2_bf16).  219: gdn_conv_wgrad_bf16 cfg 4 (wgrad_ring_bf16); gdn_fftconv_cgemm* measurement hooks; plan overrides in gdn_conv_geom.hints; gdn_gemm_x3_nt_packed / gdn_gemm_x3_ring_workspace_bytes removed (the measured-and-not-wired kernel now lives under tests/diag/).  218: gdn_gemm_x3_tn_splits.  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
+/* Revision of this header (argument lists, struct layouts).  222: gdn_fftconv_bwd bnb_*, gdn_fftconv_bnb_slots.  221: gdn_clock_probe_*.  220: gdn_conv_dgrad dx_up2x; gdn_bn_apply_up2x; bf16 tile id 12 (conv_ring2_bf16).  219: gdn_conv_wgrad_bf16 cfg 4 (wgrad_ring_bf16); gdn_fftconv_cgemm* measurement hooks; plan overrides in gdn_conv_geom.hints; gdn_gemm_x3_nt_packed / gdn_gemm_x3_ring_workspace_bytes removed (the measured-and-not-wired kernel now lives under tests/diag/).  218: gdn_gemm_x3_tn_splits.  217: gdn_conv_dgrad bnb_*.  216: gdn_conv_c1_fwd Cin.  215: GDN_HINT_NO_WINO_F4.  214: gdn_gemm_x3_nt_packed.  213: gdn_conv_c1_fwd dtypes / gdn_conv_c1_wgrad gw_bf16.  212: GDN_HINT_NO_X3 (replaces the GDN_X3 environment read).  211: gdn_gemm_x3_*.  210: gdn_conv_geom.hints, in_up2x / dx_up2x.  A binding checks it
  * for equality at load time (gdn_amd/_lib.py: ABI_VERSION). */
 int gdn_version(void);
 const char* gdn_strerror(int status);
@@ -217,6 +217,11 @@ int gdn_fftconv_fwd(const gdn_conv_geom* g, const float* x, int32_t ldx, const f
  * gradient of z = [relu](BN_train(dyb_y)) with dyb_y this layer's raw conv output, dyb_co = {scale, shift,
  * mean, invstd}[Cout] and dyb_kk = {k1, k2}[Cout] from gdn_bn_bwd_coeffs; the dy transform computes
  * dy = scale*(dz - k1 - xhat*k2) while loading, so dy itself is never written to memory.
+ * bnb_* (nullable; zero-padded layers, gdn_fftconv_bnb_slots(g) > 0 slots): dx is the final gradient of this layer's INPUT
+ * z = [relu](BN_train(bnb_y)) (bnb_y: the producer's raw conv output [B][H][W][Cin], pitch ld_bnb; bnb_co = {scale, shift,
+ * mean, invstd}[Cin]); the pass that writes dx also writes that BatchNorm's backward partial sums (sum dz, sum dz * xhat) to
+ * bnb_partial[slots][2][Cin] -- gdn_bn_bwd / gdn_bn_bwd_coeffs take them as ext_partial, and the stand-alone reduce pass
+ * over (dx, y) disappears (AE_model_unet.py:51,54 as consumed by the next conv of :50,53).
  * dx_up2x (as in_up2x of the forward; reflection-padded layers only, else GDN_ERR_UNSUPPORTED): dx, addsrc are
  * [B][H/2][W/2][Cin], the gradient of the LOW-resolution tensor the forward upsampled on load -- the pass that folds the
  * padded-domain gradient back onto the image also applies the adjoint of the interpolation (gather form, deterministic). */
@@ -225,8 +230,11 @@ size_t gdn_fftconv_bwd_workspace_bytes(const gdn_conv_geom* g);
 int gdn_fftconv_bwd(const gdn_conv_geom* g, const float* dy, int32_t ldy, const float* w,
                     const void* xf, float* dx, int32_t ldx, const float* addsrc, int32_t ld_add,
                     float* dw, const float* dyb_y, int32_t ld_dyb, const float* dyb_co,
-                    const float* dyb_kk, int32_t dyb_relu, int32_t dx_up2x, int32_t phases,
+                    const float* dyb_kk, int32_t dyb_relu,
+                    const float* bnb_y, int32_t ld_bnb, const float* bnb_co, int32_t bnb_relu, float* bnb_partial,
+                    int32_t dx_up2x, int32_t phases,
                     void* workspace, size_t workspace_bytes, void* stream);
+int64_t gdn_fftconv_bnb_slots(const gdn_conv_geom* g);
 /* Measurement hooks (bench.py roofline_cgemm): launch ONLY the per-bin complex GEMMs of the frequency-domain layer `g` on
  * whatever the workspace holds -- which: 0 forward (Y = X W), 1 data gradient, 2 the weight gradient's reduction over the
  * tiles; 1 and 2 use disjoint outputs and may run on two streams like gdn_fftconv_bwd's chains.  gdn_fftconv_cgemm_shape:

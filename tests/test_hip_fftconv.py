@@ -286,8 +286,8 @@ def test_input_affine_and_bn_backward_partials(gpu, path, k, C, B, H, W):
             close(got_dx, ref_dx, rtol=1e-4, atol_scale=1e-5, what="fft dyb dx relu=%s" % relu)
             close(dw1, dw0, rtol=1e-4, atol_scale=1e-5, what="fft dyb dw relu=%s" % relu)
             close(dgf, dg, rtol=1e-5, atol_scale=1e-6, what="dgamma"); close(dbf, db, rtol=1e-5, atol_scale=1e-6, what="dbeta")
-        return          # (the frequency-domain data gradient emits no BatchNorm partials: measured slower than the reduce pass)
-    slots = op.wino_bnb_slots(B, H, W)
+        # (round 6: the frequency-domain data gradient's gather pass emits the producer's partials too -- below)
+    slots = op.fft_bnb_slots(B, H, W) if path == "fft" else op.wino_bnb_slots(B, H, W)
     assert slots > 0
     for relu in (True, False):
         part = torch.full((slots, 2, C), float("nan"), device=gpu)

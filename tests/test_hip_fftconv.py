@@ -309,3 +309,21 @@ def test_input_affine_and_bn_backward_partials(gpu, path, k, C, B, H, W):
         close(r1, r0, rtol=1e-4, atol_scale=1e-5, what=path + " bn_bwd dy from partials")
         close(dg1, dg0, rtol=1e-4, atol_scale=1e-5, what="dgamma")
         close(db1, db0, rtol=1e-4, atol_scale=1e-5, what="dbeta")
+
+
+@pytest.mark.parametrize("C,k,B,H,W", [(64, 9, 1, 24, 1060), (128, 5, 1, 14, 1030)], ids=["k9_w1060", "k5_w1030"])
+def test_fftconv_wide_rows_take_the_two_kernel_inverse(gpu, C, k, B, H, W):
+    """Rows wider than the gather pass's x table (1024 pixels) keep the rounds 1-5 data-gradient inverse (ifft_cols -> S ->
+    two ordered ifft_rows_overlap launches) and emit no BatchNorm partials: the data gradient there must still equal the direct
+    kernel's, with and without an accumulated gradient."""
+    from gdn_amd import ops
+    gen = torch.Generator(device=gpu).manual_seed(C + k)
+    op = ops.Conv(C, C, k, 1, k // 2)
+    assert op.fft_ok(B, H, W, backward=True) and op.fft_bnb_slots(B, H, W) == 0
+    assert ops.Conv(C, C, k, 1, k // 2).fft_bnb_slots(2, 24, 64) > 0
+    w = torch.randn(k * k, C, C, device=gpu, generator=gen) / (C * k * k) ** 0.5
+    g = torch.randn(B, H, W, C, device=gpu, generator=gen)
+    skip = torch.randn(B, H, W, C, device=gpu, generator=gen)
+    ref = op.dgrad(g, ops.transpose_taps(w), (H, W))
+    close(op.fft_bwd(g, w, (H, W)), ref, rtol=1e-4, atol_scale=1e-5, what="wide-row dgrad vs direct")
+    close(op.fft_bwd(g, w, (H, W), addsrc=skip), ref + skip, rtol=1e-4, atol_scale=1e-5, what="wide-row dgrad + addsrc")
